@@ -1,0 +1,222 @@
+"""Seeded synthetic workload: full-size weights and PCM.
+
+There are no model weights and no audio on either box (reference `.gitignore:16`
+ignores `weights/`), so parity tests and `bench.py` run on deterministic synthetic
+tensors with the reference's names, shapes and on-disk conventions
+(reference `src/nemo-ggml.cpp:296-398`, `docs/TENSOR_SHAPES.md`,
+`scripts/convert_to_gguf.py:399-413`: pointwise conv squeezed to 2-D, depthwise conv
+stored as `(k, C)`).
+
+Generator: counter-based splitmix64 (no state, vectorised, reproducible from
+`(seed, tensor name, element index)` alone), values uniform in `[-a, a]` with
+`a = sqrt(3 / fan_in)` (variance `1/fan_in`), computed in float64 and rounded once
+to float32, so any implementation of splitmix64 reproduces the bytes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+D_MODEL = 1024
+N_HEADS = 8
+D_HEAD = 128
+D_FF = 4096
+N_MELS = 128
+N_BINS = 257
+N_FFT = 512
+WIN = 400
+HOP = 160
+SUB_CH = 256
+SUB_FLAT = 4352
+VOCAB = 1025
+BLANK = 1024
+HIDDEN = 640
+JOINT = 640
+LEFT_CTX = 70
+PRE_CACHE = 9
+SAMPLE_RATE = 16000
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode():
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def splitmix64(seed: int, n: int, offset: int = 0) -> np.ndarray:
+    """z_i = mix(seed + (offset+i+1)*GOLDEN), i in [0, n): uint64."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, n: int, offset: int = 0) -> np.ndarray:
+    """float64 in [0, 1) with 53 random bits."""
+    return (splitmix64(seed, n, offset) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+def _tensor(seed: int, name: str, shape, amp: float, center: float = 0.0) -> np.ndarray:
+    n = int(np.prod(shape))
+    s = seed ^ _fnv1a64(name)
+    out = np.empty(n, dtype=np.float32)
+    step = 1 << 22
+    for o in range(0, n, step):
+        k = min(step, n - o)
+        u = uniform01(s, k, o)
+        out[o:o + k] = (center + (2.0 * u - 1.0) * amp).astype(np.float32)
+    return out.reshape(shape)
+
+
+def mel_filterbank() -> np.ndarray:
+    """Deterministic triangular mel filterbank [128][257] (HTK mel, area-normalised).
+
+    Stands in for NeMo's `featurizer.fb`; any non-negative banded matrix exercises the
+    same arithmetic (reference `src/preprocessor.cpp:374-383`)."""
+    def hz2mel(f):
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+
+    def mel2hz(m):
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+
+    freqs = np.linspace(0.0, SAMPLE_RATE / 2, N_BINS)
+    pts = mel2hz(np.linspace(hz2mel(0.0), hz2mel(SAMPLE_RATE / 2), N_MELS + 2))
+    fb = np.zeros((N_MELS, N_BINS), dtype=np.float64)
+    for m in range(N_MELS):
+        lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
+        up = (freqs - lo) / (ce - lo)
+        dn = (hi - freqs) / (hi - ce)
+        fb[m] = np.maximum(0.0, np.minimum(up, dn)) * (2.0 / (hi - lo))
+    return fb.astype(np.float32)
+
+
+def hann_window() -> np.ndarray:
+    """Symmetric Hann-400 (`torch.hann_window(400, periodic=False)`)."""
+    n = np.arange(WIN, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (WIN - 1))).astype(np.float32)
+
+
+def layer_tensor_specs(kernel_size: int = 9):
+    """(suffix, shape, kind, fan_in) for one encoder layer."""
+    D, F = D_MODEL, D_FF
+    return [
+        ("norm_feed_forward1.weight", (D,), "ln_w", 0), ("norm_feed_forward1.bias", (D,), "bias", 0),
+        ("feed_forward1.linear1.weight", (F, D), "mat", D), ("feed_forward1.linear2.weight", (D, F), "mat", F),
+        ("norm_self_att.weight", (D,), "ln_w", 0), ("norm_self_att.bias", (D,), "bias", 0),
+        ("self_attn.linear_q.weight", (D, D), "mat", D), ("self_attn.linear_k.weight", (D, D), "mat", D),
+        ("self_attn.linear_v.weight", (D, D), "mat", D), ("self_attn.linear_pos.weight", (D, D), "mat", D),
+        ("self_attn.linear_out.weight", (D, D), "mat", D),
+        ("self_attn.pos_bias_u", (N_HEADS, D_HEAD), "posbias", 0),
+        ("self_attn.pos_bias_v", (N_HEADS, D_HEAD), "posbias", 0),
+        ("norm_conv.weight", (D,), "ln_w", 0), ("norm_conv.bias", (D,), "bias", 0),
+        ("conv.pointwise_conv1.weight", (2 * D, D), "mat", D),
+        ("conv.depthwise_conv.weight", (kernel_size, D), "mat", kernel_size),
+        ("conv.batch_norm.weight", (D,), "ln_w", 0), ("conv.batch_norm.bias", (D,), "bias", 0),
+        ("conv.pointwise_conv2.weight", (D, D), "mat", D),
+        ("norm_feed_forward2.weight", (D,), "ln_w", 0), ("norm_feed_forward2.bias", (D,), "bias", 0),
+        ("feed_forward2.linear1.weight", (F, D), "mat", D), ("feed_forward2.linear2.weight", (D, F), "mat", F),
+        ("norm_out.weight", (D,), "ln_w", 0), ("norm_out.bias", (D,), "bias", 0),
+    ]
+
+
+def global_tensor_specs(num_prompts: int = 0):
+    C = SUB_CH
+    specs = [
+        ("encoder.pre_encode.conv.0.weight", (C, 1, 3, 3), "mat", 9), ("encoder.pre_encode.conv.0.bias", (C,), "bias", 0),
+        ("encoder.pre_encode.conv.2.weight", (C, 1, 3, 3), "mat", 9), ("encoder.pre_encode.conv.2.bias", (C,), "bias", 0),
+        ("encoder.pre_encode.conv.3.weight", (C, C, 1, 1), "mat", C), ("encoder.pre_encode.conv.3.bias", (C,), "bias", 0),
+        ("encoder.pre_encode.conv.5.weight", (C, 1, 3, 3), "mat", 9), ("encoder.pre_encode.conv.5.bias", (C,), "bias", 0),
+        ("encoder.pre_encode.conv.6.weight", (C, C, 1, 1), "mat", C), ("encoder.pre_encode.conv.6.bias", (C,), "bias", 0),
+        ("encoder.pre_encode.out.weight", (D_MODEL, SUB_FLAT), "mat", SUB_FLAT), ("encoder.pre_encode.out.bias", (D_MODEL,), "bias", 0),
+        ("decoder.prediction.embed.weight", (VOCAB, HIDDEN), "embed", 1),
+    ]
+    for l in (0, 1):
+        p = "decoder.prediction.dec_rnn.lstm."
+        specs += [(p + f"weight_ih_l{l}", (4 * HIDDEN, HIDDEN), "mat", HIDDEN),
+                  (p + f"weight_hh_l{l}", (4 * HIDDEN, HIDDEN), "mat", HIDDEN),
+                  (p + f"bias_ih_l{l}", (4 * HIDDEN,), "bias", 0),
+                  (p + f"bias_hh_l{l}", (4 * HIDDEN,), "bias", 0)]
+    specs += [
+        ("joint.enc.weight", (JOINT, D_MODEL), "mat", D_MODEL), ("joint.enc.bias", (JOINT,), "bias", 0),
+        ("joint.pred.weight", (JOINT, HIDDEN), "mat", HIDDEN), ("joint.pred.bias", (JOINT,), "bias", 0),
+        ("joint.joint_net.2.weight", (VOCAB, JOINT), "mat", JOINT), ("joint.joint_net.2.bias", (VOCAB,), "jbias", 0),
+    ]
+    if num_prompts > 0:
+        specs += [
+            ("prompt_kernel.0.weight", (2048, D_MODEL + num_prompts), "mat", D_MODEL + num_prompts),
+            ("prompt_kernel.0.bias", (2048,), "bias", 0),
+            ("prompt_kernel.2.weight", (D_MODEL, 2048), "mat", 2048),
+            ("prompt_kernel.2.bias", (D_MODEL,), "bias", 0),
+        ]
+    return specs
+
+
+def _make(seed, name, shape, kind, fan_in, blank_bias):
+    if kind == "mat":
+        return _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)))
+    if kind == "embed":
+        w = _tensor(seed, name, shape, float(np.sqrt(3.0)))
+        w[BLANK] = 0.0  # padding row (nn.Embedding padding_idx = blank)
+        return w
+    if kind == "ln_w":
+        return _tensor(seed, name, shape, 0.05, center=1.0)
+    if kind == "bias":
+        return _tensor(seed, name, shape, 0.05)
+    if kind == "posbias":
+        return _tensor(seed, name, shape, 0.3)
+    if kind == "jbias":
+        b = _tensor(seed, name, shape, 0.05)
+        # Random joint weights give ~N(0,1) logits over 1025 classes; a trained model emits
+        # blank on most frames.  Raising the blank bias makes the synthetic emission rate
+        # realistic (measured ~0.33 tokens per 80 ms frame at +3.8) instead of 10 symbols per frame.
+        b[BLANK] += blank_bias
+        return b
+    raise ValueError(kind)
+
+
+def make_weights(n_layers: int = 24, seed: int = 0xC0FFEE, kernel_size: int = 9,
+                 num_prompts: int = 0, blank_bias: float = 3.8, layers=None) -> dict:
+    """name -> float32 ndarray for the whole model (2.4 GB at 24 layers).
+
+    `layers`: optional iterable of layer indices to materialise (default: all)."""
+    w = {
+        "preprocessor.featurizer.fb": mel_filterbank(),
+        "preprocessor.featurizer.window": hann_window(),
+    }
+    for name, shape, kind, fan_in in global_tensor_specs(num_prompts):
+        w[name] = _make(seed, name, shape, kind, fan_in, blank_bias)
+    for l in (range(n_layers) if layers is None else layers):
+        for suffix, shape, kind, fan_in in layer_tensor_specs(kernel_size):
+            name = f"encoder.layers.{l}.{suffix}"
+            w[name] = _make(seed, name, shape, kind, fan_in, blank_bias)
+    return w
+
+
+def make_pcm(stream: int, seconds: float, seed: int = 0xA5A50000) -> np.ndarray:
+    """int16 mono 16 kHz: 0.3*sin(2*pi*f_s*t)*env(t) + 0.05*N(0,1), f_s = 200 + 37*s Hz,
+    4 Hz raised-cosine envelope."""
+    n = int(round(seconds * SAMPLE_RATE))
+    t = np.arange(n, dtype=np.float64) / SAMPLE_RATE
+    f = 200.0 + 37.0 * (stream % 64)
+    env = 0.5 - 0.5 * np.cos(2.0 * np.pi * 4.0 * t)
+    u1 = uniform01(seed + stream, n, 0)
+    u2 = uniform01(seed + stream, n, n)
+    noise = np.sqrt(-2.0 * np.log(np.maximum(u1, 2.0 ** -53))) * np.cos(2.0 * np.pi * u2)
+    x = 0.3 * np.sin(2.0 * np.pi * f * t) * env + 0.05 * noise
+    return np.round(np.clip(x, -1.0, 1.0) * 32767.0).astype(np.int16)
+
+
+def chunk_mel_frames(right_context: int) -> int:
+    return PRE_CACHE + 8 * (1 + right_context)      # reference src/nemo-stream.h:65-72
+
+
+def shift_samples(right_context: int) -> int:
+    return HOP * 8 * (1 + right_context)            # reference src/nemo-stream.h:76-81
