@@ -1,0 +1,176 @@
+/*
+ * nemotron_asr_amd.h -- C ABI of the MI355X-native streaming Conformer-ASR forward path.
+ *
+ * Drop-in boundary for the hot path of m1el/nemotron-asr.cpp.  The
+ * reference has no plugin/FFI seam: the seam is the set of call sites where its stream
+ * manager touches ggml compute.  Each entry point below names the reference interface
+ * it replaces (paths relative to the reference root).  Plain pointers and sizes only;
+ * no C++ / torch types cross this boundary.  INTEGRATION.md shows the reference-side
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; nasr_last_error() gives the text
+ *     (reference convention: nullptr/false/"" + fprintf(stderr); we never abort or throw)
+ *   - not thread-safe: one host thread per engine (reference: one worker thread owns all
+ *     backend state, src/nemo-server.cpp:6-10); one engine per GPU
+ *   - PCM is s16le 16 kHz mono (src/transcribe_stream.cpp:13); mel is [frames][128] f32
+ *     row-major (src/preprocessor.cpp:370-381); encoder out is [T][1024] f32
+ *     (src/nemo-stream.cpp:1073-1075); tokens are int32 ids in [0, vocab-1)
+ *   - all streams passed to one call must share right_context (static shapes per R,
+ *     src/nemo-stream.h:15-20); each stream keeps its own caches and decoder state
+ */
+#ifndef NEMOTRON_ASR_AMD_H
+#define NEMOTRON_ASR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NASR_ABI_VERSION 1
+
+typedef struct nasr_engine nasr_engine; /* device weights + stream pool  (reference: nemo_context, src/nemo-ggml.h:240-252) */
+typedef struct nasr_stream nasr_stream; /* per-stream device state       (reference: nemo_stream_context, src/nemo-stream.h:177-262) */
+
+/* compute dtype of the encoder GEMMs / caches */
+enum { NASR_DTYPE_F32 = 0, NASR_DTYPE_BF16 = 1 };
+
+/* tensor element types arriving at the seam = GGUF/ggml type ids
+ * (scripts/convert_to_gguf.py:30-57).  Q8_0/Q4_0/F16 are dequantised at upload. */
+enum { NASR_TYPE_F32 = 0, NASR_TYPE_F16 = 1, NASR_TYPE_Q4_0 = 2, NASR_TYPE_Q8_0 = 8 };
+
+/* step flags */
+enum {
+    NASR_FLAG_PCM_DEVICE = 1u << 0, /* pcm[] are device pointers (inputs already resident in HBM) */
+    NASR_FLAG_NO_SYNC    = 1u << 1, /* do not copy tokens back / synchronise; poll with nasr_engine_collect() */
+};
+
+/* model hyper-parameters = the `nemo.*` GGUF keys read at src/nemo-ggml.cpp:108-142
+ * (+ kernel_size inferred from conv_dw_w->ne[1], :357-360) */
+typedef struct nasr_hparams {
+    int32_t n_mels;             /* 128  */
+    int32_t d_model;            /* 1024 */
+    int32_t n_heads;            /* 8    */
+    int32_t d_head;             /* 128  */
+    int32_t d_ff;               /* 4096 */
+    int32_t n_layers;           /* 24   */
+    int32_t vocab_size;         /* 1025 (blank = vocab_size-1) */
+    int32_t decoder_dim;        /* 640  */
+    int32_t joint_dim;          /* 640  */
+    int32_t subsampling_factor; /* 8    */
+    int32_t att_left_context;   /* 70   */
+    int32_t kernel_size;        /* 9    */
+    int32_t num_prompts;        /* 0 (English) or 128 (multilingual) */
+} nasr_hparams;
+
+/* one host tensor handed over by the GGUF loader: replaces the
+ * fread -> ggml_backend_tensor_set upload loop of src/nemo-ggml.cpp:257-283.
+ * ne[] is in ggml order (ne[0] fastest), names are the PyTorch names of :296-398. */
+typedef struct nasr_weight_desc {
+    const char *name;
+    int32_t     type;   /* NASR_TYPE_* */
+    int32_t     n_dims;
+    int64_t     ne[4];
+    const void *data;   /* host memory, only read during nasr_engine_create */
+} nasr_weight_desc;
+
+typedef struct nasr_stream_stats {
+    int64_t samples_in;        /* PCM samples pushed                                       */
+    int32_t chunks;            /* encoder steps run      (nemo_stream_context::total_chunks_processed) */
+    int32_t decode_iterations; /* LSTM+joint evaluations (::total_decode_iterations)       */
+    int32_t tokens;            /* tokens emitted so far                                    */
+    int32_t cache_valid_len;   /* (::cache_valid_len)                                      */
+    int32_t mel_frames_buffered;
+    int32_t reserved;
+} nasr_stream_stats;
+
+/* per-kernel-class timing collected with HIP events when profiling is enabled */
+typedef struct nasr_kernel_stat {
+    char     name[48];
+    int64_t  launches;
+    double   total_ms;
+    double   bytes;   /* algorithmic bytes moved by those launches (weights + activations) */
+    double   flops;   /* algorithmic FLOPs of those launches */
+} nasr_kernel_stat;
+
+const char *nasr_last_error(void);
+int nasr_abi_version(void);
+
+/* ---- engine: replaces nemo_init_with_backend's device side (src/nemo-ggml.cpp:448-495:
+ * backend init :35-81, tensor upload :238-292 incl. compute_pos_emb :17-32, :288-292)
+ * and nemo_free (:521-540).  max_streams sizes the per-stream state pool. ------------- */
+int  nasr_engine_create(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
+                        const nasr_weight_desc *weights, int n_weights, int max_streams);
+void nasr_engine_destroy(nasr_engine *e);
+
+/* ---- streams: replaces nemo_stream_init (src/nemo-stream.cpp:696-733 -> ::init :36-93:
+ * zeroed K/V/conv caches :320-325, decoder state zero + prev_token = blank :55-56,
+ * 9 zero mel frames :73-74, cache_valid_len = 0 :81), nemo_stream_reset (:1307-1311),
+ * nemo_stream_free (:1313-1317), nemo_stream_set_language (:735-749). ------------------ */
+int nasr_stream_create(nasr_engine *e, int right_context, int prompt_index, nasr_stream **out);
+int nasr_stream_reset(nasr_stream *s);
+int nasr_stream_destroy(nasr_stream *s);
+int nasr_stream_set_prompt(nasr_stream *s, int prompt_index);
+int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out);
+
+/* ---- the step: replaces nemo_stream_process_incremental (src/nemo-stream.cpp:1145-1206)
+ * for B streams at once = nemo_preprocessor_process (src/preprocessor.cpp:330-395) +
+ * every full chunk through process_mel_chunk_streaming (:1013-1128: encoder graph compute
+ * :1063, decode_one_step per frame :1107-1118) + the mel-buffer shift (:1189-1195).
+ * pcm[b] has n_samples[b] samples (0 allowed).  New token ids of stream b are written to
+ * tokens_out[b][0..n_tokens[b]) (at most tokens_cap[b]; the count is always the true count). */
+int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B,
+                     const int16_t *const *pcm, const int32_t *n_samples,
+                     int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens,
+                     uint32_t flags);
+
+/* debug/parity tap: same as nasr_engine_step but takes log-mel frames [n_frames][128] f32
+ * (host memory) and skips stage a-1, i.e. enters at the mel_buffer append of :1162. */
+int nasr_engine_step_mel(nasr_engine *e, nasr_stream *const *streams, int B,
+                         const float *const *mel, const int32_t *n_frames,
+                         int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens,
+                         uint32_t flags);
+
+/* tail flush: replaces nemo_stream_finalize (src/nemo-stream.cpp:1217-1293): if more than
+ * 9 mel frames are buffered, n_valid = (frames-9)/8 outputs of one zero-padded step. */
+int nasr_engine_finalize(nasr_engine *e, nasr_stream *const *streams, int B,
+                         int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens);
+
+/* with NASR_FLAG_NO_SYNC: wait for outstanding work and fetch the tokens produced since the
+ * last collect (replaces nemo_stream_get_tokens, src/nemo-stream.cpp:1301-1305, as a delta) */
+int nasr_engine_collect(nasr_engine *e, nasr_stream *const *streams, int B,
+                        int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens);
+
+/* ---- parity taps (reference: append_dump_tensor, src/nemo-stream.cpp:982-1010) --------- */
+enum {
+    NASR_TAP_MEL         = 0, /* log-mel frames produced by the last step call  [n][128]       */
+    NASR_TAP_SUBSAMPLED  = 1, /* conformer input of the last chunk (after drop-2) [T][1024]     */
+    NASR_TAP_LAYER_OUT   = 2, /* output of layer `index` for the last chunk      [T][1024]     */
+    NASR_TAP_ENCODER_OUT = 3, /* encoder output of the last chunk                [T][1024]     */
+    NASR_TAP_K_CACHE     = 4, /* K cache of layer `index`, logical order         [70][1024]    */
+    NASR_TAP_V_CACHE     = 5,
+    NASR_TAP_CONV_CACHE  = 6, /*                                                 [ks-1][1024]  */
+    NASR_TAP_DEC_STATE   = 7, /* h[2][640], c[2][640], then prev_token as float                */
+};
+/* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
+int nasr_engine_set_debug(nasr_engine *e, int enable);
+/* returns the number of floats written (<= cap) or <0 */
+int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, float *out, int64_t cap);
+
+/* ---- measurement: per-kernel-class HIP-event timing on the engine's own
+ * stream.  Replaces the std::chrono timers of src/nemo-stream.h:236-244. ---------------- */
+int nasr_engine_profile(nasr_engine *e, int enable); /* enable also resets the counters */
+int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, int cap); /* returns count */
+/* raw hipStream_t of the engine (for external event timing) */
+void *nasr_engine_hip_stream(nasr_engine *e);
+/* device malloc/free/copy helpers so a host written without HIP can keep PCM resident */
+int nasr_device_alloc(nasr_engine *e, void **out, int64_t bytes);
+int nasr_device_free(nasr_engine *e, void *p);
+int nasr_device_upload(nasr_engine *e, void *dst_device, const void *src_host, int64_t bytes);
+int nasr_engine_synchronize(nasr_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMOTRON_ASR_AMD_H */

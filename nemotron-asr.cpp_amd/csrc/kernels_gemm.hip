@@ -1,0 +1,387 @@
+// kernels_gemm.hip -- the linear layers of the encoder (reference: every ggml_mul_mat of
+// src/nemo-stream.cpp:485-487,:570,:599-601,:654,:677 and src/nemo-ggml.cpp:983,:999,:1020).
+//
+// out[m][n] = sum_k A[m][k] * W[n][k]   (W stored [out][in] like PyTorch / GGUF)
+//
+// bf16 path (gfx950 MFMA v_mfma_f32_16x16x32_bf16, f32 accumulate):
+//   * weights are PRE-PACKED at upload into MFMA A-fragment order: tile (nt, kt) of
+//     16 n x 32 k is 1 KiB, lane l = q*16 + r holds W[nt*16+r][kt*32+q*8 .. +8).  One
+//     wave-load of a tile is a single fully coalesced 1 KiB read -- the layout is chosen
+//     for the access pattern, not inherited from the file format.
+//   * the weight tile is the MFMA A operand (rows = n), activations are the B operand
+//     (cols = m), so D[n][m]: lane holds 4 consecutive n for one m -> row-major stores.
+//   * k_gemm_skinny (M <= 64): weight-streaming kernel, HBM-bound.  One 16-column tile
+//     per workgroup, K split over the 4 waves (and over blockIdx.y for split-K);
+//     activations (a few KB, L2 resident) go straight to registers; no LDS in the loop.
+//   * k_gemm_tiled (M > 64): 128 rows x 128 cols per workgroup, activation panel staged
+//     through XOR-swizzled LDS, weights straight from the packed layout.
+// f32 path (parity mode): plain LDS-tiled FMA kernel, k ascending, deterministic.
+#include "nasr_internal.h"
+
+namespace nasr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+
+__device__ __forceinline__ const char *a_row_ptr(const GemmParams &p, int m, int elt) {
+    size_t off;
+    if (p.rows_per_batch > 0) {
+        int b = m / p.rows_per_batch, i = m - b * p.rows_per_batch;
+        off = (size_t)b * p.batch_stride + (size_t)(p.row_offset + i) * p.lda;
+    } else {
+        off = (size_t)m * p.lda;
+    }
+    return (const char *)p.A + off * elt;
+}
+
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    r.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    return r;
+}
+
+// epilogue for 4 consecutive n (n0 % 4 == 0) of row m; ACT_BF16 selects the act dtype
+template <bool ACT_BF16>
+__device__ __forceinline__ void epi_quad(const GemmParams &p, int split, int m, int n0, float v0,
+                                         float v1, float v2, float v3) {
+    if (m >= p.M) return;
+    switch (p.epi) {
+    case EPI_PART_F32: {
+        float *o = p.out_f32 + ((size_t)split * p.M + m) * p.ldo + n0;
+        *(float4 *)o = make_float4(v0, v1, v2, v3);
+    } break;
+    case EPI_SILU_ACT: {
+        v0 = silu_f(v0); v1 = silu_f(v1); v2 = silu_f(v2); v3 = silu_f(v3);
+        if (ACT_BF16) *(uint2 *)((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0) = pack4_bf16(v0, v1, v2, v3);
+        else *(float4 *)((float *)p.out_act + (size_t)m * p.ldo_act + n0) = make_float4(v0, v1, v2, v3);
+    } break;
+    case EPI_QKV: {
+        int which = n0 >> 10, col = n0 & 1023;
+        if (which == 0) {
+            *(float4 *)(p.q_out + (size_t)m * D + col) = make_float4(v0, v1, v2, v3);
+        } else {
+            int b = m / p.T, i = m - b * p.T;
+            RowDesc rd = p.rows[b];
+            int ring = rd.kv_head + LCTX + i;
+            if (ring >= KVC) ring -= KVC;
+            size_t off = (size_t)rd.slot * p.kv_slot_stride + ((size_t)(which - 1) * KVC + ring) * D + col;
+            if (ACT_BF16) *(uint2 *)((bf16_t *)p.kv_pool + off) = pack4_bf16(v0, v1, v2, v3);
+            else *(float4 *)((float *)p.kv_pool + off) = make_float4(v0, v1, v2, v3);
+        }
+    } break;
+    case EPI_GLU: {   // rows were interleaved at upload: (2c, 2c+1) = (value c, gate c)
+        float *o = p.out_f32 + (size_t)m * p.ldo + (n0 >> 1);
+        *(float2 *)o = make_float2(v0 * sigmoid_f(v1), v2 * sigmoid_f(v3));
+    } break;
+    case EPI_BIAS_F32: {
+        const float4 b = *(const float4 *)(p.bias + n0);
+        *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) = make_float4(v0 + b.x, v1 + b.y, v2 + b.z, v3 + b.w);
+    } break;
+    case EPI_BIAS_RELU_F32: {
+        const float4 b = *(const float4 *)(p.bias + n0);
+        *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) =
+            make_float4(fmaxf(v0 + b.x, 0.f), fmaxf(v1 + b.y, 0.f), fmaxf(v2 + b.z, 0.f), fmaxf(v3 + b.w, 0.f));
+    } break;
+    case EPI_BIAS_RELU_ACT:
+    case EPI_BIAS_ACT: {
+        const float4 b = *(const float4 *)(p.bias + n0);
+        v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+        if (p.epi == EPI_BIAS_RELU_ACT) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (ACT_BF16) *(uint2 *)((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0) = pack4_bf16(v0, v1, v2, v3);
+        else *(float4 *)((float *)p.out_act + (size_t)m * p.ldo_act + n0) = make_float4(v0, v1, v2, v3);
+    } break;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// skinny: M <= 16*MT.  grid = (N/16, splits), block = 256 (4 waves split K).
+// ------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
+    __shared__ float red[4][MT][64][4];
+    const int nt = blockIdx.x, split = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5;
+    const int t0 = (int)((long)KT * split / p.splits), t1 = (int)((long)KT * (split + 1) / p.splits);
+    const int nts = t1 - t0;
+    const int w0 = t0 + nts * wave / 4, w1 = t0 + nts * (wave + 1) / 4;
+
+    const u32x4 *wp = (const u32x4 *)p.W + (size_t)nt * KT * 64 + lane;
+    // Rows >= M read a valid row (their MFMA columns are independent and never stored).
+    const char *arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = mt * 16 + r;
+        arow[mt] = a_row_ptr(p, m < p.M ? m : p.M - 1, 2) + q * 16;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int U = 8;   // weight tiles in flight per wave (8 KiB)
+    int kt = w0;
+    for (; kt + U <= w1; kt += U) {
+        u32x4 wv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) wv[u] = __builtin_nontemporal_load(wp + (size_t)(kt + u) * 64);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, wv[u]);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const uint4 av = *(const uint4 *)(arow[mt] + (size_t)(kt + u) * 64);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, av), acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    for (; kt < w1; kt++) {
+        const u32x4 wv = __builtin_nontemporal_load(wp + (size_t)kt * 64);
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const uint4 av = *(const uint4 *)(arow[mt] + (size_t)kt * 64);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, av), acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) red[wave][mt][lane][j] = acc[mt][j];
+    __syncthreads();
+    // wave w finishes m-tile w (MT <= 4)
+    if (wave < MT) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = ((red[0][wave][lane][j] + red[1][wave][lane][j]) + red[2][wave][lane][j]) + red[3][wave][lane][j];
+        epi_quad<true>(p, split, wave * 16 + r, nt * 16 + q * 4, v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// tiled: 128 rows x 128 cols per workgroup (4 waves x 2 n-tiles x 8 m-tiles), K chunks of
+// 64 through a double-buffered XOR-swizzled LDS panel.  grid = (N/128, ceil(M/128), splits)
+// flattened with an XCD-aware remap so that blocks sharing weight columns share an L2.
+// ------------------------------------------------------------------------------------
+constexpr int TM = 128, TKC = 64;
+
+__device__ __forceinline__ int panel_off(int row, int chunk) {  // byte offset in a [128][64] bf16 panel
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tiled(GemmParams p, int n_groups, int m_chunks) {
+    __shared__ __attribute__((aligned(16))) char panel[2][TM * TKC * 2];
+    // XCD-aware bijective remap of the flat block id (8 XCDs, round-robin dispatch)
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks;
+    const int rest = id / m_chunks;
+    const int ng = rest % n_groups, split = rest / n_groups;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5;
+    const int kc_total = KT >> 1;                                   // chunks of 64
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int m0 = mc * TM;
+    const int ntile0 = (ng * 4 + wave) * 2;
+    const uint4 *wp0 = (const uint4 *)p.W + (size_t)ntile0 * KT * 64 + lane;
+    const uint4 *wp1 = wp0 + (size_t)KT * 64;
+
+    // panel loader: thread t -> row t/2, chunks (t&1)*4 .. +4
+    const int lrow = threadIdx.x >> 1, lhalf = threadIdx.x & 1;
+    const bool lok = (m0 + lrow) < p.M;
+    const char *lsrc = a_row_ptr(p, lok ? m0 + lrow : 0, 2) + lhalf * 64;
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 pre[4];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) pre[i] = lok ? *(const uint4 *)(lsrc + (size_t)kc * 128 + i * 16) : make_uint4(0, 0, 0, 0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) *(uint4 *)(panel[buf] + panel_off(lrow, lhalf * 4 + i)) = pre[i];
+    };
+    int cur = 0;
+    if (c0 < c1) { gload(c0); lstore(0); }
+    __syncthreads();
+    for (int kc = c0; kc < c1; kc++) {
+        const bool more = kc + 1 < c1;
+        if (more) gload(kc + 1);
+        uint4 w[2][2];
+        w[0][0] = wp0[(size_t)(2 * kc) * 64];
+        w[0][1] = wp0[(size_t)(2 * kc + 1) * 64];
+        w[1][0] = wp1[(size_t)(2 * kc) * 64];
+        w[1][1] = wp1[(size_t)(2 * kc + 1) * 64];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++) {
+                uint4 bv = *(const uint4 *)(panel[cur] + panel_off(mt * 16 + r, k2 * 4 + q));
+                bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+            }
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++)
+            epi_quad<true>(p, split, m0 + mt * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1],
+                           acc[j][mt][2], acc[j][mt][3]);
+}
+
+void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
+    GemmParams p = p0;
+    if (p.splits < 1) p.splits = 1;
+    if (p.M <= 64) {
+        dim3 grid(p.N / 16, p.splits);
+        if (p.M <= 16) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, st, p);
+        else if (p.M <= 32) hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_gemm_skinny<4>, grid, dim3(256), 0, st, p);
+    } else {
+        int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+        dim3 grid(n_groups * m_chunks * p.splits);
+        hipLaunchKernelGGL(k_gemm_tiled, grid, dim3(256), 0, st, p, n_groups, m_chunks);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// f32 parity kernel: 64 n x 16 m per workgroup, K chunks of 32, k ascending.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void epi_elem_f32(const GemmParams &p, int m, int n, float v, float vpair) {
+    if (m >= p.M) return;
+    switch (p.epi) {
+    case EPI_PART_F32: p.out_f32[(size_t)m * p.ldo + n] = v; break;
+    case EPI_SILU_ACT: ((float *)p.out_act)[(size_t)m * p.ldo_act + n] = silu_f(v); break;
+    case EPI_QKV: {
+        int which = n >> 10, col = n & 1023;
+        if (which == 0) p.q_out[(size_t)m * D + col] = v;
+        else {
+            int b = m / p.T, i = m - b * p.T;
+            RowDesc rd = p.rows[b];
+            int ring = rd.kv_head + LCTX + i;
+            if (ring >= KVC) ring -= KVC;
+            ((float *)p.kv_pool)[(size_t)rd.slot * p.kv_slot_stride + ((size_t)(which - 1) * KVC + ring) * D + col] = v;
+        }
+    } break;
+    case EPI_GLU: if ((n & 1) == 0) p.out_f32[(size_t)m * p.ldo + (n >> 1)] = v * sigmoid_f(vpair); break;
+    case EPI_BIAS_F32: p.out_f32[(size_t)m * p.ldo + n] = v + p.bias[n]; break;
+    case EPI_BIAS_RELU_F32: p.out_f32[(size_t)m * p.ldo + n] = fmaxf(v + p.bias[n], 0.f); break;
+    case EPI_BIAS_RELU_ACT: ((float *)p.out_act)[(size_t)m * p.ldo_act + n] = fmaxf(v + p.bias[n], 0.f); break;
+    case EPI_BIAS_ACT: ((float *)p.out_act)[(size_t)m * p.ldo_act + n] = v + p.bias[n]; break;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmParams p) {
+    __shared__ float As[16][33];
+    __shared__ float Ws[64][33];
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 16;
+    const int tn = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const float *W = (const float *)p.W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += 32) {
+        // A tile: 16 x 32 = 512 elements, 2 per thread
+        for (int e = threadIdx.x; e < 512; e += 256) {
+            int mm = e >> 5, kk = e & 31;
+            float v = 0.f;
+            if (m0 + mm < p.M) v = ((const float *)a_row_ptr(p, m0 + mm, 4))[k0 + kk];
+            As[mm][kk] = v;
+        }
+        for (int e = threadIdx.x; e < 2048; e += 256) {
+            int nn = e >> 5, kk = e & 31;
+            Ws[nn][kk] = W[(size_t)(n0 + nn) * p.K + k0 + kk];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; kk++) {
+            float w = Ws[tn][kk];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = fmaf(As[tg * 4 + j][kk], w, acc[j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float vp = __shfl_xor(acc[j], 1);
+        epi_elem_f32(p, m0 + tg * 4 + j, n0 + tn, acc[j], vp);
+    }
+}
+
+void launch_gemm_f32(const GemmParams &p0, hipStream_t st) {
+    GemmParams p = p0;
+    p.splits = 1;
+    dim3 grid(p.N / 64, (p.M + 15) / 16);
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------
+// upload-time layout kernels
+// ------------------------------------------------------------------------------------
+__global__ void k_pack_weight_bf16(const float *w, bf16_t *packed, int N, int K) {
+    const int KT = K >> 5;
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element group
+    size_t total = (size_t)(N >> 4) * KT * 64;
+    if (g >= total) return;
+    int lane = (int)(g & 63);
+    size_t tile = g >> 6;
+    int kt = (int)(tile % KT), nt = (int)(tile / KT);
+    int q = lane >> 4, r = lane & 15;
+    const float *src = w + (size_t)(nt * 16 + r) * K + kt * 32 + q * 8;
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = f32_to_bf16(src[j]);
+    *(uint4 *)(packed + g * 8) = *(const uint4 *)o;
+}
+
+void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st) {
+    size_t total = (size_t)(N >> 4) * (K >> 5) * 64;
+    hipLaunchKernelGGL(k_pack_weight_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_f32, packed, N, K);
+}
+
+__global__ void k_f32_to_bf16(const float *in, bf16_t *out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16(in[i]);
+}
+void launch_f32_to_bf16(const float *in, bf16_t *out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+}
+
+__global__ void k_fill_f32(float *p, float v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_f32(float *p, float v, int64_t n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);
+}
+
+__global__ void k_relu(float *x, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.f);
+}
+void launch_relu(float *x, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
+}
+
+}  // namespace nasr

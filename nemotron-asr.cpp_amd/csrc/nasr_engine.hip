@@ -1,0 +1,1290 @@
+// nasr_engine.hip -- host side of the MI355X engine: the C ABI of include/nemotron_asr_amd.h.
+//
+// Owns device weights (re-laid-out at upload), the per-stream state pool (K/V rings, conv
+// caches, LSTM state, audio/mel rings) and the per-step launch sequence.  The chunk/shift
+// arithmetic of the reference's stream manager (src/nemo-stream.cpp:1145-1293,
+// src/nemo-stream.h:65-100) is mirrored on the host: every count it needs is a pure
+// function of the number of samples pushed, so no device read-back is needed to schedule.
+#include "nasr_internal.h"
+#include "nemotron_asr_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace nasr;
+
+static thread_local char g_err[512] = "";
+static int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+#define HIPCHK(x)                                                                           \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *nasr_last_error(void) { return g_err; }
+extern "C" int nasr_abi_version(void) { return NASR_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------
+struct LayerW {
+    float *ln_ff1_w, *ln_ff1_b, *ln_att_w, *ln_att_b, *ln_conv_w, *ln_conv_b, *ln_ff2_w, *ln_ff2_b, *ln_out_w, *ln_out_b;
+    void *ff1_w1, *ff1_w2, *wqkv, *wo, *pw1, *pw2, *ff2_w1, *ff2_w2;   // packed bf16 or f32 [N][K]
+    float *wpos_f32;                                                    // [1024][1024] f32 (load-time pos projection)
+    float *bias_u, *bias_v, *dw, *cln_w, *cln_b;
+    void *posproj[TMAX + 1];                                            // per T: [70+2T-1][1024] act dtype
+};
+
+struct Prof {
+    struct Rec { int cat; hipEvent_t a, b; double bytes, flops; };
+    bool on = false;
+    std::vector<std::string> names;
+    std::vector<nasr_kernel_stat> stats;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    int cat(const char *n) {
+        for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return (int)i;
+        names.push_back(n);
+        nasr_kernel_stat s;
+        memset(&s, 0, sizeof(s));
+        snprintf(s.name, sizeof(s.name), "%s", n);
+        stats.push_back(s);
+        return (int)names.size() - 1;
+    }
+};
+
+struct nasr_stream {
+    nasr_engine *e;
+    int slot, R, T, prompt;
+    // host mirror of the stream manager state (reference nemo_stream_context)
+    int abuf_cnt, abuf_par;          // samples waiting in the audio buffer (pre-seeded 256 zeros)
+    int mel_start, mel_count;        // mel ring window
+    int valid_len, kv_head, cc_par;  // cache_valid_len, K/V ring head, conv-cache parity
+    int chunks, tok_read;
+    int64_t samples_in;
+    int last_T;                      // rows of the last chunk (for taps)
+    bool alive;
+};
+
+struct nasr_engine {
+    int device = 0, dtype = 0, max_streams = 0;
+    nasr_hparams hp;
+    bool bf16 = false;
+    int esz = 4;
+    hipStream_t st = nullptr;
+    // front-end constants
+    float *window = nullptr, *fbT = nullptr, *cos_t = nullptr, *sin_t = nullptr;
+    float *w0t, *b0, *w2t, *b2, *b3, *w5t, *b5, *b6, *sub_out_b;
+    void *w3, *w6, *sub_out_w;
+    std::vector<LayerW> L;
+    float *embed, *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2], *jenc_w, *jenc_b, *pred_w, *pred_b, *out_w, *out_b;
+    float *pk1a = nullptr, *pk1p = nullptr, *pk1_b = nullptr, *pk2_w = nullptr, *pk2_b = nullptr;
+    // state pools
+    float *abuf, *last_sample, *mel_ring;
+    std::vector<void *> kv_pool;     // per layer [slot][2][KVC][1024] act dtype
+    std::vector<float *> cc_pool;    // per layer [slot][2][ks-1][1024]
+    float *dec_h, *dec_c;
+    DecCtrl *ctrl;
+    int *tok_ring;
+    // workspace (sized for max_streams x TMAX rows)
+    float *x, *part, *q, *glu, *encproj, *sub_a, *hfuse;
+    void *a, *hbuf, *ctx, *cbuf, *sub_b;
+    float *jact;
+    unsigned long long *key;
+    int *n_active;
+    int *collect_dev;                // [B][1+COLLECT_STRIDE]
+    // descriptor staging
+    char *pin = nullptr; size_t pin_cap = 0, pin_off = 0;
+    char *ddesc = nullptr; size_t ddesc_cap = 0, ddesc_off = 0;
+    int16_t *pcm_stage = nullptr; size_t pcm_stage_cap = 0;
+    float *mel_stage = nullptr; size_t mel_stage_cap = 0;
+    // debug taps
+    bool debug = false;
+    float *tap_mel = nullptr; int tap_mel_cap = 0;      // [max_streams][tap_mel_cap][128] by batch row
+    float *tap_sub = nullptr, *tap_layers = nullptr, *tap_enc = nullptr;  // [slot][...]
+    std::vector<int> tap_mel_frames;                     // per slot: frames captured in last call
+    std::vector<int> tap_mel_row;
+    std::vector<nasr_stream *> slots;
+    std::vector<void *> allocs;
+    Prof prof;
+};
+
+static const int COLLECT_STRIDE = 64;
+
+template <typename Tp>
+static int dalloc(nasr_engine *e, Tp **out, size_t n_elems) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n_elems * sizeof(Tp), 16);
+    HIPCHK(hipMalloc(&p, bytes));
+    e->allocs.push_back(p);
+    *out = (Tp *)p;
+    return 0;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+static void prof_flush(nasr_engine *e) {
+    Prof &pf = e->prof;
+    if (pf.pending.empty()) return;
+    hipStreamSynchronize(e->st);
+    for (auto &r : pf.pending) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        nasr_kernel_stat &s = pf.stats[r.cat];
+        s.launches++;
+        s.total_ms += ms;
+        s.bytes += r.bytes;
+        s.flops += r.flops;
+        pf.pool.push_back(r.a);
+        pf.pool.push_back(r.b);
+    }
+    pf.pending.clear();
+}
+struct ProfScope {
+    nasr_engine *e; int cat = -1; hipEvent_t a = nullptr; double bytes, flops;
+    ProfScope(nasr_engine *e_, const char *name, double bytes_ = 0, double flops_ = 0) : e(e_), bytes(bytes_), flops(flops_) {
+        if (!e->prof.on) return;
+        Prof &pf = e->prof;
+        if (pf.pending.size() >= 4096) prof_flush(e);
+        cat = pf.cat(name);
+        hipEvent_t b;
+        if (pf.pool.size() >= 2) { a = pf.pool.back(); pf.pool.pop_back(); b = pf.pool.back(); pf.pool.pop_back(); }
+        else { hipEventCreate(&a); hipEventCreate(&b); }
+        evb = b;
+        hipEventRecord(a, e->st);
+    }
+    ~ProfScope() {
+        if (cat < 0) return;
+        hipEventRecord(evb, e->st);
+        e->prof.pending.push_back({cat, a, evb, bytes, flops});
+    }
+    hipEvent_t evb = nullptr;
+};
+
+// ---- host helpers: dequantisation of GGUF tensor types at upload ---------------------------------
+static float f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ff, f;
+    if (exp == 0) {
+        if (man == 0) f = sign;
+        else {
+            exp = 127 - 15 + 1;
+            while (!(man & 0x400)) { man <<= 1; exp--; }
+            man &= 0x3ff;
+            f = sign | (exp << 23) | (man << 13);
+        }
+    } else if (exp == 31) f = sign | 0x7f800000u | (man << 13);
+    else f = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float r;
+    memcpy(&r, &f, 4);
+    return r;
+}
+
+// numel of a desc
+static int64_t desc_numel(const nasr_weight_desc &d) {
+    int64_t n = 1;
+    for (int i = 0; i < d.n_dims && i < 4; i++) n *= d.ne[i];
+    return n;
+}
+
+// returns f32 host copy (dequantised); layouts per scripts/convert_to_gguf.py:118-204
+static int to_f32(const nasr_weight_desc &d, std::vector<float> &out) {
+    const int64_t n = desc_numel(d);
+    out.resize((size_t)n);
+    switch (d.type) {
+    case NASR_TYPE_F32: memcpy(out.data(), d.data, (size_t)n * 4); return 0;
+    case NASR_TYPE_F16: {
+        const uint16_t *s = (const uint16_t *)d.data;
+        for (int64_t i = 0; i < n; i++) out[(size_t)i] = f16_to_f32(s[i]);
+        return 0;
+    }
+    case NASR_TYPE_Q8_0: {   // 34-byte blocks: f16 scale + 32 x int8
+        if (n % 32) return fail("%s: Q8_0 numel not a multiple of 32", d.name);
+        const uint8_t *s = (const uint8_t *)d.data;
+        for (int64_t b = 0; b < n / 32; b++) {
+            uint16_t hs; memcpy(&hs, s + b * 34, 2);
+            const float sc = f16_to_f32(hs);
+            const int8_t *qv = (const int8_t *)(s + b * 34 + 2);
+            for (int i = 0; i < 32; i++) out[(size_t)(b * 32 + i)] = sc * (float)qv[i];
+        }
+        return 0;
+    }
+    case NASR_TYPE_Q4_0: {   // 18-byte blocks: f16 scale + 16 bytes; low nibbles = elems 0..15, high = 16..31
+        if (n % 32) return fail("%s: Q4_0 numel not a multiple of 32", d.name);
+        const uint8_t *s = (const uint8_t *)d.data;
+        for (int64_t b = 0; b < n / 32; b++) {
+            uint16_t hs; memcpy(&hs, s + b * 18, 2);
+            const float sc = f16_to_f32(hs);
+            const uint8_t *qv = s + b * 18 + 2;
+            for (int i = 0; i < 16; i++) {
+                out[(size_t)(b * 32 + i)] = sc * (float)((int)(qv[i] & 0xf) - 8);
+                out[(size_t)(b * 32 + 16 + i)] = sc * (float)((int)(qv[i] >> 4) - 8);
+            }
+        }
+        return 0;
+    }
+    }
+    return fail("%s: unsupported tensor type %d", d.name, d.type);
+}
+
+struct Loader {
+    nasr_engine *e;
+    std::map<std::string, const nasr_weight_desc *> by_name;
+    float *scratch = nullptr; size_t scratch_cap = 0;   // device f32 staging for packing
+
+    int get(const std::string &name, int64_t numel, std::vector<float> &out) {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) return fail("missing tensor: %s", name.c_str());
+        if (desc_numel(*it->second) != numel)
+            return fail("%s: has %lld elements, expected %lld", name.c_str(), (long long)desc_numel(*it->second), (long long)numel);
+        return to_f32(*it->second, out);
+    }
+    // plain f32 vector / small tensor
+    int vec(const std::string &name, int64_t numel, float **dev) {
+        std::vector<float> h;
+        if (get(name, numel, h)) return -1;
+        if (dalloc(e, dev, (size_t)numel)) return -1;
+        HIPCHK(hipMemcpy(*dev, h.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
+        return 0;
+    }
+    int upload_vec(const std::vector<float> &h, float **dev) {
+        if (dalloc(e, dev, h.size())) return -1;
+        HIPCHK(hipMemcpy(*dev, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        return 0;
+    }
+    // matrix [N][K] f32 host -> engine GEMM layout (packed bf16 tiles, or f32 row-major)
+    int matrix(const std::vector<float> &h, int N, int K, void **dev) {
+        const size_t n = (size_t)N * K;
+        if (!e->bf16) {
+            float *d;
+            if (dalloc(e, &d, n)) return -1;
+            HIPCHK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+            *dev = d;
+            return 0;
+        }
+        if (n > scratch_cap) {
+            if (scratch) hipFree(scratch);
+            HIPCHK(hipMalloc((void **)&scratch, n * 4));
+            scratch_cap = n;
+        }
+        HIPCHK(hipMemcpy(scratch, h.data(), n * 4, hipMemcpyHostToDevice));
+        bf16_t *d;
+        if (dalloc(e, &d, n)) return -1;
+        launch_pack_weight_bf16(scratch, d, N, K, e->st);
+        HIPCHK(hipStreamSynchronize(e->st));
+        *dev = d;
+        return 0;
+    }
+    int matrix_named(const std::string &name, int N, int K, void **dev) {
+        std::vector<float> h;
+        if (get(name, (int64_t)N * K, h)) return -1;
+        return matrix(h, N, K, dev);
+    }
+};
+
+static void transpose_9x256(const std::vector<float> &w /*[256][9]*/, std::vector<float> &t /*[9][256]*/) {
+    t.resize(9 * SUBC);
+    for (int c = 0; c < SUBC; c++)
+        for (int k = 0; k < 9; k++) t[(size_t)k * SUBC + c] = w[(size_t)c * 9 + k];
+}
+
+static void host_pos_emb(int position, float *out) {   // reference src/nemo-ggml.cpp:17-32
+    const float p = (float)position;
+    for (int i = 0; i < D; i += 2) {
+        const float div_term = std::exp(-(float)i * std::log(10000.0f) / (float)D);
+        out[i] = std::sin(p * div_term);
+        out[i + 1] = std::cos(p * div_term);
+    }
+}
+
+static int load_weights(nasr_engine *e, const nasr_weight_desc *w, int n_w) {
+    Loader ld;
+    ld.e = e;
+    for (int i = 0; i < n_w; i++) {
+        if (!w[i].name || !w[i].data) return fail("weight %d: null name/data", i);
+        ld.by_name[w[i].name] = &w[i];
+    }
+    std::vector<float> h, t;
+    // ---- a-1 constants: padded window, transposed filterbank, twiddles (src/preprocessor.cpp:80-110,:296-299)
+    {
+        if (ld.get("preprocessor.featurizer.window", WIN, h)) return -1;
+        std::vector<float> win(NFFT, 0.0f);
+        memcpy(win.data() + (NFFT - WIN) / 2, h.data(), WIN * 4);
+        if (ld.upload_vec(win, &e->window)) return -1;
+        if (ld.get("preprocessor.featurizer.fb", (int64_t)NMEL * NBINS, h)) return -1;
+        std::vector<float> fbT((size_t)NBINS * NMEL);
+        for (int m = 0; m < NMEL; m++)
+            for (int k = 0; k < NBINS; k++) fbT[(size_t)k * NMEL + m] = h[(size_t)m * NBINS + k];
+        if (ld.upload_vec(fbT, &e->fbT)) return -1;
+        std::vector<float> ct(NFFT), sn(NFFT);
+        for (int i = 0; i < NFFT; i++) {
+            const float theta = (2.0f * (float)M_PI * (float)i) / (float)NFFT;
+            sn[i] = sinf(theta);
+            ct[i] = cosf(theta);
+        }
+        if (ld.upload_vec(ct, &e->cos_t) || ld.upload_vec(sn, &e->sin_t)) return -1;
+    }
+    // ---- a-2 subsampling -----------------------------------------------------------------
+    const std::string pe = "encoder.pre_encode.";
+    if (ld.get(pe + "conv.0.weight", SUBC * 9, h)) return -1;
+    transpose_9x256(h, t);
+    if (ld.upload_vec(t, &e->w0t) || ld.vec(pe + "conv.0.bias", SUBC, &e->b0)) return -1;
+    if (ld.get(pe + "conv.2.weight", SUBC * 9, h)) return -1;
+    transpose_9x256(h, t);
+    if (ld.upload_vec(t, &e->w2t) || ld.vec(pe + "conv.2.bias", SUBC, &e->b2)) return -1;
+    if (ld.get(pe + "conv.5.weight", SUBC * 9, h)) return -1;
+    transpose_9x256(h, t);
+    if (ld.upload_vec(t, &e->w5t) || ld.vec(pe + "conv.5.bias", SUBC, &e->b5)) return -1;
+    if (ld.matrix_named(pe + "conv.3.weight", SUBC, SUBC, &e->w3) || ld.vec(pe + "conv.3.bias", SUBC, &e->b3)) return -1;
+    if (ld.matrix_named(pe + "conv.6.weight", SUBC, SUBC, &e->w6) || ld.vec(pe + "conv.6.bias", SUBC, &e->b6)) return -1;
+    {   // out.weight [1024][c*17+w] -> [1024][w*256+c]: our activations are channel-fastest (:1014-1017)
+        if (ld.get(pe + "out.weight", (int64_t)D * SUBFLAT, h)) return -1;
+        t.resize(h.size());
+        for (int n = 0; n < D; n++)
+            for (int c = 0; c < SUBC; c++)
+                for (int wv = 0; wv < SUBF; wv++)
+                    t[(size_t)n * SUBFLAT + wv * SUBC + c] = h[(size_t)n * SUBFLAT + c * SUBF + wv];
+        if (ld.matrix(t, D, SUBFLAT, &e->sub_out_w) || ld.vec(pe + "out.bias", D, &e->sub_out_b)) return -1;
+    }
+    // ---- encoder layers --------------------------------------------------------------------
+    const int ks = e->hp.kernel_size;
+    e->L.resize(e->hp.n_layers);
+    for (int l = 0; l < e->hp.n_layers; l++) {
+        LayerW &L = e->L[l];
+        memset(&L, 0, sizeof(L));
+        const std::string p = "encoder.layers." + std::to_string(l) + ".";
+        if (ld.vec(p + "norm_feed_forward1.weight", D, &L.ln_ff1_w) || ld.vec(p + "norm_feed_forward1.bias", D, &L.ln_ff1_b) ||
+            ld.vec(p + "norm_self_att.weight", D, &L.ln_att_w) || ld.vec(p + "norm_self_att.bias", D, &L.ln_att_b) ||
+            ld.vec(p + "norm_conv.weight", D, &L.ln_conv_w) || ld.vec(p + "norm_conv.bias", D, &L.ln_conv_b) ||
+            ld.vec(p + "norm_feed_forward2.weight", D, &L.ln_ff2_w) || ld.vec(p + "norm_feed_forward2.bias", D, &L.ln_ff2_b) ||
+            ld.vec(p + "norm_out.weight", D, &L.ln_out_w) || ld.vec(p + "norm_out.bias", D, &L.ln_out_b) ||
+            ld.vec(p + "self_attn.pos_bias_u", D, &L.bias_u) || ld.vec(p + "self_attn.pos_bias_v", D, &L.bias_v) ||
+            ld.vec(p + "conv.depthwise_conv.weight", (int64_t)ks * D, &L.dw) ||
+            ld.vec(p + "conv.batch_norm.weight", D, &L.cln_w) || ld.vec(p + "conv.batch_norm.bias", D, &L.cln_b) ||
+            ld.vec(p + "self_attn.linear_pos.weight", (int64_t)D * D, &L.wpos_f32))
+            return -1;
+        if (ld.matrix_named(p + "feed_forward1.linear1.weight", FF, D, &L.ff1_w1) ||
+            ld.matrix_named(p + "feed_forward1.linear2.weight", D, FF, &L.ff1_w2) ||
+            ld.matrix_named(p + "feed_forward2.linear1.weight", FF, D, &L.ff2_w1) ||
+            ld.matrix_named(p + "feed_forward2.linear2.weight", D, FF, &L.ff2_w2) ||
+            ld.matrix_named(p + "self_attn.linear_out.weight", D, D, &L.wo) ||
+            ld.matrix_named(p + "conv.pointwise_conv2.weight", D, D, &L.pw2))
+            return -1;
+        {   // fused QKV [3072][1024]
+            std::vector<float> qkv((size_t)3 * D * D), part;
+            const char *nm[3] = {"self_attn.linear_q.weight", "self_attn.linear_k.weight", "self_attn.linear_v.weight"};
+            for (int i = 0; i < 3; i++) {
+                if (ld.get(p + nm[i], (int64_t)D * D, part)) return -1;
+                memcpy(qkv.data() + (size_t)i * D * D, part.data(), (size_t)D * D * 4);
+            }
+            if (ld.matrix(qkv, 3 * D, D, &L.wqkv)) return -1;
+        }
+        {   // pointwise_conv1 rows interleaved (value c, gate c) so GLU is an epilogue (:657-664)
+            if (ld.get(p + "conv.pointwise_conv1.weight", (int64_t)2 * D * D, h)) return -1;
+            t.resize(h.size());
+            for (int c = 0; c < D; c++) {
+                memcpy(&t[(size_t)(2 * c) * D], &h[(size_t)c * D], D * 4);
+                memcpy(&t[(size_t)(2 * c + 1) * D], &h[(size_t)(D + c) * D], D * 4);
+            }
+            if (ld.matrix(t, 2 * D, D, &L.pw1)) return -1;
+        }
+    }
+    // ---- decoder / joint (always f32) -------------------------------------------------------
+    const std::string dp = "decoder.prediction.";
+    if (ld.vec(dp + "embed.weight", (int64_t)VOCAB * HID, &e->embed)) return -1;
+    for (int l = 0; l < 2; l++) {
+        const std::string s = std::to_string(l);
+        if (ld.vec(dp + "dec_rnn.lstm.weight_ih_l" + s, (int64_t)4 * HID * HID, &e->w_ih[l]) ||
+            ld.vec(dp + "dec_rnn.lstm.weight_hh_l" + s, (int64_t)4 * HID * HID, &e->w_hh[l]) ||
+            ld.vec(dp + "dec_rnn.lstm.bias_ih_l" + s, 4 * HID, &e->b_ih[l]) ||
+            ld.vec(dp + "dec_rnn.lstm.bias_hh_l" + s, 4 * HID, &e->b_hh[l]))
+            return -1;
+    }
+    if (ld.vec("joint.enc.weight", (int64_t)JNT * D, &e->jenc_w) || ld.vec("joint.enc.bias", JNT, &e->jenc_b) ||
+        ld.vec("joint.pred.weight", (int64_t)JNT * HID, &e->pred_w) || ld.vec("joint.pred.bias", JNT, &e->pred_b) ||
+        ld.vec("joint.joint_net.2.weight", (int64_t)VOCAB * JNT, &e->out_w) || ld.vec("joint.joint_net.2.bias", VOCAB, &e->out_b))
+        return -1;
+    // ---- prompt kernel (multilingual) -----------------------------------------------------
+    const int P = e->hp.num_prompts;
+    if (P > 0) {
+        if (ld.get("prompt_kernel.0.weight", (int64_t)2048 * (D + P), h)) return -1;
+        std::vector<float> a((size_t)2048 * D), pp((size_t)P * 2048);
+        for (int n = 0; n < 2048; n++) {
+            memcpy(&a[(size_t)n * D], &h[(size_t)n * (D + P)], D * 4);
+            for (int k = 0; k < P; k++) pp[(size_t)k * 2048 + n] = h[(size_t)n * (D + P) + D + k];
+        }
+        if (ld.upload_vec(a, &e->pk1a) || ld.upload_vec(pp, &e->pk1p) || ld.vec("prompt_kernel.0.bias", 2048, &e->pk1_b) ||
+            ld.vec("prompt_kernel.2.weight", (int64_t)D * 2048, &e->pk2_w) || ld.vec("prompt_kernel.2.bias", D, &e->pk2_b))
+            return -1;
+    } else if (ld.by_name.count("prompt_kernel.0.weight")) {
+        return fail("prompt_kernel weights present but num_prompts is 0");   // src/nemo-ggml.cpp:431-434
+    }
+    if (ld.scratch) hipFree(ld.scratch);
+    return 0;
+}
+
+// pos projection rows for chunk length T, per layer: P[r] = W_pos . emb(rel = 70+T-1-r)
+// (reference recomputes this GEMM in every layer of every chunk, src/nemo-stream.cpp:514-516;
+// its operands are input-independent so it is done once per (layer, T) here)
+static int ensure_posproj(nasr_engine *e, int T) {
+    if (e->L.empty() || e->L[0].posproj[T]) return 0;
+    const int n_rel = LCTX + 2 * T - 1;
+    std::vector<float> emb((size_t)n_rel * D);
+    for (int r = 0; r < n_rel; r++) host_pos_emb((LCTX + T - 1) - r, &emb[(size_t)r * D]);
+    float *demb, *dout;
+    HIPCHK(hipMalloc((void **)&demb, emb.size() * 4));
+    HIPCHK(hipMalloc((void **)&dout, emb.size() * 4));
+    HIPCHK(hipMemcpy(demb, emb.data(), emb.size() * 4, hipMemcpyHostToDevice));
+    for (auto &L : e->L) {
+        GemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = demb; g.W = L.wpos_f32; g.M = n_rel; g.N = D; g.K = D; g.lda = D;
+        g.epi = EPI_PART_F32; g.out_f32 = dout; g.ldo = D; g.splits = 1;
+        launch_gemm_f32(g, e->st);
+        if (e->bf16) {
+            bf16_t *pp;
+            if (dalloc(e, &pp, emb.size())) return -1;
+            launch_f32_to_bf16(dout, pp, (int64_t)emb.size(), e->st);
+            L.posproj[T] = pp;
+        } else {
+            float *pp;
+            if (dalloc(e, &pp, emb.size())) return -1;
+            HIPCHK(hipMemcpyAsync(pp, dout, emb.size() * 4, hipMemcpyDeviceToDevice, e->st));
+            L.posproj[T] = pp;
+        }
+        HIPCHK(hipStreamSynchronize(e->st));
+    }
+    hipFree(demb);
+    hipFree(dout);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
+                                  const nasr_weight_desc *weights, int n_weights, int max_streams) {
+    if (!out || !hp || !weights) return fail("nasr_engine_create: null argument");
+    *out = nullptr;
+    if (dtype != NASR_DTYPE_F32 && dtype != NASR_DTYPE_BF16) return fail("unsupported dtype %d", dtype);
+    if (hp->d_model != D || hp->n_heads != NH || hp->d_head != DH || hp->d_ff != FF || hp->n_mels != NMEL ||
+        hp->vocab_size != VOCAB || hp->decoder_dim != HID || hp->joint_dim != JNT || hp->att_left_context != LCTX ||
+        hp->subsampling_factor != 8)
+        return fail("this build is specialised for d_model 1024 / 8x128 heads / d_ff 4096 / 128 mels / vocab 1025 / "
+                    "LSTM 640 / left context 70 (got d_model=%d heads=%d d_ff=%d vocab=%d)",
+                    hp->d_model, hp->n_heads, hp->d_ff, hp->vocab_size);
+    if (hp->n_layers < 1 || hp->kernel_size < 2 || hp->kernel_size > MAX_KS) return fail("bad n_layers/kernel_size");
+    if (max_streams < 1 || max_streams > 4096) return fail("max_streams out of range");
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) return fail("no HIP device visible: the MI355X engine has no CPU fallback");
+    if (device_id < 0 || device_id >= n_dev) return fail("device %d out of range (%d visible)", device_id, n_dev);
+    HIPCHK(hipSetDevice(device_id));
+    nasr_engine *e = new nasr_engine();
+    e->device = device_id; e->dtype = dtype; e->max_streams = max_streams; e->hp = *hp;
+    e->bf16 = dtype == NASR_DTYPE_BF16; e->esz = e->bf16 ? 2 : 4;
+    if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
+    if (load_weights(e, weights, n_weights)) { nasr_engine_destroy(e); return -1; }
+
+    const size_t S = (size_t)max_streams, Lr = (size_t)hp->n_layers, ks1 = (size_t)hp->kernel_size - 1;
+    const size_t M = S * TMAX;
+    int rc = 0;
+    rc |= dalloc(e, &e->abuf, S * 2 * ABUF_CAP);
+    rc |= dalloc(e, &e->last_sample, S);
+    rc |= dalloc(e, &e->mel_ring, S * MEL_RING * NMEL);
+    e->kv_pool.resize(Lr); e->cc_pool.resize(Lr);
+    for (size_t l = 0; l < Lr && !rc; l++) {
+        char *kp;
+        rc |= dalloc(e, &kp, S * 2 * KVC * D * e->esz);
+        e->kv_pool[l] = kp;
+        rc |= dalloc(e, &e->cc_pool[l], S * 2 * ks1 * D);
+    }
+    rc |= dalloc(e, &e->dec_h, S * 4 * HID);
+    rc |= dalloc(e, &e->dec_c, S * 4 * HID);
+    rc |= dalloc(e, &e->ctrl, S);
+    rc |= dalloc(e, &e->tok_ring, S * TOK_CAP);
+    rc |= dalloc(e, &e->x, M * D);
+    rc |= dalloc(e, &e->part, 8 * M * D);
+    rc |= dalloc(e, &e->q, M * D);
+    rc |= dalloc(e, &e->glu, M * D);
+    rc |= dalloc(e, &e->encproj, M * JNT);
+    rc |= dalloc(e, &e->hfuse, hp->num_prompts > 0 ? M * 2048 : 4);
+    { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->a = p; }
+    { char *p; rc |= dalloc(e, &p, M * FF * e->esz); e->hbuf = p; }
+    { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->ctx = p; }
+    { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->cbuf = p; }
+    // subsampling ping-pong buffers, sized for R = 13: H1 = 61, W1 = 65
+    const size_t sub_elems = S * 61 * 65 * SUBC;
+    rc |= dalloc(e, &e->sub_a, sub_elems);
+    { char *p; rc |= dalloc(e, &p, (S * 31 * 33 * SUBC) * 4); e->sub_b = p; }
+    rc |= dalloc(e, &e->jact, S * JNT);
+    rc |= dalloc(e, &e->key, 2 * S);
+    rc |= dalloc(e, &e->n_active, 4);
+    rc |= dalloc(e, &e->collect_dev, S * (1 + COLLECT_STRIDE));
+    if (rc) { nasr_engine_destroy(e); return -1; }
+    e->pin_cap = 8u << 20;
+    e->pin_off = 256;
+    if (hipHostMalloc((void **)&e->pin, e->pin_cap, hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+    e->ddesc_cap = 8u << 20;
+    if (hipMalloc((void **)&e->ddesc, e->ddesc_cap) != hipSuccess) { nasr_engine_destroy(e); return fail("hipMalloc desc failed"); }
+    e->slots.assign(S, nullptr);
+    e->tap_mel_frames.assign(S, 0);
+    e->tap_mel_row.assign(S, 0);
+    if (hipStreamSynchronize(e->st) != hipSuccess) { nasr_engine_destroy(e); return fail("engine init sync failed"); }
+    *out = e;
+    return 0;
+}
+
+extern "C" void nasr_engine_destroy(nasr_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->st) hipStreamSynchronize(e->st);
+    for (auto *s : e->slots) delete s;
+    for (void *p : e->allocs) hipFree(p);
+    if (e->pin) hipHostFree(e->pin);
+    if (e->ddesc) hipFree(e->ddesc);
+    if (e->pcm_stage) hipFree(e->pcm_stage);
+    if (e->mel_stage) hipFree(e->mel_stage);
+    if (e->tap_mel) hipFree(e->tap_mel);
+    if (e->tap_sub) hipFree(e->tap_sub);
+    if (e->tap_layers) hipFree(e->tap_layers);
+    if (e->tap_enc) hipFree(e->tap_enc);
+    for (auto &r : e->prof.pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto ev : e->prof.pool) hipEventDestroy(ev);
+    if (e->st) hipStreamDestroy(e->st);
+    delete e;
+}
+
+// ---- descriptor staging: pinned bump arena -> device arena (async) --------------------------
+template <typename Tp>
+static int stage_desc(nasr_engine *e, const std::vector<Tp> &host, const Tp **dev_out) {
+    const size_t bytes = (host.size() * sizeof(Tp) + 255) & ~(size_t)255;
+    if (bytes > e->pin_cap / 2) return fail("descriptor too large");
+    if (e->pin_off + bytes > e->pin_cap || e->ddesc_off + bytes > e->ddesc_cap) {
+        HIPCHK(hipStreamSynchronize(e->st));   // all earlier copies/kernels done: arenas reusable
+        e->pin_off = 256;   // first 256 bytes: host landing zone of the decode 'n_active' read-back
+        e->ddesc_off = 0;
+    }
+    char *hp = e->pin + e->pin_off, *dp = e->ddesc + e->ddesc_off;
+    memcpy(hp, host.data(), host.size() * sizeof(Tp));
+    HIPCHK(hipMemcpyAsync(dp, hp, host.size() * sizeof(Tp), hipMemcpyHostToDevice, e->st));
+    e->pin_off += bytes;
+    e->ddesc_off += bytes;
+    *dev_out = (const Tp *)dp;
+    return 0;
+}
+
+// ---- streams ------------------------------------------------------------------------------------
+static int stream_zero_state(nasr_stream *s) {
+    nasr_engine *e = s->e;
+    const size_t slot = (size_t)s->slot, ks1 = (size_t)e->hp.kernel_size - 1;
+    for (int l = 0; l < e->hp.n_layers; l++) {
+        HIPCHK(hipMemsetAsync((char *)e->kv_pool[l] + slot * 2 * KVC * D * e->esz, 0, (size_t)2 * KVC * D * e->esz, e->st));
+        HIPCHK(hipMemsetAsync(e->cc_pool[l] + slot * 2 * ks1 * D, 0, 2 * ks1 * D * 4, e->st));
+    }
+    HIPCHK(hipMemsetAsync(e->dec_h + slot * 4 * HID, 0, 4 * HID * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->dec_c + slot * 4 * HID, 0, 4 * HID * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->abuf + slot * 2 * ABUF_CAP, 0, (size_t)2 * ABUF_CAP * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->last_sample + slot, 0, 4, e->st));
+    HIPCHK(hipMemsetAsync(e->mel_ring + slot * MEL_RING * NMEL, 0, (size_t)MEL_RING * NMEL * 4, e->st));
+    DecCtrl c;
+    memset(&c, 0, sizeof(c));
+    c.prev_token = BLANK;                      // src/nemo-stream.cpp:55-56
+    std::vector<DecCtrl> cv(1, c);
+    const DecCtrl *dsrc;
+    if (stage_desc(e, cv, &dsrc)) return -1;
+    HIPCHK(hipMemcpyAsync(e->ctrl + slot, dsrc, sizeof(DecCtrl), hipMemcpyDeviceToDevice, e->st));
+    s->abuf_cnt = NFFT / 2;                    // 256 zero samples pre-seeded, src/preprocessor.cpp:220-221
+    s->abuf_par = 0;
+    s->mel_start = 0;
+    s->mel_count = PRE_CACHE;                  // 9 literal-zero frames, src/nemo-stream.cpp:73-74
+    s->valid_len = 0;                          // :81
+    s->kv_head = 0;
+    s->cc_par = 0;
+    s->chunks = 0;
+    s->tok_read = 0;
+    s->samples_in = 0;
+    s->last_T = 0;
+    return 0;
+}
+
+extern "C" int nasr_stream_create(nasr_engine *e, int right_context, int prompt_index, nasr_stream **out) {
+    if (!e || !out) return fail("nasr_stream_create: null argument");
+    *out = nullptr;
+    if (right_context != 0 && right_context != 1 && right_context != 6 && right_context != 13)
+        return fail("right_context must be 0, 1, 6 or 13 (src/nemo-stream.h:15-20), got %d", right_context);
+    HIPCHK(hipSetDevice(e->device));
+    int slot = -1;
+    for (int i = 0; i < e->max_streams; i++)
+        if (!e->slots[i]) { slot = i; break; }
+    if (slot < 0) return fail("stream pool exhausted (max_streams=%d)", e->max_streams);
+    if (ensure_posproj(e, 1 + right_context)) return -1;
+    nasr_stream *s = new nasr_stream();
+    s->e = e; s->slot = slot; s->R = right_context; s->T = 1 + right_context;
+    s->prompt = e->hp.num_prompts > 0 ? prompt_index : -1;
+    s->alive = true;
+    e->slots[slot] = s;
+    if (stream_zero_state(s)) { e->slots[slot] = nullptr; delete s; return -1; }
+    *out = s;
+    return 0;
+}
+
+extern "C" int nasr_stream_reset(nasr_stream *s) {
+    if (!s) return fail("null stream");
+    HIPCHK(hipSetDevice(s->e->device));
+    // NOTE: the reference's reset leaves stale conv-cache/K/V contents in place
+    // (src/nemo-stream.cpp:95-115); here a reset stream == a fresh stream.
+    return stream_zero_state(s);
+}
+
+extern "C" int nasr_stream_destroy(nasr_stream *s) {
+    if (!s) return 0;
+    nasr_engine *e = s->e;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->st);
+    e->slots[s->slot] = nullptr;
+    delete s;
+    return 0;
+}
+
+extern "C" int nasr_stream_set_prompt(nasr_stream *s, int prompt_index) {
+    if (!s) return fail("null stream");
+    if (s->e->hp.num_prompts <= 0) return fail("model is not multilingual (num_prompts=0)");   // src/nemo-stream.cpp:737-740
+    if (prompt_index < 0 || prompt_index >= s->e->hp.num_prompts) return fail("prompt index %d out of range", prompt_index);
+    s->prompt = prompt_index;
+    return 0;
+}
+
+// ---- the chunk step: encoder + decode for the rows that have a full chunk buffered ----------------
+static double gemm_bytes(const nasr_engine *e, int M, int N, int K, int wesz) {
+    return (double)N * K * wesz + (double)M * K * e->esz + (double)M * N * 4;
+}
+
+static int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
+    (void)tag;
+    const bool use_bf16 = e->bf16 && !f32_weights;
+    const char *name = !use_bf16 ? "k_gemm_f32" : (g.M <= 64 ? "k_gemm_skinny" : "k_gemm_tiled");
+    ProfScope ps(e, name, gemm_bytes(e, g.M, g.N, g.K, use_bf16 ? 2 : 4), 2.0 * g.M * g.N * g.K);
+    if (use_bf16) launch_gemm_bf16(g, e->st);
+    else launch_gemm_f32(g, e->st);
+    return 0;
+}
+
+// residual GEMM: part = A.W^T (split-K), followed by k_post
+static int pick_splits(const nasr_engine *e, int M, int N, int K) {
+    if (!e->bf16) return 1;
+    int tasks = (M <= 64) ? N / 16 : (N / 128) * ((M + 127) / 128);
+    if (M > 64) return tasks < 128 ? 4 : (tasks < 256 ? 2 : 1);   // partial traffic grows with M
+    int s = 1;
+    while (s < 8 && tasks * s < 256 && (K / 32) / (s * 2) >= 4) s *= 2;
+    return s;
+}
+
+static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, const std::vector<int> &n_dec) {
+    const int B = (int)rows_s.size();
+    const int T = rows_s[0]->T, R = rows_s[0]->R;
+    const int M = B * T;
+    const int chunk_mel = PRE_CACHE + 8 * (1 + R);
+    const int shift = 8 * (1 + R);
+    std::vector<RowDesc> rd(B);
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = rows_s[b];
+        rd[b].slot = s->slot; rd[b].valid_len = s->valid_len; rd[b].kv_head = s->kv_head;
+        rd[b].mel_start = s->mel_start; rd[b].cc_par = s->cc_par; rd[b].n_dec = n_dec[b];
+        rd[b].prompt = s->prompt; rd[b].pad = 0;
+    }
+    const RowDesc *rows;
+    if (stage_desc(e, rd, &rows)) return -1;
+    hipStream_t st = e->st;
+    const int act = e->bf16 ? 1 : 0;
+
+    // ---- a-2 subsampling ------------------------------------------------------------------
+    const int H1 = chunk_mel / 2 + 1, W1 = 65, H2 = H1 / 2 + 1, W2 = 33, H3 = H2 / 2 + 1, W3 = 17;
+    {
+        ProfScope ps(e, "k_sub_conv0", (double)B * H1 * W1 * SUBC * 4, 2.0 * B * H1 * W1 * SUBC * 9);
+        launch_sub_conv0(rows, B, chunk_mel, e->mel_ring, e->w0t, e->b0, e->sub_a, H1, W1, st);
+    }
+    {
+        ProfScope ps(e, "k_sub_dw", (double)B * H1 * W1 * SUBC * 4, 2.0 * B * H2 * W2 * SUBC * 9);
+        launch_sub_dw(e->sub_a, B, H1, W1, e->w2t, e->b2, e->sub_b, act, st);
+    }
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = e->sub_b; g.W = e->w3; g.M = B * H2 * W2; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
+    g.epi = EPI_BIAS_RELU_F32; g.out_f32 = e->sub_a; g.ldo = SUBC; g.bias = e->b3;
+    run_gemm(e, g, false, "sub_pw3");
+    {
+        ProfScope ps(e, "k_sub_dw", (double)B * H2 * W2 * SUBC * 4, 2.0 * B * H3 * W3 * SUBC * 9);
+        launch_sub_dw(e->sub_a, B, H2, W2, e->w5t, e->b5, e->sub_b, act, st);
+    }
+    memset(&g, 0, sizeof(g));
+    g.A = e->sub_b; g.W = e->w6; g.M = B * H3 * W3; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
+    g.epi = EPI_BIAS_RELU_ACT; g.out_act = e->sub_a; g.ldo_act = SUBC; g.bias = e->b6;
+    run_gemm(e, g, false, "sub_pw6");
+    // out projection on the last T of the T+2 frames (drop 2: src/nemo-stream.cpp:154-162,:303)
+    memset(&g, 0, sizeof(g));
+    g.A = e->sub_a; g.W = e->sub_out_w; g.M = M; g.N = D; g.K = SUBFLAT; g.lda = SUBFLAT; g.splits = 1;
+    g.rows_per_batch = T; g.batch_stride = H3 * SUBFLAT; g.row_offset = DROP_EXTRA;
+    g.epi = EPI_BIAS_F32; g.out_f32 = e->x; g.ldo = D; g.bias = e->sub_out_b;
+    run_gemm(e, g, false, "sub_out");
+
+    // debug taps are indexed by slot: [slot][TMAX][1024] (+ layers)
+    auto tap_copy = [&](float *tap_base, size_t per_slot, size_t layer_off) -> int {
+        for (int b = 0; b < B; b++)
+            HIPCHK(hipMemcpyAsync(tap_base + (size_t)rows_s[b]->slot * per_slot + layer_off, e->x + (size_t)b * T * D,
+                                  (size_t)T * D * 4, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    if (e->debug && tap_copy(e->tap_sub, (size_t)TMAX * D, 0)) return -1;
+
+    // ---- 24 cached conformer layers -----------------------------------------------------------
+    PostParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.x = e->x; pp.M = M; pp.ln2_w = e->L[0].ln_ff1_w; pp.ln2_b = e->L[0].ln_ff1_b; pp.a_out = e->a; pp.act_bf16 = act;
+    { ProfScope ps(e, "k_post", (double)M * D * (4 + e->esz)); launch_post(pp, st); }
+
+    const int nL = e->hp.n_layers, ks = e->hp.kernel_size;
+    for (int l = 0; l < nL; l++) {
+        LayerW &L = e->L[l];
+        auto ffn = [&](void *w1, void *w2, const float *nln_w, const float *nln_b, bool last) {
+            GemmParams a;
+            memset(&a, 0, sizeof(a));
+            a.A = e->a; a.W = w1; a.M = M; a.N = FF; a.K = D; a.lda = D; a.splits = 1;
+            a.epi = EPI_SILU_ACT; a.out_act = e->hbuf; a.ldo_act = FF;
+            run_gemm(e, a, false, "ffn_w1");
+            memset(&a, 0, sizeof(a));
+            a.A = e->hbuf; a.W = w2; a.M = M; a.N = D; a.K = FF; a.lda = FF; a.splits = pick_splits(e, M, D, FF);
+            a.epi = EPI_PART_F32; a.out_f32 = e->part; a.ldo = D;
+            run_gemm(e, a, false, "ffn_w2");
+            PostParams q;
+            memset(&q, 0, sizeof(q));
+            q.x = e->x; q.M = M; q.part = e->part; q.splits = a.splits; q.scale = 0.5f;   // :633-634
+            q.a_out = e->a; q.act_bf16 = act;
+            if (last) { q.ln_out = 1; q.ln1_w = L.ln_out_w; q.ln1_b = L.ln_out_b; }       // :687
+            q.ln2_w = nln_w; q.ln2_b = nln_b;
+            ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * a.splits + e->esz));
+            launch_post(q, st);
+        };
+        // 1. FFN1 (:631-634) -> a = LN_att(x)
+        ffn(L.ff1_w1, L.ff1_w2, L.ln_att_w, L.ln_att_b, false);
+        // 2. attention (:637-643)
+        memset(&g, 0, sizeof(g));
+        g.A = e->a; g.W = L.wqkv; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.splits = 1;
+        g.epi = EPI_QKV; g.q_out = e->q; g.kv_pool = e->kv_pool[l]; g.kv_slot_stride = (int64_t)2 * KVC * D;
+        g.rows = rows; g.T = T;
+        run_gemm(e, g, false, "qkv");
+        {
+            AttnParams ap;
+            memset(&ap, 0, sizeof(ap));
+            ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = act;
+            ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T;
+            ap.ctx_out = e->ctx;
+            const int KV = LCTX + T;
+            ProfScope ps(e, "k_attention", (double)B * (2.0 * KV + KV + T - 1) * D * e->esz, 2.0 * B * T * KV * D * 3);
+            launch_attention(ap, st);
+        }
+        memset(&g, 0, sizeof(g));
+        g.A = e->ctx; g.W = L.wo; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
+        g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
+        run_gemm(e, g, false, "attn_out");
+        {
+            PostParams q;
+            memset(&q, 0, sizeof(q));
+            q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
+            q.ln2_w = L.ln_conv_w; q.ln2_b = L.ln_conv_b; q.a_out = e->a; q.act_bf16 = act;
+            ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
+            launch_post(q, st);
+        }
+        // 3. conv module (:646-679)
+        memset(&g, 0, sizeof(g));
+        g.A = e->a; g.W = L.pw1; g.M = M; g.N = 2 * D; g.K = D; g.lda = D; g.splits = 1;
+        g.epi = EPI_GLU; g.out_f32 = e->glu; g.ldo = D;
+        run_gemm(e, g, false, "pw1");
+        {
+            ConvParams cp;
+            memset(&cp, 0, sizeof(cp));
+            cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
+            cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = T; cp.ks = ks;
+            cp.c_out = e->cbuf; cp.act_bf16 = act;
+            ProfScope ps(e, "k_dwconv", (double)M * D * (4 + e->esz) + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks);
+            launch_dwconv(cp, st);
+        }
+        memset(&g, 0, sizeof(g));
+        g.A = e->cbuf; g.W = L.pw2; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
+        g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
+        run_gemm(e, g, false, "pw2");
+        {
+            PostParams q;
+            memset(&q, 0, sizeof(q));
+            q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
+            q.ln2_w = L.ln_ff2_w; q.ln2_b = L.ln_ff2_b; q.a_out = e->a; q.act_bf16 = act;
+            ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
+            launch_post(q, st);
+        }
+        // 4. FFN2 (:682-685) + norm_out (:687); then the next layer's first LayerNorm
+        const bool has_next = l + 1 < nL;
+        ffn(L.ff2_w1, L.ff2_w2, has_next ? e->L[l + 1].ln_ff1_w : nullptr, has_next ? e->L[l + 1].ln_ff1_b : nullptr, true);
+        if (e->debug && tap_copy(e->tap_layers, (size_t)nL * TMAX * D, (size_t)l * TMAX * D)) return -1;
+    }
+    // ---- a-11 prompt fusion (multilingual only, src/nemo-ggml.cpp:1087-1105) ---------------------
+    if (e->hp.num_prompts > 0) {
+        memset(&g, 0, sizeof(g));
+        g.A = e->x; g.W = e->pk1a; g.M = M; g.N = 2048; g.K = D; g.lda = D; g.splits = 1;
+        g.epi = EPI_BIAS_F32; g.out_f32 = e->hfuse; g.ldo = 2048; g.bias = e->pk1_b;
+        { ProfScope ps(e, "k_gemm_f32", gemm_bytes(e, M, 2048, D, 4), 2.0 * M * 2048 * D); launch_gemm_f32(g, st); }
+        launch_prompt_add_relu(e->hfuse, e->pk1p, rows, M, T, e->hp.num_prompts, st);
+        memset(&g, 0, sizeof(g));
+        g.A = e->hfuse; g.W = e->pk2_w; g.M = M; g.N = D; g.K = 2048; g.lda = 2048; g.splits = 1;
+        g.epi = EPI_BIAS_F32; g.out_f32 = e->x; g.ldo = D; g.bias = e->pk2_b;
+        { ProfScope ps(e, "k_gemm_f32", gemm_bytes(e, M, D, 2048, 4), 2.0 * M * D * 2048); launch_gemm_f32(g, st); }
+    }
+    if (e->debug && tap_copy(e->tap_enc, (size_t)TMAX * D, 0)) return -1;
+
+    // ---- a-13 encoder projection of the joint, hoisted out of the symbol loop --------------------
+    memset(&g, 0, sizeof(g));
+    g.A = e->x; g.W = e->jenc_w; g.M = M; g.N = JNT; g.K = D; g.lda = D; g.splits = 1;
+    g.epi = EPI_BIAS_F32; g.out_f32 = e->encproj; g.ldo = JNT; g.bias = e->jenc_b;
+    { ProfScope ps(e, "k_gemm_f32", (double)JNT * D * 4 + (double)M * (D + JNT) * 4, 2.0 * M * JNT * D); launch_gemm_f32(g, st); }
+
+    // ---- a-12..a-14 greedy decode, device resident -----------------------------------------------
+    DecParams dp;
+    memset(&dp, 0, sizeof(dp));
+    dp.rows = rows; dp.B = B; dp.T = T; dp.ctrl = e->ctrl; dp.h = e->dec_h; dp.c = e->dec_c; dp.encproj = e->encproj;
+    dp.embed = e->embed;
+    for (int i = 0; i < 2; i++) { dp.w_ih[i] = e->w_ih[i]; dp.w_hh[i] = e->w_hh[i]; dp.b_ih[i] = e->b_ih[i]; dp.b_hh[i] = e->b_hh[i]; }
+    dp.pred_w = e->pred_w; dp.pred_b = e->pred_b; dp.out_w = e->out_w; dp.out_b = e->out_b;
+    dp.jact = e->jact; dp.key = e->key; dp.n_active = e->n_active; dp.tok_ring = e->tok_ring;
+    launch_decode_begin(dp, st);
+    int max_dec = 0;
+    for (int b = 0; b < B; b++) max_dec = std::max(max_dec, n_dec[b]);
+    int it = 0, budget = max_dec + 2;
+    int *h_active = (int *)e->pin;   // first 64 bytes of the pinned arena are reserved (pin_off starts at 256)
+    while (max_dec > 0) {
+        {
+            ProfScope ps(e, "k_dec_iter", (double)budget * (4.0 * 4 * HID * HID * 4 + (double)JNT * HID * 4 + (double)VOCAB * JNT * 4),
+                         (double)budget * 2.0 * B * (4.0 * 4 * HID * HID + JNT * HID + VOCAB * JNT));
+            for (int k = 0; k < budget; k++) launch_decode_iter(dp, it++, st);
+        }
+        HIPCHK(hipMemcpyAsync(h_active, e->n_active, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (*h_active == 0) break;
+        if (it > max_dec * MAX_SYMBOLS + 4) return fail("decode did not terminate");
+        budget = 2;
+    }
+    // ---- a-15 host mirror of the stream manager bookkeeping (:1085, :1189-1195) ---------------------
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = rows_s[b];
+        s->valid_len = std::min(s->valid_len + T, LCTX);
+        s->kv_head = (s->kv_head + T) % KVC;
+        s->cc_par ^= 1;
+        s->mel_start = (s->mel_start + shift) & (MEL_RING - 1);
+        s->mel_count -= shift;
+        s->chunks++;
+        s->last_T = T;
+    }
+    return 0;
+}
+
+// run chunk steps while any of the given streams has a full chunk buffered (:1174)
+static int drain_chunks(nasr_engine *e, nasr_stream *const *streams, int B) {
+    for (;;) {
+        std::vector<nasr_stream *> ready;
+        for (int b = 0; b < B; b++)
+            if (streams[b]->mel_count >= PRE_CACHE + 8 * streams[b]->T) ready.push_back(streams[b]);
+        if (ready.empty()) return 0;
+        std::vector<int> nd(ready.size(), ready[0]->T);
+        if (run_chunk(e, ready, nd)) return -1;
+    }
+}
+
+static int validate_batch(nasr_engine *e, nasr_stream *const *streams, int B) {
+    if (!e || !streams || B < 1) return fail("null engine/streams or B < 1");
+    if (B > e->max_streams) return fail("B=%d exceeds max_streams=%d", B, e->max_streams);
+    for (int b = 0; b < B; b++) {
+        if (!streams[b] || streams[b]->e != e) return fail("stream %d does not belong to this engine", b);
+        if (streams[b]->R != streams[0]->R) return fail("all streams of one call must share right_context");
+        for (int c = 0; c < b; c++)
+            if (streams[c] == streams[b]) return fail("stream %d passed twice", b);
+    }
+    return 0;
+}
+
+// gather new tokens of the B streams
+__global__ void k_collect(const int *slots, const int *tok_read, int B, const DecCtrl *ctrl, const int *tok_ring, int *out, int stride) {
+    const int b = blockIdx.x;
+    const int slot = slots[b];
+    const int n_tok = ctrl[slot].n_tok, rd = tok_read[b];
+    const int n_new = n_tok - rd;
+    if (threadIdx.x == 0) out[(size_t)b * (1 + stride)] = n_new;
+    for (int i = threadIdx.x; i < n_new && i < stride; i += blockDim.x)
+        out[(size_t)b * (1 + stride) + 1 + i] = tok_ring[(size_t)slot * TOK_CAP + ((rd + i) & (TOK_CAP - 1))];
+}
+
+static int collect_tokens(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
+                          const int32_t *tokens_cap, int32_t *n_tokens) {
+    std::vector<int> meta(2 * (size_t)B);
+    for (int b = 0; b < B; b++) { meta[b] = streams[b]->slot; meta[B + b] = streams[b]->tok_read; }
+    const int *dmeta;
+    if (stage_desc(e, meta, &dmeta)) return -1;
+    hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st, dmeta, dmeta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE);
+    std::vector<int> host((size_t)B * (1 + COLLECT_STRIDE));
+    HIPCHK(hipMemcpyAsync(host.data(), e->collect_dev, host.size() * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (int b = 0; b < B; b++) {
+        const int *rec = &host[(size_t)b * (1 + COLLECT_STRIDE)];
+        const int n_new = rec[0];
+        if (n_new < 0 || n_new > TOK_CAP) return fail("token ring overrun on stream %d (%d new tokens)", b, n_new);
+        const int cap = tokens_out && tokens_out[b] && tokens_cap ? tokens_cap[b] : 0;
+        const int n_copy = std::min(n_new, cap);
+        if (n_new <= COLLECT_STRIDE) {
+            for (int i = 0; i < n_copy; i++) tokens_out[b][i] = rec[1 + i];
+        } else if (n_copy > 0) {   // rare long push: fetch straight from the ring
+            std::vector<int> ring(TOK_CAP);
+            HIPCHK(hipMemcpy(ring.data(), e->tok_ring + (size_t)streams[b]->slot * TOK_CAP, TOK_CAP * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n_copy; i++) tokens_out[b][i] = ring[(streams[b]->tok_read + i) & (TOK_CAP - 1)];
+        }
+        if (n_tokens) n_tokens[b] = n_new;
+        streams[b]->tok_read += n_new;
+    }
+    return 0;
+}
+
+static int ensure_debug_buffers(nasr_engine *e) {
+    if (e->tap_sub) return 0;
+    const size_t S = (size_t)e->max_streams;
+    e->tap_mel_cap = 128;
+    HIPCHK(hipMalloc((void **)&e->tap_mel, S * e->tap_mel_cap * NMEL * 4));
+    HIPCHK(hipMalloc((void **)&e->tap_sub, S * TMAX * D * 4));
+    HIPCHK(hipMalloc((void **)&e->tap_layers, S * (size_t)e->hp.n_layers * TMAX * D * 4));
+    HIPCHK(hipMalloc((void **)&e->tap_enc, S * TMAX * D * 4));
+    return 0;
+}
+
+extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
+    if (!e) return fail("null engine");
+    HIPCHK(hipSetDevice(e->device));
+    if (enable && ensure_debug_buffers(e)) return -1;
+    e->debug = enable != 0;
+    return 0;
+}
+
+extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm,
+                                const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap,
+                                int32_t *n_tokens, uint32_t flags) {
+    if (validate_batch(e, streams, B)) return -1;
+    if (!pcm || !n_samples) return fail("null pcm / n_samples");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<int64_t> off(B, 0);
+    std::vector<const int16_t *> base(B, nullptr);
+    size_t total = 0;
+    for (int b = 0; b < B; b++) {
+        if (n_samples[b] < 0) return fail("negative n_samples");
+        if (n_samples[b] > 0 && !pcm[b]) return fail("null pcm for stream %d", b);
+        total += (size_t)n_samples[b];
+    }
+    if (!(flags & NASR_FLAG_PCM_DEVICE)) {
+        // hand-over of host buffers: one gather into the device staging area
+        if (total > e->pcm_stage_cap) {
+            HIPCHK(hipStreamSynchronize(e->st));
+            if (e->pcm_stage) hipFree(e->pcm_stage);
+            e->pcm_stage_cap = total + 65536;
+            HIPCHK(hipMalloc((void **)&e->pcm_stage, e->pcm_stage_cap * 2));
+        }
+        size_t o = 0;
+        ProfScope ps(e, "h2d_pcm", (double)total * 2);
+        for (int b = 0; b < B; b++) {
+            if (n_samples[b] > 0) HIPCHK(hipMemcpyAsync(e->pcm_stage + o, pcm[b], (size_t)n_samples[b] * 2, hipMemcpyHostToDevice, e->st));
+            base[b] = e->pcm_stage + o;
+            o += (size_t)n_samples[b];
+        }
+    } else {
+        for (int b = 0; b < B; b++) base[b] = pcm[b];
+    }
+    if (e->debug) for (int b = 0; b < B; b++) { e->tap_mel_frames[streams[b]->slot] = 0; e->tap_mel_row[streams[b]->slot] = b; }
+    for (int b = 0; b < B; b++) streams[b]->samples_in += n_samples[b];
+    // sub-pushes of at most MAX_PUSH samples keep the audio buffer and the mel ring bounded
+    for (;;) {
+        std::vector<PcmDesc> pd;
+        int max_frames = 0, max_n = 0;
+        std::vector<int> who;
+        for (int b = 0; b < B; b++) {
+            const int64_t rem = n_samples[b] - off[b];
+            if (rem <= 0) continue;
+            nasr_stream *s = streams[b];
+            PcmDesc d;
+            memset(&d, 0, sizeof(d));
+            d.pcm = base[b] + off[b];
+            d.slot = s->slot;
+            d.n = (int)std::min<int64_t>(rem, MAX_PUSH);
+            d.cnt = s->abuf_cnt;
+            d.par = s->abuf_par;
+            const int avail = d.cnt + d.n;
+            d.n_frames = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;   // src/preprocessor.cpp:320-328
+            d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
+            d.consumed = d.n_frames * HOP;
+            pd.push_back(d);
+            who.push_back(b);
+            max_frames = std::max(max_frames, d.n_frames);
+            max_n = std::max(max_n, d.n);
+        }
+        if (pd.empty()) break;
+        const PcmDesc *dpd;
+        if (stage_desc(e, pd, &dpd)) return -1;
+        MelParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.desc = dpd; mp.B = (int)pd.size(); mp.max_frames = max_frames; mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+        if (e->debug) { mp.tap = e->tap_mel; mp.tap_cap = e->tap_mel_cap; }
+        {
+            ProfScope ps(e, "k_mel", 0, 0);
+            launch_mel(mp, max_n, e->st);
+        }
+        for (size_t i = 0; i < pd.size(); i++) {
+            nasr_stream *s = streams[who[i]];
+            off[who[i]] += pd[i].n;
+            s->abuf_cnt = pd[i].cnt + pd[i].n - pd[i].consumed;
+            if (pd[i].n_frames > 0) s->abuf_par ^= 1;
+            s->mel_count += pd[i].n_frames;
+            if (e->debug) { e->tap_mel_frames[s->slot] = pd[i].n_frames; e->tap_mel_row[s->slot] = (int)i; }
+        }
+        if (drain_chunks(e, streams, B)) return -1;
+    }
+    if (flags & NASR_FLAG_NO_SYNC) {
+        if (n_tokens) for (int b = 0; b < B; b++) n_tokens[b] = 0;
+        return 0;
+    }
+    return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+extern "C" int nasr_engine_step_mel(nasr_engine *e, nasr_stream *const *streams, int B, const float *const *mel,
+                                    const int32_t *n_frames, int32_t *const *tokens_out, const int32_t *tokens_cap,
+                                    int32_t *n_tokens, uint32_t flags) {
+    if (validate_batch(e, streams, B)) return -1;
+    if (!mel || !n_frames) return fail("null mel / n_frames");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<int> off(B, 0);
+    const int piece = 8 * streams[0]->T;   // one shift at a time keeps the ring bounded
+    for (;;) {
+        std::vector<PcmDesc> pd;
+        std::vector<int> who;
+        for (int b = 0; b < B; b++) {
+            if (n_frames[b] < 0 || (n_frames[b] > 0 && !mel[b])) return fail("bad mel input for stream %d", b);
+            const int rem = n_frames[b] - off[b];
+            if (rem <= 0) continue;
+            PcmDesc d;
+            memset(&d, 0, sizeof(d));
+            d.slot = streams[b]->slot;
+            d.n_frames = std::min(rem, piece);
+            d.mel_wpos = (streams[b]->mel_start + streams[b]->mel_count) & (MEL_RING - 1);
+            pd.push_back(d);
+            who.push_back(b);
+        }
+        if (pd.empty()) break;
+        const size_t need = pd.size() * (size_t)piece * NMEL;
+        if (need > e->mel_stage_cap) {
+            HIPCHK(hipStreamSynchronize(e->st));
+            if (e->mel_stage) hipFree(e->mel_stage);
+            e->mel_stage_cap = need;
+            HIPCHK(hipMalloc((void **)&e->mel_stage, need * 4));
+        }
+        for (size_t i = 0; i < pd.size(); i++)
+            HIPCHK(hipMemcpyAsync(e->mel_stage + i * (size_t)piece * NMEL, mel[who[i]] + (size_t)off[who[i]] * NMEL,
+                                  (size_t)pd[i].n_frames * NMEL * 4, hipMemcpyHostToDevice, e->st));
+        const PcmDesc *dpd;
+        if (stage_desc(e, pd, &dpd)) return -1;
+        launch_mel_put(e->mel_stage, dpd, (int)pd.size(), piece, e->mel_ring, e->st);
+        for (size_t i = 0; i < pd.size(); i++) {
+            off[who[i]] += pd[i].n_frames;
+            streams[who[i]]->mel_count += pd[i].n_frames;
+        }
+        if (drain_chunks(e, streams, B)) return -1;
+        HIPCHK(hipStreamSynchronize(e->st));   // host mel staging is reused next round
+    }
+    if (flags & NASR_FLAG_NO_SYNC) {
+        if (n_tokens) for (int b = 0; b < B; b++) n_tokens[b] = 0;
+        return 0;
+    }
+    return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+extern "C" int nasr_engine_finalize(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
+                                    const int32_t *tokens_cap, int32_t *n_tokens) {
+    if (validate_batch(e, streams, B)) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    // src/nemo-stream.cpp:1234-1258: frames > 9 -> n_valid = (frames-9)/8 outputs of one zero-padded step
+    std::vector<nasr_stream *> rows;
+    std::vector<int> nd;
+    std::vector<PcmDesc> pd;
+    int max_pad = 0;
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = streams[b];
+        const int chunk_mel = PRE_CACHE + 8 * s->T;
+        if (s->mel_count <= PRE_CACHE) continue;
+        const int n_valid = (s->mel_count - PRE_CACHE) / 8;
+        if (n_valid <= 0) continue;
+        if (s->mel_count < chunk_mel) {
+            PcmDesc d;
+            memset(&d, 0, sizeof(d));
+            d.slot = s->slot;
+            d.n_frames = chunk_mel - s->mel_count;
+            d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
+            pd.push_back(d);
+            max_pad = std::max(max_pad, d.n_frames);
+            s->mel_count = chunk_mel;
+        }
+        rows.push_back(s);
+        nd.push_back(std::min(n_valid, s->T));
+    }
+    if (!pd.empty()) {
+        const PcmDesc *dpd;
+        if (stage_desc(e, pd, &dpd)) return -1;
+        launch_mel_zero(dpd, (int)pd.size(), max_pad, e->mel_ring, e->st);
+    }
+    if (!rows.empty() && run_chunk(e, rows, nd)) return -1;
+    return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+extern "C" int nasr_engine_collect(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
+                                   const int32_t *tokens_cap, int32_t *n_tokens) {
+    if (validate_batch(e, streams, B)) return -1;
+    HIPCHK(hipSetDevice(e->device));
+    return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+extern "C" int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out) {
+    if (!s || !out) return fail("null argument");
+    nasr_engine *e = s->e;
+    HIPCHK(hipSetDevice(e->device));
+    DecCtrl c;
+    HIPCHK(hipStreamSynchronize(e->st));
+    HIPCHK(hipMemcpy(&c, e->ctrl + s->slot, sizeof(c), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->samples_in = s->samples_in;
+    out->chunks = s->chunks;
+    out->decode_iterations = c.iterations;
+    out->tokens = c.n_tok;
+    out->cache_valid_len = s->valid_len;
+    out->mel_frames_buffered = s->mel_count;
+    return 0;
+}
+
+extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, float *out, int64_t cap) {
+    if (!s || !out) return fail("null argument");
+    nasr_engine *e = s->e;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->st));
+    const size_t slot = (size_t)s->slot;
+    const int T = s->last_T;
+    auto need_debug = [&]() { return e->tap_sub != nullptr; };
+    switch (which) {
+    case NASR_TAP_MEL: {
+        if (!need_debug()) return fail("debug taps not enabled");
+        const int n = std::min(e->tap_mel_frames[slot], e->tap_mel_cap);
+        if ((int64_t)n * NMEL > cap) return fail("tap buffer too small");
+        HIPCHK(hipMemcpy(out, e->tap_mel + (size_t)e->tap_mel_row[slot] * e->tap_mel_cap * NMEL, (size_t)n * NMEL * 4, hipMemcpyDeviceToHost));
+        return (int64_t)n * NMEL;
+    }
+    case NASR_TAP_SUBSAMPLED:
+    case NASR_TAP_ENCODER_OUT:
+    case NASR_TAP_LAYER_OUT: {
+        if (!need_debug()) return fail("debug taps not enabled");
+        if ((int64_t)T * D > cap) return fail("tap buffer too small");
+        const float *src = which == NASR_TAP_SUBSAMPLED ? e->tap_sub + slot * TMAX * D
+                         : which == NASR_TAP_ENCODER_OUT ? e->tap_enc + slot * TMAX * D
+                         : e->tap_layers + (slot * e->hp.n_layers + (size_t)index) * TMAX * D;
+        if (which == NASR_TAP_LAYER_OUT && (index < 0 || index >= e->hp.n_layers)) return fail("layer index out of range");
+        HIPCHK(hipMemcpy(out, src, (size_t)T * D * 4, hipMemcpyDeviceToHost));
+        return (int64_t)T * D;
+    }
+    case NASR_TAP_K_CACHE:
+    case NASR_TAP_V_CACHE: {
+        if (index < 0 || index >= e->hp.n_layers) return fail("layer index out of range");
+        if ((int64_t)LCTX * D > cap) return fail("tap buffer too small");
+        const int v = which == NASR_TAP_V_CACHE ? 1 : 0;
+        std::vector<char> raw((size_t)KVC * D * e->esz);
+        HIPCHK(hipMemcpy(raw.data(), (char *)e->kv_pool[index] + (slot * 2 + v) * KVC * D * e->esz, raw.size(), hipMemcpyDeviceToHost));
+        for (int j = 0; j < LCTX; j++) {   // logical order: ring[(kv_head + j) % KVC]
+            const int ring = (s->kv_head + j) % KVC;
+            for (int d = 0; d < D; d++) {
+                if (e->bf16) {
+                    uint32_t u = (uint32_t)((const uint16_t *)raw.data())[(size_t)ring * D + d] << 16;
+                    memcpy(&out[(size_t)j * D + d], &u, 4);
+                } else out[(size_t)j * D + d] = ((const float *)raw.data())[(size_t)ring * D + d];
+            }
+        }
+        return (int64_t)LCTX * D;
+    }
+    case NASR_TAP_CONV_CACHE: {
+        if (index < 0 || index >= e->hp.n_layers) return fail("layer index out of range");
+        const size_t ks1 = (size_t)e->hp.kernel_size - 1;
+        if ((int64_t)(ks1 * D) > cap) return fail("tap buffer too small");
+        HIPCHK(hipMemcpy(out, e->cc_pool[index] + (slot * 2 + s->cc_par) * ks1 * D, ks1 * D * 4, hipMemcpyDeviceToHost));
+        return (int64_t)(ks1 * D);
+    }
+    case NASR_TAP_DEC_STATE: {
+        if (cap < 4 * HID + 1) return fail("tap buffer too small");
+        DecCtrl c;
+        HIPCHK(hipMemcpy(&c, e->ctrl + slot, sizeof(c), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, e->dec_h + (slot * 2 + c.cur) * 2 * HID, 2 * HID * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out + 2 * HID, e->dec_c + (slot * 2 + c.cur) * 2 * HID, 2 * HID * 4, hipMemcpyDeviceToHost));
+        out[4 * HID] = (float)c.prev_token;
+        return 4 * HID + 1;
+    }
+    }
+    return fail("unknown tap %d", which);
+}
+
+extern "C" int nasr_engine_profile(nasr_engine *e, int enable) {
+    if (!e) return fail("null engine");
+    HIPCHK(hipSetDevice(e->device));
+    prof_flush(e);
+    if (enable) for (auto &s : e->prof.stats) { s.launches = 0; s.total_ms = 0; s.bytes = 0; s.flops = 0; }
+    e->prof.on = enable != 0;
+    return 0;
+}
+
+extern "C" int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, int cap) {
+    if (!e) return fail("null engine");
+    HIPCHK(hipSetDevice(e->device));
+    prof_flush(e);
+    int n = 0;
+    for (auto &s : e->prof.stats) {
+        if (s.launches == 0) continue;
+        if (out && n < cap) out[n] = s;
+        n++;
+    }
+    return n;
+}
+
+extern "C" void *nasr_engine_hip_stream(nasr_engine *e) { return e ? (void *)e->st : nullptr; }
+
+extern "C" int nasr_device_alloc(nasr_engine *e, void **out, int64_t bytes) {
+    if (!e || !out || bytes <= 0) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMalloc(out, (size_t)bytes));
+    return 0;
+}
+extern "C" int nasr_device_free(nasr_engine *e, void *p) {
+    if (!e) return fail("null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipFree(p));
+    return 0;
+}
+extern "C" int nasr_device_upload(nasr_engine *e, void *dst, const void *src, int64_t bytes) {
+    if (!e || !dst || !src) return fail("bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int nasr_engine_synchronize(nasr_engine *e) {
+    if (!e) return fail("null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->st));
+    return 0;
+}

@@ -1,0 +1,196 @@
+// nasr_internal.h -- shared declarations of the HIP engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nasr {
+
+// ---- model constants this build is specialised for (nemotron-speech-streaming-0.6B and
+// its multilingual sibling: reference src/nemo-ggml.h:37-55). n_layers / kernel_size /
+// num_prompts stay runtime. -----------------------------------------------------------
+constexpr int D      = 1024;
+constexpr int NH     = 8;
+constexpr int DH     = 128;
+constexpr int FF     = 4096;
+constexpr int NMEL   = 128;
+constexpr int NBINS  = 257;
+constexpr int NFFT   = 512;
+constexpr int HOP    = 160;
+constexpr int WIN    = 400;
+constexpr int LCTX   = 70;    // att_left_context
+constexpr int TMAX   = 14;    // 1 + max right context (13)
+constexpr int KVC    = 84;    // K/V ring capacity = LCTX + TMAX rows
+constexpr int SUBC   = 256;   // subsampling channels
+constexpr int SUBF   = 17;    // subsampled freq bins
+constexpr int SUBFLAT = SUBC * SUBF;  // 4352
+constexpr int VOCAB  = 1025;
+constexpr int BLANK  = 1024;
+constexpr int HID    = 640;
+constexpr int JNT    = 640;
+constexpr int PRE_CACHE = 9;
+constexpr int DROP_EXTRA = 2;
+constexpr int MAX_SYMBOLS = 10;
+constexpr int MEL_RING = 256;         // mel ring frames per stream (power of two)
+constexpr int MAX_PUSH = 17920;       // samples per internal sub-push (= R=13 shift)
+constexpr int ABUF_CAP = MAX_PUSH + NFFT + 64;
+constexpr int MAX_KS   = 32;          // max depthwise kernel size supported
+constexpr int TOK_CAP  = 4096;        // per-stream device token ring between collects
+
+typedef uint16_t bf16_t;
+
+// ---- per-step descriptors (uploaded by the host for every launch sequence) -----------
+struct RowDesc {          // one per batch row (= stream taking part in this chunk step)
+    int slot;             // state-pool slot
+    int valid_len;        // cache_valid_len BEFORE this chunk (src/nemo-stream.cpp:1037)
+    int kv_head;          // ring index of logical key 0
+    int mel_start;        // mel-ring index of the first frame of the chunk
+    int cc_par;           // conv-cache buffer to read (the other one is written)
+    int n_dec;            // encoder frames to decode (T, or n_valid on the tail flush)
+    int prompt;           // language prompt index (multilingual) or -1
+    int pad;
+};
+
+struct PcmDesc {          // one per stream receiving samples in a sub-push
+    const int16_t *pcm;   // device pointer to the samples of this sub-push
+    int slot;
+    int n;                // samples in this sub-push
+    int cnt;              // samples already in the audio buffer
+    int par;              // audio buffer parity holding them
+    int n_frames;         // frames this sub-push completes
+    int mel_wpos;         // mel-ring write index of the first new frame
+    int consumed;         // samples consumed = n_frames * HOP
+    int pad;
+};
+
+struct DecCtrl {          // per-slot decoder control block (device resident)
+    int t;                // current encoder frame within the chunk
+    int n_frames;         // frames to decode in this chunk
+    int symbols;          // symbols emitted for the current frame
+    int prev_token;
+    int cur;              // which of the two LSTM state versions is committed
+    int n_tok;            // tokens written to the token ring so far (monotonic)
+    int active;
+    int iterations;       // total LSTM+joint evaluations (stat)
+    int row;              // batch row of this slot in the current step
+    int pad[3];
+};
+
+// ---- epilogues of the GEMM kernels ------------------------------------------------------
+enum Epi {
+    EPI_PART_F32 = 0,   // out_f32[split][m][n] = acc                      (split-K partials)
+    EPI_SILU_ACT,       // out_act[m][n] = silu(acc)
+    EPI_QKV,            // n<1024: q f32; else K/V ring rows (act dtype)
+    EPI_GLU,            // interleaved (value,gate) pairs -> out_f32[m][n/2] = v*sigmoid(g)
+    EPI_BIAS_F32,       // out_f32[m][n] = acc + bias[n]
+    EPI_BIAS_RELU_ACT,  // out_act[m][n] = relu(acc + bias[n])
+    EPI_BIAS_RELU_F32,  // out_f32[m][n] = relu(acc + bias[n])
+    EPI_BIAS_ACT,       // out_act[m][n] = acc + bias[n]
+};
+
+struct GemmParams {
+    const void *A;        // activations [M][K] (act dtype: bf16 or f32), row stride lda
+    const void *W;        // weights: bf16 packed tiles or f32 row-major [N][K]
+    int M, N, K;
+    int lda;
+    // optional batched row map for A: row m -> (m / rows_per_batch)*batch_stride +
+    // row_offset*lda + (m % rows_per_batch)*lda ; disabled when rows_per_batch == 0
+    int rows_per_batch, batch_stride, row_offset;
+    int splits;           // split-K factor (EPI_PART_F32 only)
+    int epi;
+    float *out_f32;  int ldo;     // f32 output / partials ([split][M][ldo])
+    void  *out_act;  int ldo_act; // act-dtype output
+    const float *bias;
+    // EPI_QKV
+    float *q_out;                 // [M][1024] f32
+    void  *kv_pool;               // K/V rings of this layer: [slot][2][KVC][1024] act dtype
+    int64_t kv_slot_stride;       // elements between slots
+    const RowDesc *rows;  int T;  // row m -> stream m / T, frame m % T
+};
+
+// ---- kernel launchers (defined in the .hip files) -----------------------------------
+void launch_gemm_bf16(const GemmParams &p, hipStream_t st);
+void launch_gemm_f32(const GemmParams &p, hipStream_t st);
+void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st);
+void launch_f32_to_bf16(const float *in, bf16_t *out, int64_t n, hipStream_t st);
+
+struct MelParams {
+    const PcmDesc *desc; int B; int max_frames;
+    float *abuf;          // [slot][2][ABUF_CAP]
+    float *last_sample;   // [slot]
+    float *mel_ring;      // [slot][MEL_RING][128]
+    const float *window;  // [512] padded Hann
+    const float *fbT;     // [257][128] transposed filterbank
+    const float *cos_t, *sin_t;  // [512]
+    float *tap; int tap_cap;     // optional debug copy of produced frames [B][tap_cap][128]
+};
+void launch_mel(const MelParams &p, int max_n, hipStream_t st);
+void launch_mel_put(const float *staged, const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
+void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
+
+void launch_sub_conv0(const RowDesc *rows, int B, int chunk_mel, const float *mel_ring, const float *w0t,
+                      const float *b0, float *out, int H1, int W1, hipStream_t st);
+void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, const float *bias, void *out,
+                   int out_bf16, hipStream_t st);
+
+struct PostParams {       // x += scale * sum_s part[s]; then LayerNorm(s)
+    float *x; int M;
+    const float *part; int splits; float scale;   // splits = 0: no residual update
+    const float *ln1_w, *ln1_b;   // if ln_out: x = LN1(x) written back first
+    int ln_out;
+    const float *ln2_w, *ln2_b;   // a = LN2(x) (null: no act output)
+    void *a_out; int act_bf16;
+    float *copy_out;              // optional f32 copy of the final x (taps / encoder out)
+};
+void launch_post(const PostParams &p, hipStream_t st);
+
+struct AttnParams {
+    const float *q;       // [M][1024]
+    const void *kv_pool; int64_t kv_slot_stride; int act_bf16;
+    const void *posproj;  // [n_rel][1024] act dtype, row r <-> rel = (70+T-1) - r
+    const float *bias_u, *bias_v;  // [8][128]
+    const RowDesc *rows; int B; int T;
+    void *ctx_out;        // [M][1024] act dtype
+};
+void launch_attention(const AttnParams &p, hipStream_t st);
+
+struct ConvParams {
+    const float *glu;     // [M][1024] f32
+    float *cc_pool; int64_t cc_slot_stride;  // [slot][2][ks-1][1024] (this layer)
+    const float *dw;      // [ks][1024]
+    const float *ln_w, *ln_b;
+    const RowDesc *rows; int B; int T; int ks;
+    void *c_out; int act_bf16;
+};
+void launch_dwconv(const ConvParams &p, hipStream_t st);
+
+struct DecParams {
+    const RowDesc *rows; int B; int T;
+    DecCtrl *ctrl;               // [slot]
+    float *h, *c;                // [slot][2 versions][2 layers][640]
+    const float *encproj;        // [M][640]  (joint.enc applied, bias included)
+    const float *embed;          // [1025][640]
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
+    const float *pred_w, *pred_b, *out_w, *out_b;
+    float *jact;                 // [B][640]
+    unsigned long long *key;     // [2][B] packed argmax keys
+    int *n_active;               // device counter
+    int *tok_ring;               // [slot][TOK_CAP]
+};
+void launch_decode_begin(const DecParams &p, hipStream_t st);
+void launch_decode_iter(const DecParams &p, int iter, hipStream_t st);
+
+void launch_prompt_add_relu(float *h, const float *w1p, const RowDesc *rows, int M, int T, int P, hipStream_t st);
+void launch_relu(float *x, int64_t n, hipStream_t st);
+void launch_fill_f32(float *p, float v, int64_t n, hipStream_t st);
+
+// bf16 helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // RNE; NaN kept NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+}  // namespace nasr

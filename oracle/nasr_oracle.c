@@ -201,11 +201,11 @@ static const model_slot k_model_slots[] = {
     {"encoder.pre_encode.conv.0.bias", MOFF(conv0_b), 256, 0},
     {"encoder.pre_encode.conv.2.weight", MOFF(conv2_w), 256 * 9, 0},
     {"encoder.pre_encode.conv.2.bias", MOFF(conv2_b), 256, 0},
-    {"encoder.pre_encode.conv.3.weight", MOFF(conv3_w), 256 * 256, 0},
+    {"encoder.pre_encode.conv.3.weight", MOFF(conv3_w), 256 * 256, 1},
     {"encoder.pre_encode.conv.3.bias", MOFF(conv3_b), 256, 0},
     {"encoder.pre_encode.conv.5.weight", MOFF(conv5_w), 256 * 9, 0},
     {"encoder.pre_encode.conv.5.bias", MOFF(conv5_b), 256, 0},
-    {"encoder.pre_encode.conv.6.weight", MOFF(conv6_w), 256 * 256, 0},
+    {"encoder.pre_encode.conv.6.weight", MOFF(conv6_w), 256 * 256, 1},
     {"encoder.pre_encode.conv.6.bias", MOFF(conv6_b), 256, 0},
     {"encoder.pre_encode.out.weight", MOFF(sub_out_w), 1024 * 4352, 1},
     {"encoder.pre_encode.out.bias", MOFF(sub_out_b), 1024, 0},
@@ -461,8 +461,10 @@ int orc_subsampling(const orc_model *m, const float *mel, int n_frames, float *o
     float *b = (float *)xmalloc(sizeof(float) * (size_t)H1 * W1 * C);
     conv3x3_s2(mel, n_frames, ORC_N_MELS, C, 1, m->conv0_w, m->conv0_b, 1, a); /* conv0+ReLU */
     conv3x3_s2(a, H1, W1, C, 0, m->conv2_w, m->conv2_b, 0, b);                /* dw conv2 */
+    if (m->emulate_bf16) round_bf16_inplace(b, (int64_t)H2 * W2 * C);          /* GEMM operand */
     conv1x1_relu(b, H2 * W2, m->conv3_w, m->conv3_b, a);                       /* pw conv3+ReLU */
     conv3x3_s2(a, H2, W2, C, 0, m->conv5_w, m->conv5_b, 0, b);                /* dw conv5 */
+    if (m->emulate_bf16) round_bf16_inplace(b, (int64_t)H3 * W3 * C);
     conv1x1_relu(b, H3 * W3, m->conv6_w, m->conv6_b, a);                       /* pw conv6+ReLU */
     /* flatten flat[t][c*17 + w] (:1014-1017) */
     float *flat = (float *)xmalloc(sizeof(float) * (size_t)H3 * ORC_SUB_FLAT);
