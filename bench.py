@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- RTFx (audio-seconds per wall-second) of the streaming forward path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B --right-context R --dtype bf16]
+
+A "step" is one pass of the hot path over one batch: every stream of the batch is pushed
+1280*(1+R) new PCM samples (80 ms * (1+R) of audio), which runs PCM->log-mel, one cached
+encoder chunk (24 layers) and the RNN-T greedy decode for all B streams in one launch
+sequence.  Default workload = BASELINE.json configs[1]: nemotron-0.6B, bf16, batch = 1 stream,
+80 ms lookahead (R = 0), full-size seeded synthetic weights and PCM (no checkpoints/audio exist
+on the box).  PCM is resident in HBM before the timed region starts (NASR_FLAG_PCM_DEVICE).
+
+Multi-GPU (N > 1, launched by torch.distributed.run): streams are independent, so rank r owns
+its own B streams on GPU r with replicated weights -- weak scaling, no data-path collective
+(SURVEY.md §8e).  torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
+of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="streams per GPU")
+    ap.add_argument("--right-context", type=int, default=0, choices=[0, 1, 6, 13])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=3.2, help="audio seconds of the CPU-baseline sample")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ge.load_package()
+    from nemotron_asr_amd import capi, synth
+
+    B, R = args.batch, args.right_context
+    T = 1 + R
+    n_step = synth.shift_samples(R)
+    total_steps = args.warmup + args.steps
+    audio_per_step = B * n_step / synth.SAMPLE_RATE
+
+    t0 = time.time()
+    W = synth.make_weights(n_layers=args.layers)
+    t_weights = time.time() - t0
+    dtype = capi.DTYPE_BF16 if args.dtype == "bf16" else capi.DTYPE_F32
+    eng = capi.Engine(W, n_layers=args.layers, dtype=dtype, max_streams=B, device=local_rank)
+    streams = [eng.stream(R) for _ in range(B)]
+    # PCM for every step, resident in HBM before timing starts.  Extra steps for the profile pass.
+    prof_steps = 0 if args.no_profile_pass else min(args.steps, 50)
+    n_total = (total_steps + prof_steps) * n_step
+    secs = n_total / synth.SAMPLE_RATE
+    pcm_host = [synth.make_pcm(rank * B + s, secs)[:n_total] for s in range(B)]
+    pcm_dev = [eng.upload(p) for p in pcm_host]
+
+    L = capi.lib()
+    handles = (C.c_void_p * B)(*[s.h for s in streams])
+    tok_cap = 16 * T
+    tok_bufs = [np.zeros(tok_cap, np.int32) for _ in range(B)]
+    tptrs = (C.c_void_p * B)(*[b.ctypes.data for b in tok_bufs])
+    caps = (C.c_int32 * B)(*([tok_cap] * B))
+    ntok = (C.c_int32 * B)()
+    ns = (C.c_int32 * B)(*([n_step] * B))
+    step_ptrs = [(C.c_void_p * B)(*[pcm_dev[s] + 2 * k * n_step for s in range(B)]) for k in range(total_steps + prof_steps)]
+
+    tokens_total = 0
+
+    def run_step(k):
+        nonlocal tokens_total
+        rc = L.nasr_engine_step(eng.h, handles, B, step_ptrs[k], ns, tptrs, caps, ntok, capi.FLAG_PCM_DEVICE)
+        if rc < 0:
+            raise RuntimeError(L.nasr_last_error().decode())
+        tokens_total += sum(ntok[b] for b in range(B))
+
+    def barrier():
+        eng.synchronize()
+        if dist is not None:
+            dist.barrier()
+        eng.synchronize()
+
+    for k in range(args.warmup):
+        run_step(k)
+    tokens_total = 0
+    barrier()
+    t_start = time.perf_counter()
+    for k in range(args.warmup, total_steps):
+        run_step(k)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tokens_timed = tokens_total
+    chunks_timed = streams[0].stats().chunks
+
+    value = world * audio_per_step * args.steps / elapsed
+
+    # ---- per-kernel HIP-event pass (same steps, events around every launch) ------------------
+    roofline = None
+    kernels = []
+    if prof_steps and rank == 0:
+        eng.profile(True)
+        for k in range(total_steps, total_steps + prof_steps):
+            run_step(k)
+        kernels = eng.profile_read()
+        eng.profile(False)
+        dom = max((k for k in kernels if k["name"].startswith("k_gemm")), key=lambda k: k["total_ms"], default=None)
+        if dom and dom["total_ms"] > 0:
+            avg_ms = dom["total_ms"] / dom["launches"]
+            if dom["name"] == "k_gemm_tiled":
+                ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+                roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS,
+                                unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                                avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps)
+            else:
+                ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+                roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps,
+                                alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]))
+
+    # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample ------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        om = ob.OracleModel(W, args.layers)
+        ost = ob.OracleStream(om, R)
+        n_cpu_steps = max(2, int(args.cpu_seconds * synth.SAMPLE_RATE / n_step))
+        p = pcm_host[0]
+        ost.process(p[:2 * n_step])            # warm-up: fills the first chunk
+        c0 = ost.total_chunks
+        tc = time.perf_counter()
+        for k in range(2, 2 + n_cpu_steps):
+            ost.process(p[k * n_step:(k + 1) * n_step])
+        tcpu = time.perf_counter() - tc
+        cpu = dict(value=round(n_cpu_steps * n_step / synth.SAMPLE_RATE / tcpu, 3), unit="audio-s/s",
+                   cores=ob.lib().orc_num_threads(), kind="port",
+                   sample=f"{n_cpu_steps} steps ({n_cpu_steps * n_step / synth.SAMPLE_RATE:.2f} s of audio) of stream 0, "
+                          f"same weights/PCM, f32 CPU restatement (oracle/nasr_oracle.c, OpenMP), "
+                          f"{ost.total_chunks - c0} chunks in {tcpu:.2f} s")
+
+    if rank == 0:
+        out = {
+            "metric": "RTFx (audio-sec/sec), nemotron-0.6B streaming forward path",
+            "value": round(value, 2),
+            "unit": "audio-s/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}, batch={B} stream(s)/GPU, "
+                            f"{80 * T} ms lookahead (R={R}), {world}xMI355X"
+                            + (" [BASELINE.json configs[1]]" if (B, R, args.dtype, args.layers) == (1, 0, "bf16", 24) else ""),
+                "streams_per_gpu": B, "right_context": R, "audio_s_per_step_per_gpu": audio_per_step,
+                "parallelism": f"stream-sharded x{world}, no collectives",
+                "pcm": "device-resident", "tokens_emitted": tokens_timed, "chunks": chunks_timed,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in kernels],
+            "setup_s": {"weights": round(t_weights, 1)},
+        }
+        print(json.dumps(out), flush=True)
+    for s in streams:
+        s.destroy()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_melframes(MelParams p) {
         __syncthreads();
     }
     for (int k = threadIdx.x; k < NBINS; k += 256) {
-        float mag = __fsqrt_rn(__fadd_rn(__fmul_rn(re[k], re[k]), __fmul_rn(im[k], im[k])));  // :201
+        float mag = sqrtf(__fadd_rn(__fmul_rn(re[k], re[k]), __fmul_rn(im[k], im[k])));  // :201
         pw[k] = __fmul_rn(mag, mag);                                                        // :363-367
     }
     __syncthreads();

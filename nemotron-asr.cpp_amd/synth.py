@@ -33,6 +33,7 @@ HIDDEN = 640
 JOINT = 640
 LEFT_CTX = 70
 PRE_CACHE = 9
+PRED_GAIN = 16.0
 SAMPLE_RATE = 16000
 
 _GOLDEN = np.uint64(0x9E3779B97F4A7C15)
@@ -146,8 +147,8 @@ def global_tensor_specs(num_prompts: int = 0):
                   (p + f"bias_hh_l{l}", (4 * HIDDEN,), "bias", 0)]
     specs += [
         ("joint.enc.weight", (JOINT, D_MODEL), "mat", D_MODEL), ("joint.enc.bias", (JOINT,), "bias", 0),
-        ("joint.pred.weight", (JOINT, HIDDEN), "mat", HIDDEN), ("joint.pred.bias", (JOINT,), "bias", 0),
-        ("joint.joint_net.2.weight", (VOCAB, JOINT), "mat", JOINT), ("joint.joint_net.2.bias", (VOCAB,), "jbias", 0),
+        ("joint.pred.weight", (JOINT, HIDDEN), "jpred", HIDDEN), ("joint.pred.bias", (JOINT,), "bias", 0),
+        ("joint.joint_net.2.weight", (VOCAB, JOINT), "jout", JOINT), ("joint.joint_net.2.bias", (VOCAB,), "bias", 0),
     ]
     if num_prompts > 0:
         specs += [
@@ -172,18 +173,25 @@ def _make(seed, name, shape, kind, fan_in, blank_bias):
         return _tensor(seed, name, shape, 0.05)
     if kind == "posbias":
         return _tensor(seed, name, shape, 0.3)
-    if kind == "jbias":
-        b = _tensor(seed, name, shape, 0.05)
-        # Random joint weights give ~N(0,1) logits over 1025 classes; a trained model emits
-        # blank on most frames.  Raising the blank bias makes the synthetic emission rate
-        # realistic (measured ~0.33 tokens per 80 ms frame at +3.8) instead of 10 symbols per frame.
-        b[BLANK] += blank_bias
-        return b
+    if kind == "jpred":
+        # The 2-layer LSTM output of a random network is small (rms ~0.06); a gain of 16 makes the
+        # prediction-network term as large as the encoder term, so an emission re-randomises the
+        # next decision (otherwise a frame that emits once emits the 10-symbol cap every time).
+        return _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)) * PRED_GAIN)
+    if kind == "jout":
+        # Random joint weights give ~N(0, s^2) logits over 1024 tokens whose maximum scales with the
+        # activation level s.  A trained model emits blank on most frames: the blank row is a
+        # constant g/640, i.e. blank logit = g * mean(relu(.)), which scales with s too, so the
+        # blank/non-blank balance does not drift with the decoder state.  g = blank_gain = 5.5
+        # gives ~0.1-0.4 tokens per 80 ms frame with 0-10 symbols per emitting frame (measured).
+        w = _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)))
+        w[BLANK, :] = np.float32(blank_bias / fan_in)
+        return w
     raise ValueError(kind)
 
 
 def make_weights(n_layers: int = 24, seed: int = 0xC0FFEE, kernel_size: int = 9,
-                 num_prompts: int = 0, blank_bias: float = 3.8, layers=None) -> dict:
+                 num_prompts: int = 0, blank_bias: float = 5.5, layers=None) -> dict:
     """name -> float32 ndarray for the whole model (2.4 GB at 24 layers).
 
     `layers`: optional iterable of layer indices to materialise (default: all)."""

@@ -42,7 +42,16 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # Bound the OpenMP team: GPU hosts expose hundreds of hardware threads but the job may be
+        # pinned to a few, and an oversubscribed spinning team is orders of magnitude slower.
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(str(ORACLE_SO))
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        try:
+            n_cpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n_cpu = os.cpu_count() or 1
+        L.orc_set_num_threads(int(os.environ.get("NASR_ORACLE_THREADS", min(n_cpu, 16))))
         L.orc_model_create.restype = C.c_void_p
         L.orc_model_create.argtypes = [C.c_int] * 4
         L.orc_model_set_tensor.argtypes = [C.c_void_p, C.c_char_p, _fp, C.c_int64]

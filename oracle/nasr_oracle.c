@@ -24,6 +24,14 @@
 /* small helpers                                                                   */
 /* ------------------------------------------------------------------------------ */
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -69,7 +77,7 @@ static inline float siluf_(float x) { return x * sigmoidf_(x); }
  * (ggml_mul_mat(w, x) with w stored [out][in]; src/reference/ops.cpp:28-58) */
 static void gemm_nt(const float *x, int M, int K, const float *w, int N,
                     const float *bias, float *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((size_t)N * K * M > 200000)
     for (int n = 0; n < N; n++) {
         const float *wr = w + (size_t)n * K;
         for (int m = 0; m < M; m++) {
