@@ -9,32 +9,25 @@
 // frame :849; arg-max keeps the first maximum :899-906).  Streams are independent, so the
 // result is identical to the reference's sequential per-stream loop.
 //
-// All arithmetic is f32 (the reference keeps decoder/joint weights F32 in every GGUF flavour).
+// All arithmetic is f32 (the reference keeps decoder/joint weights F32 in every GGUF flavour):
+// the three mat-vec stages are batched over the streams and run on the f32-input MFMA
+// (v_mfma_f32_16x16x4_f32, bit-exact fmaf chains).  Weights are pre-packed at upload into
+// MFMA A-fragment order -- tile (nt, kg) = 16 rows x 16 k is 1 KiB, lane l = q*16 + r holds
+// W[row(nt, r)][kg*16 + 4q .. +4) as one float4 = its operand for 4 consecutive MFMAs -- so a
+// wave-load is one contiguous 1 KiB read.  The stream vectors are the B operand: lane (q, j)
+// loads x[stream j][kg*16 + 4q .. +4), contiguous as well.  For the LSTM the 16 rows of a tile
+// are ordered (unit u, gate g) = (r/4, r%4), which lands the four gates i,f,g,o of one hidden
+// unit in the four accumulator registers of one lane: the cell update needs no data movement.
 #include "nasr_internal.h"
 
 namespace nasr {
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// dot of a 640-float weight row with a 640-float vector, lanes strided by 4 floats
-__device__ __forceinline__ float dot640(const float *w, const float *x, int lane) {
-    float s = 0.0f;
-    // 640 = 160 float4; lane handles float4 indices lane, lane+64, lane+128 (<160)
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int idx = lane + c * 64;
-        if (idx < 160) {
-            const float4 a = ((const float4 *)w)[idx], b = ((const float4 *)x)[idx];
-            s += a.x * b.x; s += a.y * b.y; s += a.z * b.z; s += a.w * b.w;
-        }
-    }
-    return wsum(s);
-}
+constexpr int KG640 = HID / 16;     // 40 k-groups of 16
+constexpr int MT_MAX = 4;           // m-tiles (16 streams each) per pass
 
 __global__ void k_dec_begin(DecParams p) {
     if (threadIdx.x == 0) {
@@ -49,61 +42,129 @@ __global__ void k_dec_begin(DecParams p) {
             ct->active = rd.n_dec > 0 ? 1 : 0;
             n += ct->active;
             p.key[b] = 0ull;
-            p.key[p.B + b] = 0ull;
         }
         *p.n_active = n;
     }
 }
 
-// LSTM layer L for every active stream: one wave per hidden unit j (its 4 gate rows i,f,g,o:
-// src/nemo-ggml.cpp:601-612).  grid = 160 x 4 waves.  New state goes to version 1-cur.
-template <int L>
-__global__ __launch_bounds__(256) void k_dec_lstm(DecParams p) {
-    if (*p.n_active == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + wave;
-    const float *wih = p.w_ih[L], *whh = p.w_hh[L], *bih = p.b_ih[L], *bhh = p.b_hh[L];
-    for (int b = 0; b < p.B; b++) {
-        const int slot = p.rows[b].slot;
-        const DecCtrl ct = p.ctrl[slot];
-        if (!ct.active) continue;
-        const float *hc = p.h + (((size_t)slot * 2 + ct.cur) * 2) * HID;       // committed [2][640]
-        const float *cc = p.c + (((size_t)slot * 2 + ct.cur) * 2) * HID;
-        float *hn = p.h + (((size_t)slot * 2 + (ct.cur ^ 1)) * 2) * HID;       // candidate
-        float *cn = p.c + (((size_t)slot * 2 + (ct.cur ^ 1)) * 2) * HID;
-        const float *x = L == 0 ? p.embed + (size_t)ct.prev_token * HID : hn;  // layer 1 input = h0'
-        const float *hp = hc + L * HID;
-        float g[4];
+// acc[mt] += W_tile(nt, kg range) . X   for MT m-tiles; xrow[mt] = this lane's stream vector
+template <int MT>
+__device__ __forceinline__ void mfma_range(const float4 *wt, int kg0, int kg1, const float *const *xrow, int q,
+                                           f32x4 *acc) {
+    for (int kg = kg0; kg < kg1; kg++) {
+        const float4 w = wt[(size_t)kg * 64];
 #pragma unroll
-        for (int gi = 0; gi < 4; gi++) {
-            const int row = gi * HID + j;
-            const float a = dot640(wih + (size_t)row * HID, x, lane);           // :595
-            const float bsum = dot640(whh + (size_t)row * HID, hp, lane);       // :596
-            g[gi] = ((a + bsum) + bih[row]) + bhh[row];                         // :597-599
-        }
-        if (lane == 0) {
-            const float cprev = cc[L * HID + j];
-            const float cnew = sigm(g[1]) * cprev + sigm(g[0]) * tanhf(g[2]);   // :615
-            cn[L * HID + j] = cnew;
-            hn[L * HID + j] = sigm(g[3]) * tanhf(cnew);                         // :618
+        for (int mt = 0; mt < MT; mt++) {
+            const float4 x = *(const float4 *)(xrow[mt] + kg * 16 + q * 4);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc[mt], 0, 0, 0);
         }
     }
 }
 
-// joint hidden: relu(enc_proj[frame] + W_pred . h1' + b_pred)  (src/nemo-ggml.cpp:1204-1217)
+// ---- LSTM layer L: grid = 160 (4 hidden units per workgroup), 4 waves split K ----------------------
+template <int L>
+__global__ __launch_bounds__(256) void k_dec_lstm(DecParams p) {
+    if (*p.n_active == 0) return;
+    __shared__ float red[4][2][MT_MAX][64][4];
+    const int nt = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane >> 4, r = lane & 15;
+    const float4 *w_ih = (const float4 *)p.w_ih[L] + (size_t)nt * KG640 * 64 + lane;
+    const float4 *w_hh = (const float4 *)p.w_hh[L] + (size_t)nt * KG640 * 64 + lane;
+    const int kg0 = wave * (KG640 / 4), kg1 = kg0 + KG640 / 4;
+    for (int b0 = 0; b0 < p.B; b0 += 16 * MT_MAX) {
+        const float *xr[MT_MAX], *hr[MT_MAX];
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++) {
+            int b = b0 + mt * 16 + r;
+            if (b >= p.B) b = 0;                                   // valid memory, result discarded
+            const int slot = p.rows[b].slot;
+            const DecCtrl ct = p.ctrl[slot];
+            const float *hcom = p.h + (((size_t)slot * 2 + ct.cur) * 2) * HID;
+            const float *hnew = p.h + (((size_t)slot * 2 + (ct.cur ^ 1)) * 2) * HID;
+            xr[mt] = L == 0 ? p.embed + (size_t)ct.prev_token * HID : hnew;   // layer 1 input = h0'
+            hr[mt] = hcom + L * HID;
+        }
+        f32x4 ai[MT_MAX], ah[MT_MAX];
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++) { ai[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ah[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        mfma_range<MT_MAX>(w_ih, kg0, kg1, xr, q, ai);             // src/nemo-ggml.cpp:595
+        mfma_range<MT_MAX>(w_hh, kg0, kg1, hr, q, ah);             // :596
+        __syncthreads();                                           // previous pass done with `red`
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { red[wave][0][mt][lane][j] = ai[mt][j]; red[wave][1][mt][lane][j] = ah[mt][j]; }
+        __syncthreads();
+        // wave mt finishes m-tile mt: lane (q, r) holds gates i,f,g,o of unit nt*4+q for stream b
+        const int mt = wave;
+        const int b = b0 + mt * 16 + r;
+        if (b < p.B) {
+            const int slot = p.rows[b].slot;
+            const DecCtrl ct = p.ctrl[slot];
+            if (ct.active) {
+                const int unit = nt * 4 + q;
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float gi = ((red[0][0][mt][lane][j] + red[1][0][mt][lane][j]) + red[2][0][mt][lane][j]) + red[3][0][mt][lane][j];
+                    const float gh = ((red[0][1][mt][lane][j] + red[1][1][mt][lane][j]) + red[2][1][mt][lane][j]) + red[3][1][mt][lane][j];
+                    const int row = j * HID + unit;
+                    g[j] = ((gi + gh) + p.b_ih[L][row]) + p.b_hh[L][row];     // :597-599
+                }
+                const float cprev = p.c[(((size_t)slot * 2 + ct.cur) * 2 + L) * HID + unit];
+                const float cnew = sigm(g[1]) * cprev + sigm(g[0]) * tanhf(g[2]);   // :615
+                p.c[(((size_t)slot * 2 + (ct.cur ^ 1)) * 2 + L) * HID + unit] = cnew;
+                p.h[(((size_t)slot * 2 + (ct.cur ^ 1)) * 2 + L) * HID + unit] = sigm(g[3]) * tanhf(cnew);   // :618
+            }
+        }
+    }
+}
+
+// ---- joint hidden: relu(enc_proj[frame] + W_pred . h1' + b_pred), grid = 40 (:1204-1217) ---------
 __global__ __launch_bounds__(256) void k_dec_jact(DecParams p) {
     if (*p.n_active == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    for (int b = 0; b < p.B; b++) {
-        const int slot = p.rows[b].slot;
-        const DecCtrl ct = p.ctrl[slot];
-        if (!ct.active) continue;
-        const float *h1 = p.h + (((size_t)slot * 2 + (ct.cur ^ 1)) * 2 + 1) * HID;
-        const float d = dot640(p.pred_w + (size_t)n * HID, h1, lane) + p.pred_b[n];
-        if (lane == 0) {
-            const float e = p.encproj[((size_t)b * p.T + ct.t) * JNT + n];
-            p.jact[(size_t)b * JNT + n] = fmaxf(e + d, 0.0f);
+    __shared__ float red[4][MT_MAX][64][4];
+    const int nt = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane >> 4, r = lane & 15;
+    const float4 *w = (const float4 *)p.pred_w + (size_t)nt * KG640 * 64 + lane;
+    const int kg0 = wave * (KG640 / 4), kg1 = kg0 + KG640 / 4;
+    for (int b0 = 0; b0 < p.B; b0 += 16 * MT_MAX) {
+        const float *xr[MT_MAX];
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++) {
+            int b = b0 + mt * 16 + r;
+            if (b >= p.B) b = 0;
+            const int slot = p.rows[b].slot;
+            const int cur = p.ctrl[slot].cur;
+            xr[mt] = p.h + (((size_t)slot * 2 + (cur ^ 1)) * 2 + 1) * HID;   // h1'
+        }
+        f32x4 acc[MT_MAX];
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_range<MT_MAX>(w, kg0, kg1, xr, q, acc);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) red[wave][mt][lane][j] = acc[mt][j];
+        __syncthreads();
+        const int mt = wave;
+        const int b = b0 + mt * 16 + r;
+        if (b < p.B) {
+            const int slot = p.rows[b].slot;
+            const DecCtrl ct = p.ctrl[slot];
+            if (ct.active) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int n = nt * 16 + q * 4 + j;
+                    const float d = (((red[0][mt][lane][j] + red[1][mt][lane][j]) + red[2][mt][lane][j]) + red[3][mt][lane][j]) + p.pred_b[n];
+                    const float e = p.encproj[((size_t)b * p.T + ct.t) * JNT + n];
+                    p.jact[(size_t)b * JNT + n] = fmaxf(e + d, 0.0f);
+                }
+            }
         }
     }
 }
@@ -114,21 +175,51 @@ __device__ __forceinline__ unsigned long long pack_key(float v, int idx) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (uint32_t)idx);
 }
 
-// logits + arg-max (first maximum wins: ties resolved towards the smaller index)
-__global__ __launch_bounds__(256) void k_dec_logits(DecParams p, int parity) {
+// ---- logits + arg-max, grid = 65 (1040 padded vocab rows); first maximum wins (:899-906) -----------
+__global__ __launch_bounds__(256) void k_dec_logits(DecParams p) {
     if (*p.n_active == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + wave;
-    if (v >= VOCAB) return;
-    for (int b = 0; b < p.B; b++) {
-        const int slot = p.rows[b].slot;
-        if (!p.ctrl[slot].active) continue;
-        const float lg = dot640(p.out_w + (size_t)v * JNT, p.jact + (size_t)b * JNT, lane) + p.out_b[v];  // :1220-1221
-        if (lane == 0) atomicMax(&p.key[(size_t)parity * p.B + b], pack_key(lg, v));
+    __shared__ float red[4][MT_MAX][64][4];
+    const int nt = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane >> 4, r = lane & 15;
+    const float4 *w = (const float4 *)p.out_w + (size_t)nt * KG640 * 64 + lane;
+    const int kg0 = wave * (KG640 / 4), kg1 = kg0 + KG640 / 4;
+    for (int b0 = 0; b0 < p.B; b0 += 16 * MT_MAX) {
+        const float *xr[MT_MAX];
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++) {
+            int b = b0 + mt * 16 + r;
+            if (b >= p.B) b = 0;
+            xr[mt] = p.jact + (size_t)b * JNT;
+        }
+        f32x4 acc[MT_MAX];
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_range<MT_MAX>(w, kg0, kg1, xr, q, acc);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT_MAX; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) red[wave][mt][lane][j] = acc[mt][j];
+        __syncthreads();
+        const int mt = wave;
+        const int b = b0 + mt * 16 + r;
+        if (b < p.B && p.ctrl[p.rows[b].slot].active) {
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int v = nt * 16 + q * 4 + j;
+                if (v < VOCAB) {
+                    const float lg = (((red[0][mt][lane][j] + red[1][mt][lane][j]) + red[2][mt][lane][j]) + red[3][mt][lane][j]) + p.out_b[v];   // :1220-1221
+                    const unsigned long long k = pack_key(lg, v);
+                    best = k > best ? k : best;
+                }
+            }
+            if (best) atomicMax(&p.key[b], best);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_dec_commit(DecParams p, int parity) {
+__global__ __launch_bounds__(256) void k_dec_commit(DecParams p) {
     __shared__ int cnt;
     if (*p.n_active == 0) return;
     if (threadIdx.x == 0) cnt = 0;
@@ -137,7 +228,7 @@ __global__ __launch_bounds__(256) void k_dec_commit(DecParams p, int parity) {
         const int slot = p.rows[b].slot;
         DecCtrl *ct = &p.ctrl[slot];
         if (ct->active) {
-            const unsigned long long k = p.key[(size_t)parity * p.B + b];
+            const unsigned long long k = p.key[b];
             const int best = (int)(0xffffffffu - (uint32_t)(k & 0xffffffffull));
             ct->iterations++;
             if (best == BLANK) {                       // src/nemo-stream.cpp:908-911
@@ -153,7 +244,7 @@ __global__ __launch_bounds__(256) void k_dec_commit(DecParams p, int parity) {
             if (ct->t >= ct->n_frames) ct->active = 0;
             else atomicAdd(&cnt, 1);
         }
-        p.key[(size_t)parity * p.B + b] = 0ull;
+        p.key[b] = 0ull;
     }
     __syncthreads();
     if (threadIdx.x == 0) *p.n_active = cnt;
@@ -163,12 +254,12 @@ void launch_decode_begin(const DecParams &p, hipStream_t st) {
     hipLaunchKernelGGL(k_dec_begin, dim3(1), dim3(64), 0, st, p);
 }
 void launch_decode_iter(const DecParams &p, int iter, hipStream_t st) {
-    const int parity = iter & 1;
+    (void)iter;
     hipLaunchKernelGGL(k_dec_lstm<0>, dim3(HID / 4), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_dec_lstm<1>, dim3(HID / 4), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_dec_jact, dim3(JNT / 4), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_dec_logits, dim3((VOCAB + 3) / 4), dim3(256), 0, st, p, parity);
-    hipLaunchKernelGGL(k_dec_commit, dim3(1), dim3(256), 0, st, p, parity);
+    hipLaunchKernelGGL(k_dec_jact, dim3(JNT / 16), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_dec_logits, dim3((VOCAB + 15) / 16), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_dec_commit, dim3(1), dim3(256), 0, st, p);
 }
 
 }  // namespace nasr

@@ -296,6 +296,23 @@ static void transpose_9x256(const std::vector<float> &w /*[256][9]*/, std::vecto
         for (int k = 0; k < 9; k++) t[(size_t)k * SUBC + c] = w[(size_t)c * 9 + k];
 }
 
+// f32 MFMA (16x16x4) A-fragment packing for the decoder matrices: tile (nt, kg) = 16 rows x 16 k,
+// lane l = q*16 + r holds W[row(nt, r)][kg*16 + 4q .. +4).  lstm_order: tile row r = 4*u + gate
+// maps to source row gate*640 + nt*4 + u, so one lane ends up with the 4 gates of one unit.
+static void pack_f32_mfma(const std::vector<float> &w, int N, int K, bool lstm_order, std::vector<float> &out) {
+    const int NT = (N + 15) / 16, KG = K / 16;
+    out.assign((size_t)NT * KG * 64 * 4, 0.0f);
+    for (int nt = 0; nt < NT; nt++)
+        for (int kg = 0; kg < KG; kg++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int q = lane >> 4, r = lane & 15;
+                const int row = lstm_order ? (r & 3) * HID + nt * 4 + (r >> 2) : nt * 16 + r;
+                if (row >= N) continue;
+                for (int sI = 0; sI < 4; sI++)
+                    out[(((size_t)nt * KG + kg) * 64 + lane) * 4 + sI] = w[(size_t)row * K + kg * 16 + 4 * q + sI];
+            }
+}
+
 static void host_pos_emb(int position, float *out) {   // reference src/nemo-ggml.cpp:17-32
     const float p = (float)position;
     for (int i = 0; i < D; i += 2) {
@@ -402,16 +419,25 @@ static int load_weights(nasr_engine *e, const nasr_weight_desc *w, int n_w) {
     if (ld.vec(dp + "embed.weight", (int64_t)VOCAB * HID, &e->embed)) return -1;
     for (int l = 0; l < 2; l++) {
         const std::string s = std::to_string(l);
-        if (ld.vec(dp + "dec_rnn.lstm.weight_ih_l" + s, (int64_t)4 * HID * HID, &e->w_ih[l]) ||
-            ld.vec(dp + "dec_rnn.lstm.weight_hh_l" + s, (int64_t)4 * HID * HID, &e->w_hh[l]) ||
-            ld.vec(dp + "dec_rnn.lstm.bias_ih_l" + s, 4 * HID, &e->b_ih[l]) ||
+        if (ld.get(dp + "dec_rnn.lstm.weight_ih_l" + s, (int64_t)4 * HID * HID, h)) return -1;
+        pack_f32_mfma(h, 4 * HID, HID, true, t);
+        if (ld.upload_vec(t, &e->w_ih[l])) return -1;
+        if (ld.get(dp + "dec_rnn.lstm.weight_hh_l" + s, (int64_t)4 * HID * HID, h)) return -1;
+        pack_f32_mfma(h, 4 * HID, HID, true, t);
+        if (ld.upload_vec(t, &e->w_hh[l])) return -1;
+        if (ld.vec(dp + "dec_rnn.lstm.bias_ih_l" + s, 4 * HID, &e->b_ih[l]) ||
             ld.vec(dp + "dec_rnn.lstm.bias_hh_l" + s, 4 * HID, &e->b_hh[l]))
             return -1;
     }
     if (ld.vec("joint.enc.weight", (int64_t)JNT * D, &e->jenc_w) || ld.vec("joint.enc.bias", JNT, &e->jenc_b) ||
-        ld.vec("joint.pred.weight", (int64_t)JNT * HID, &e->pred_w) || ld.vec("joint.pred.bias", JNT, &e->pred_b) ||
-        ld.vec("joint.joint_net.2.weight", (int64_t)VOCAB * JNT, &e->out_w) || ld.vec("joint.joint_net.2.bias", VOCAB, &e->out_b))
+        ld.vec("joint.pred.bias", JNT, &e->pred_b) || ld.vec("joint.joint_net.2.bias", VOCAB, &e->out_b))
         return -1;
+    if (ld.get("joint.pred.weight", (int64_t)JNT * HID, h)) return -1;
+    pack_f32_mfma(h, JNT, HID, false, t);
+    if (ld.upload_vec(t, &e->pred_w)) return -1;
+    if (ld.get("joint.joint_net.2.weight", (int64_t)VOCAB * JNT, h)) return -1;
+    pack_f32_mfma(h, VOCAB, JNT, false, t);
+    if (ld.upload_vec(t, &e->out_w)) return -1;
     // ---- prompt kernel (multilingual) -----------------------------------------------------
     const int P = e->hp.num_prompts;
     if (P > 0) {
