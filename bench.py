@@ -65,7 +65,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ge.load_package()
-    from nemotron_asr_amd import capi, synth
+    from nemotron_asr_amd import capi, sharding, synth
 
     B, R = args.batch, args.right_context
     T = 1 + R
@@ -83,7 +83,7 @@ def main():
     prof_steps = 0 if args.no_profile_pass else min(args.steps, 50)
     n_total = (total_steps + prof_steps) * n_step
     secs = n_total / synth.SAMPLE_RATE
-    pcm_host = [synth.make_pcm(rank * B + s, secs)[:n_total] for s in range(B)]
+    pcm_host = [synth.make_pcm(sid, secs)[:n_total] for sid in sharding.stream_ids(rank, world, B)]
     pcm_dev = [eng.upload(p) for p in pcm_host]
 
     L = capi.lib()
@@ -106,10 +106,7 @@ def main():
         tokens_total += sum(ntok[b] for b in range(B))
 
     def barrier():
-        eng.synchronize()
-        if dist is not None:
-            dist.barrier()
-        eng.synchronize()
+        sharding.barrier(dist, eng.synchronize)
 
     for k in range(args.warmup):
         run_step(k)
@@ -120,15 +117,11 @@ def main():
         run_step(k)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
     tokens_timed = tokens_total
     chunks_timed = streams[0].stats().chunks
 
-    value = world * audio_per_step * args.steps / elapsed
+    value = sharding.aggregate_rtfx(world, audio_per_step * args.steps, elapsed)
 
     # ---- per-kernel HIP-event pass (same steps, events around every launch) ------------------
     roofline = None

@@ -153,6 +153,9 @@ enum {
     NASR_TAP_CONV_CACHE  = 6, /*                                                 [ks-1][1024]  */
     NASR_TAP_DEC_STATE   = 7, /* h[2][640], c[2][640], then prev_token as float                */
 };
+/* engine options: "fused" (1: small-M fused layer kernels, default) / "graph" (1: hipGraph replay of the
+ * steady-state step, default).  Both are pure performance switches; results are unchanged. */
+int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);
 /* returns the number of floats written (<= cap) or <0 */

@@ -21,7 +21,7 @@ EXPORTS = [
     "nasr_last_error", "nasr_abi_version", "nasr_engine_create", "nasr_engine_destroy",
     "nasr_stream_create", "nasr_stream_reset", "nasr_stream_destroy", "nasr_stream_set_prompt",
     "nasr_stream_get_stats", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
-    "nasr_engine_collect", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
+    "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize",
 ]
@@ -73,6 +73,7 @@ def lib():
         L.nasr_engine_finalize.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, ip]
         L.nasr_engine_collect.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, ip]
         L.nasr_engine_set_debug.argtypes = [vp, C.c_int]
+        L.nasr_engine_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.nasr_stream_get_tap.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64]
         L.nasr_stream_get_tap.restype = C.c_int64
         L.nasr_engine_profile.argtypes = [vp, C.c_int]
@@ -180,6 +181,9 @@ class Engine:
 
     def stream(self, right_context=0, prompt_index=-1) -> Stream:
         return Stream(self, right_context, prompt_index)
+
+    def set_option(self, key: str, value: int):
+        _chk(lib().nasr_engine_set_option(self.h, key.encode(), int(value)))
 
     def set_debug(self, on=True):
         _chk(lib().nasr_engine_set_debug(self.h, int(on)))

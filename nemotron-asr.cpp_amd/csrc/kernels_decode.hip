@@ -250,6 +250,48 @@ __global__ __launch_bounds__(256) void k_dec_commit(DecParams p) {
     if (threadIdx.x == 0) *p.n_active = cnt;
 }
 
+// ---- joint.enc projection hoisted out of the symbol loop: out[m][n] = W[n].x[m] + b[n] -------------
+// (src/nemo-ggml.cpp:1204-1205; the reference recomputes it per symbol).  f32 MFMA, packed weights,
+// grid = (N/16, ceil(M/64)), 4 waves split K.
+__global__ __launch_bounds__(256) void k_encproj(const float *x, const float *wpk, const float *bias, float *out, int M, int K, int N) {
+    __shared__ float red[4][MT_MAX][64][4];
+    const int nt = blockIdx.x, b0 = blockIdx.y * 16 * MT_MAX;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    const int KG = K / 16;
+    const float4 *w = (const float4 *)wpk + (size_t)nt * KG * 64 + lane;
+    const int kg0 = wave * (KG / 4), kg1 = kg0 + KG / 4;
+    const float *xr[MT_MAX];
+#pragma unroll
+    for (int mt = 0; mt < MT_MAX; mt++) {
+        int m = b0 + mt * 16 + r;
+        if (m >= M) m = M - 1;
+        xr[mt] = x + (size_t)m * K;
+    }
+    f32x4 acc[MT_MAX];
+#pragma unroll
+    for (int mt = 0; mt < MT_MAX; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_range<MT_MAX>(w, kg0, kg1, xr, q, acc);
+#pragma unroll
+    for (int mt = 0; mt < MT_MAX; mt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) red[wave][mt][lane][j] = acc[mt][j];
+    __syncthreads();
+    const int mt = wave, m = b0 + mt * 16 + r;
+    if (m < M) {
+        float4 o;
+        float *op = (float *)&o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = nt * 16 + q * 4 + j;
+            op[j] = (((red[0][mt][lane][j] + red[1][mt][lane][j]) + red[2][mt][lane][j]) + red[3][mt][lane][j]) + bias[n];
+        }
+        *(float4 *)(out + (size_t)m * N + nt * 16 + q * 4) = o;
+    }
+}
+void launch_encproj(const float *x, const float *wpk, const float *bias, float *out, int M, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(k_encproj, dim3(N / 16, (M + 16 * MT_MAX - 1) / (16 * MT_MAX)), dim3(256), 0, st, x, wpk, bias, out, M, K, N);
+}
+
 void launch_decode_begin(const DecParams &p, hipStream_t st) {
     hipLaunchKernelGGL(k_dec_begin, dim3(1), dim3(64), 0, st, p);
 }

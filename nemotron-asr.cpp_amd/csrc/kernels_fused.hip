@@ -1,0 +1,433 @@
+// kernels_fused.hip -- the batch-1 / small-M (M <= 16 rows) form of the conformer layer.
+//
+// At small M every linear layer is a weight-streaming problem (HBM-bound) and the step is
+// dominated by kernel count, not bytes: the unfused layer is 14 launches.  Here the
+// element-wise / reduction stages ride in the PROLOGUE of the GEMM that consumes them, so a
+// layer is 8 launches:
+//   PRO_LN     residual add of the previous GEMM's split-K partials + LayerNorm (+ the previous
+//              layer's norm_out) -> bf16 A panel in LDS               (k_post folded in)
+//   PRO_ATTN   cached rel-pos attention of ONE head (blockIdx.y) -> that head's 128 ctx columns;
+//              the out-projection is split-K over the 8 heads         (k_attention folded in)
+//   PRO_DWCONV cached depthwise conv + LayerNorm + SiLU -> A panel     (k_dwconv folded in)
+//   PRO_PLAIN  activations straight from global (FFN second linear)
+// Every workgroup recomputes the tiny prologue redundantly (M x 1024 elements, L2 resident);
+// block (0,0) alone writes state that must persist (updated residual stream, conv cache).
+// The GEMM body / weight layout / epilogues are those of k_gemm_skinny (kernels_gemm.hip).
+#include "nasr_internal.h"
+#include "nasr_epilogue.h"
+
+namespace nasr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ float wsum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wmax_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// LDS A panel: [16 rows][KP] bf16, 16-byte chunks XOR-swizzled with the row so that the MFMA
+// B-fragment read (16 rows x same chunk) is bank-conflict free.
+__device__ __forceinline__ int panel_byte(int row, int k, int KP) {   // k multiple of 4 -> 8-byte aligned
+    const int chunk = k >> 3;
+    return row * KP * 2 + (((chunk ^ (row & 15)) << 4) | ((k & 7) << 1));
+}
+
+__device__ __forceinline__ void store4_panel(char *panel, int row, int k, int KP, float a, float b, float c, float d) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    r.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    *(uint2 *)(panel + panel_byte(row, k, KP)) = r;
+}
+
+// LayerNorm of a 1024-row held as 16 values per lane (4 float4 at e = lane*4 + 256*i)
+__device__ __forceinline__ void wave_ln(float4 v[4], const float *w, const float *b, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wsum_f(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float inv = 1.0f / sqrtf(wsum_f(q) * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = lane * 4 + 256 * i;
+        const float4 ww = *(const float4 *)(w + e), bb = *(const float4 *)(b + e);
+        v[i] = make_float4(v[i].x * inv * ww.x + bb.x, v[i].y * inv * ww.y + bb.y, v[i].z * inv * ww.z + bb.z, v[i].w * inv * ww.w + bb.w);
+    }
+}
+
+// sum over the 256-thread block; sh = 4 floats of LDS scratch
+__device__ __forceinline__ float bsum(float v, float *sh) {
+    v = wsum_f(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// LayerNorm of one 1024-row spread over the block (4 channels per thread), weights already loaded
+__device__ __forceinline__ float4 block_ln(float4 v, float4 ww, float4 bb, float *sh) {
+    const float mean = bsum((v.x + v.y) + (v.z + v.w), sh) * (1.0f / D);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float var = bsum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh) * (1.0f / D);
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    return make_float4(dx * inv * ww.x + bb.x, dy * inv * ww.y + bb.y, dz * inv * ww.z + bb.z, dw * inv * ww.w + bb.w);
+}
+
+template <bool BF16>
+__device__ __forceinline__ float dot32(const float *qs, const void *row) {   // 32 elements
+    float s = 0.0f;
+    if (BF16) {
+        const uint4 *r = (const uint4 *)row;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint4 u = r[c];
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                s += qs[c * 8 + 2 * e] * __uint_as_float(w[e] << 16);
+                s += qs[c * 8 + 2 * e + 1] * __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+    }
+    return s;
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmParams &g = p.g;
+    const int nt = blockIdx.x, split = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane >> 4, r = lane & 15;
+    const int KT = g.K >> 5;
+    const int t0 = (int)((long)KT * split / g.splits), t1 = (int)((long)KT * (split + 1) / g.splits);
+    const int KP = (t1 - t0) * 32;                 // K range of this workgroup
+    float *red = (float *)smem;                    // [4][64][4] floats = 4 KiB
+    char *panel = smem + 4096;                     // [16][KP] bf16
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+    const int M = g.M;
+
+    // The weight stream does not depend on the prologue: issue this wave's tiles (<= 8 KiB) first so
+    // the HBM latency runs under the prologue.
+    constexpr int U = 8;
+    const int nts = t1 - t0;
+    const int w0 = t0 + nts * wave / 4, w1 = t0 + nts * (wave + 1) / 4;   // host guarantees w1 - w0 <= U
+    const u32x4 *wp = (const u32x4 *)g.W + (size_t)nt * KT * 64 + lane;
+    u32x4 wv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
+        wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
+    }
+
+    if (PRO == PRO_LN && M <= 4) {
+        // block-per-row: every global load of the prologue is issued up front (one memory round trip)
+        const int c4 = threadIdx.x * 4;
+        const float4 lw = *(const float4 *)(p.ln_w + c4), lb = *(const float4 *)(p.ln_b + c4);
+        float4 ow = make_float4(0.f, 0.f, 0.f, 0.f), ob = ow;
+        if (p.lno_w) { ow = *(const float4 *)(p.lno_w + c4); ob = *(const float4 *)(p.lno_b + c4); }
+        float4 xv[4], t[4][8];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (m < M) {
+                xv[m] = *(const float4 *)(p.x_in + (size_t)m * D + c4);
+#pragma unroll
+                for (int sI = 0; sI < 8; sI++)
+                    t[m][sI] = sI < p.part_splits ? *(const float4 *)(p.part + ((size_t)sI * M + m) * D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (m < M) {
+                float4 v = xv[m];
+                if (p.part_splits > 0) {
+                    float4 o = t[m][0];
+#pragma unroll
+                    for (int sI = 1; sI < 8; sI++)
+                        if (sI < p.part_splits) { o.x += t[m][sI].x; o.y += t[m][sI].y; o.z += t[m][sI].z; o.w += t[m][sI].w; }
+                    v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
+                }
+                if (p.lno_w) v = block_ln(v, ow, ob, red);                 // previous layer's norm_out (:687)
+                if (writer && p.x_out) *(float4 *)(p.x_out + (size_t)m * D + c4) = v;
+                v = block_ln(v, lw, lb, red);
+                store4_panel(panel, m, c4, KP, v.x, v.y, v.z, v.w);
+            }
+        }
+        __syncthreads();
+    } else if (PRO == PRO_LN) {
+        for (int m = wave; m < M; m += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = lane * 4 + 256 * i;
+                v[i] = *(const float4 *)(p.x_in + (size_t)m * D + e);
+                if (p.part_splits > 0) {
+                    float4 t[8];
+#pragma unroll
+                    for (int s = 0; s < 8; s++)      // independent loads: issued together, summed in order
+                        t[s] = s < p.part_splits ? *(const float4 *)(p.part + ((size_t)s * M + m) * D + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 o = t[0];
+#pragma unroll
+                    for (int s = 1; s < 8; s++)
+                        if (s < p.part_splits) { o.x += t[s].x; o.y += t[s].y; o.z += t[s].z; o.w += t[s].w; }
+                    v[i].x += p.scale * o.x; v[i].y += p.scale * o.y; v[i].z += p.scale * o.z; v[i].w += p.scale * o.w;
+                }
+            }
+            if (p.lno_w) wave_ln(v, p.lno_w, p.lno_b, lane);           // previous layer's norm_out (:687)
+            if (writer && p.x_out) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) *(float4 *)(p.x_out + (size_t)m * D + lane * 4 + 256 * i) = v[i];
+            }
+            wave_ln(v, p.ln_w, p.ln_b, lane);
+#pragma unroll
+            for (int i = 0; i < 4; i++) store4_panel(panel, m, lane * 4 + 256 * i, KP, v[i].x, v[i].y, v[i].z, v[i].w);
+        }
+        __syncthreads();
+    } else if (PRO == PRO_ATTN) {
+        // one head (= split) of the cached rel-pos attention for all M rows (src/nemo-stream.cpp:463-573)
+        const AttnParams &a = p.at;
+        const int h = split, T = a.T, KV = LCTX + T;
+        float *qu = (float *)(panel + 16 * KP * 2);                  // [16][128]
+        float *qv = qu + 16 * DH;                                    // [16][128]
+        float *sc = qv + 16 * DH;                                    // [16][KVC]
+        for (int e = threadIdx.x; e < M * DH; e += 256) {
+            const int m = e >> 7, d = e & 127;
+            const float qq = a.q[(size_t)m * D + h * DH + d];
+            qu[e] = qq + a.bias_u[h * DH + d];
+            qv[e] = qq + a.bias_v[h * DH + d];
+        }
+        __syncthreads();
+        const float scale = 0.08838834764831845f;
+        const int sub = threadIdx.x & 1;                     // 2 lanes per (row, key) pair, 64 dims each
+        for (int pr = threadIdx.x >> 1; pr < ((M * KV + 127) & ~127); pr += 128) {   // uniform trip count
+            const bool ok = pr < M * KV;
+            const int m = ok ? pr / KV : 0, j = ok ? pr - m * KV : 0;
+            const int b = m / T, i = m - b * T;
+            const RowDesc rd = a.rows[b];
+            int ring = rd.kv_head + j;
+            if (ring >= KVC) ring -= KVC;
+            const bf16_t *krow = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)ring * D + h * DH + sub * 64;
+            const bf16_t *prow = (const bf16_t *)a.posproj + (size_t)(j + T - 1 - i) * D + h * DH + sub * 64;
+            uint4 kk[8], pp[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) { kk[c] = ((const uint4 *)krow)[c]; pp[c] = ((const uint4 *)prow)[c]; }
+            const float *qa = qu + m * DH + sub * 64, *qb = qv + m * DH + sub * 64;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const uint32_t kw[4] = {kk[c].x, kk[c].y, kk[c].z, kk[c].w}, pw[4] = {pp[c].x, pp[c].y, pp[c].z, pp[c].w};
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++) {
+                    s1 += qa[c * 8 + 2 * e2] * __uint_as_float(kw[e2] << 16);
+                    s1 += qa[c * 8 + 2 * e2 + 1] * __uint_as_float(kw[e2] & 0xffff0000u);
+                    s2 += qb[c * 8 + 2 * e2] * __uint_as_float(pw[e2] << 16);
+                    s2 += qb[c * 8 + 2 * e2 + 1] * __uint_as_float(pw[e2] & 0xffff0000u);
+                }
+            }
+            float v = s1 + s2;
+            v += __shfl_xor(v, 1);
+            if (ok && sub == 0) {
+                v *= scale;
+                if (j < LCTX - rd.valid_len) v += -1e9f;
+                sc[m * KVC + j] = v;
+            }
+        }
+        __syncthreads();
+        for (int m = wave; m < M; m += 4) {
+            const float v0 = lane < KV ? sc[m * KVC + lane] : -INFINITY;
+            const float v1 = lane + 64 < KV ? sc[m * KVC + lane + 64] : -INFINITY;
+            const float mx = wmax_f(fmaxf(v0, v1));
+            const float e0 = lane < KV ? __expf(v0 - mx) : 0.0f;
+            const float e1 = lane + 64 < KV ? __expf(v1 - mx) : 0.0f;
+            const float inv = 1.0f / wsum_f(e0 + e1);
+            if (lane < KV) sc[m * KVC + lane] = e0 * inv;
+            if (lane + 64 < KV) sc[m * KVC + lane + 64] = e1 * inv;
+        }
+        __syncthreads();
+        // P.V: thread = (key group kg of 8, 4 consecutive d); partial sums reduced through LDS
+        {
+            float *pv = qu;                                   // reuse: [8 groups][16 rows... handled per row][128]
+            const int dq = threadIdx.x & 31, kgp = threadIdx.x >> 5;
+            for (int m = 0; m < M; m++) {
+                const int b = m / T;
+                const RowDesc rd = a.rows[b];
+                const bf16_t *vbase = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)KVC * D + h * DH + dq * 4;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                uint2 vv[11];
+#pragma unroll
+                for (int u = 0; u < 11; u++) {                // KV <= 84 -> at most 11 keys per group
+                    const int j = kgp + 8 * u;
+                    int ring = rd.kv_head + (j < KV ? j : 0);
+                    if (ring >= KVC) ring -= KVC;
+                    vv[u] = *(const uint2 *)(vbase + (size_t)ring * D);
+                }
+#pragma unroll
+                for (int u = 0; u < 11; u++) {
+                    const int j = kgp + 8 * u;
+                    const float w = j < KV ? sc[m * KVC + j] : 0.0f;
+                    acc.x += w * __uint_as_float(vv[u].x << 16); acc.y += w * __uint_as_float(vv[u].x & 0xffff0000u);
+                    acc.z += w * __uint_as_float(vv[u].y << 16); acc.w += w * __uint_as_float(vv[u].y & 0xffff0000u);
+                }
+                __syncthreads();                              // previous row's reduction done with pv
+                *(float4 *)(pv + kgp * DH + dq * 4) = acc;
+                __syncthreads();
+                if (threadIdx.x < DH) {
+                    const int d = threadIdx.x;
+                    float o = 0.f;
+#pragma unroll
+                    for (int gI = 0; gI < 8; gI++) o += pv[gI * DH + d];
+                    *(bf16_t *)(panel + m * KP * 2 + ((((d >> 3) ^ (m & 15)) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
+                }
+            }
+        }
+        __syncthreads();
+    } else if (PRO == PRO_DWCONV) {
+        const ConvParams &c = p.cv;
+        const int T = c.T, ks1 = c.ks - 1;
+        const int k0 = t0 * 32;
+        if (M <= 4) {
+            // block-per-row, 4 channels per thread; taps unrolled so all loads are in flight together
+            const int c4 = threadIdx.x * 4;
+            const float4 lw = *(const float4 *)(c.ln_w + c4), lb = *(const float4 *)(c.ln_b + c4);
+            for (int m = 0; m < M; m++) {
+                const int b = m / T, i = m - b * T;
+                const RowDesc rd = c.rows[b];
+                const float *cc_in = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)rd.cc_par * ks1 * D;
+                float *cc_out = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
+                const float *gl = c.glu + (size_t)b * T * D;
+                float4 acc;
+                if (c.ks == 9) {
+                    float4 z[9], w[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        const int rr = i + k;
+                        z[k] = rr < 8 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - 8) * D + c4);
+                        w[k] = *(const float4 *)(c.dw + (size_t)k * D + c4);
+                    }
+                    acc = make_float4(z[0].x * w[0].x, z[0].y * w[0].y, z[0].z * w[0].z, z[0].w * w[0].w);
+#pragma unroll
+                    for (int k = 1; k < 9; k++) { acc.x += z[k].x * w[k].x; acc.y += z[k].y * w[k].y; acc.z += z[k].z * w[k].z; acc.w += z[k].w * w[k].w; }
+                } else {
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < c.ks; k++) {
+                        const int rr = i + k;
+                        const float4 z = rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + c4);
+                        const float4 w = *(const float4 *)(c.dw + (size_t)k * D + c4);
+                        if (k == 0) acc = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
+                        else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
+                    }
+                }
+                float4 n = block_ln(acc, lw, lb, red);
+                if (c4 >= k0 && c4 < k0 + KP) {
+                    n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));
+                    n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
+                    store4_panel(panel, m, c4 - k0, KP, n.x, n.y, n.z, n.w);
+                }
+                if (writer && i == 0) {
+                    for (int r2 = 0; r2 < ks1; r2++) {
+                        const int rr = T + r2;
+                        *(float4 *)(cc_out + (size_t)r2 * D + c4) =
+                            rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + c4);
+                    }
+                }
+            }
+        } else
+        for (int m = wave; m < M; m += 4) {
+            const int b = m / T, i = m - b * T;
+            const RowDesc rd = c.rows[b];
+            const float *cc_in = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)rd.cc_par * ks1 * D;
+            float *cc_out = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
+            const float *gl = c.glu + (size_t)b * T * D;
+            float4 v[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int e = lane * 4 + 256 * ii;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < c.ks; k++) {
+                    const int rr = i + k;
+                    const float4 z = rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + e) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + e);
+                    const float4 w = *(const float4 *)(c.dw + (size_t)k * D + e);
+                    if (k == 0) acc = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
+                    else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
+                }
+                v[ii] = acc;
+            }
+            wave_ln(v, c.ln_w, c.ln_b, lane);
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const int e = lane * 4 + 256 * ii;
+                if (e >= k0 && e < k0 + KP) {
+                    float4 n = v[ii];
+                    n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));
+                    n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
+                    store4_panel(panel, m, e - k0, KP, n.x, n.y, n.z, n.w);
+                }
+            }
+            if (writer && i == 0) {   // new conv cache = last ks-1 rows of [cache ; glu] -> other parity buffer
+                for (int r2 = 0; r2 < ks1; r2++) {
+                    const int rr = T + r2;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ii++) {
+                        const int e = lane * 4 + 256 * ii;
+                        const float4 z = rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + e) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + e);
+                        *(float4 *)(cc_out + (size_t)r2 * D + e) = z;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- GEMM over this workgroup's k-tiles (weights already in registers) -------------------------
+    const char *arow = nullptr;
+    if (PRO == PRO_PLAIN) arow = (const char *)g.A + ((size_t)(r < M ? r : M - 1) * g.lda) * 2 + q * 16;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int kt = w0 + u;
+        if (kt < w1) {
+            uint4 av;
+            if (PRO == PRO_PLAIN) av = *(const uint4 *)(arow + (size_t)kt * 64);
+            else av = *(const uint4 *)(panel + r * KP * 2 + (((((kt - t0) << 2) | q) ^ r) << 4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[u]), __builtin_bit_cast(bf16x8, av), acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) red[(wave * 64 + lane) * 4 + j] = acc[j];
+    __syncthreads();
+    if (wave == 0) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = ((red[lane * 4 + j] + red[(64 + lane) * 4 + j]) + red[(128 + lane) * 4 + j]) + red[(192 + lane) * 4 + j];
+        epi_quad<true>(g, split, r, nt * 16 + q * 4, v[0], v[1], v[2], v[3]);
+    }
+}
+
+void launch_fused_skinny(const FusedParams &p, hipStream_t st) {
+    const GemmParams &g = p.g;
+    const int KP = (g.K / g.splits);
+    size_t lds = 4096 + (size_t)16 * KP * 2;
+    if (p.pro == PRO_ATTN) lds += (size_t)(2 * 16 * DH + 16 * KVC) * 4;
+    dim3 grid(g.N / 16, g.splits);
+    switch (p.pro) {
+    case PRO_LN: hipLaunchKernelGGL(k_fused_skinny<PRO_LN>, grid, dim3(256), lds, st, p); break;
+    case PRO_PLAIN: hipLaunchKernelGGL(k_fused_skinny<PRO_PLAIN>, grid, dim3(256), 4096, st, p); break;
+    case PRO_ATTN: hipLaunchKernelGGL(k_fused_skinny<PRO_ATTN>, grid, dim3(256), lds, st, p); break;
+    case PRO_DWCONV: hipLaunchKernelGGL(k_fused_skinny<PRO_DWCONV>, grid, dim3(256), lds, st, p); break;
+    }
+}
+
+}  // namespace nasr

@@ -72,7 +72,7 @@ struct nasr_stream {
     int valid_len, kv_head, cc_par;  // cache_valid_len, K/V ring head, conv-cache parity
     int chunks, tok_read;
     int64_t samples_in;
-    int last_T;                      // rows of the last chunk (for taps)
+    int last_T, last_row;            // rows of the last chunk (for taps)
     bool alive;
 };
 
@@ -97,7 +97,14 @@ struct nasr_engine {
     DecCtrl *ctrl;
     int *tok_ring;
     // workspace (sized for max_streams x TMAX rows)
-    float *x, *part, *q, *glu, *encproj, *sub_a, *hfuse;
+    float *x, *x2, *part, *q, *glu, *encproj, *sub_a, *hfuse;
+    bool opt_fused = true, opt_graph = true;
+    // hipGraph replay of the steady-state step: fixed descriptor buffers + one exec per (B, T)
+    std::map<int, hipGraphExec_t> graphs;
+    RowDesc *g_rows = nullptr; PcmDesc *g_pcm = nullptr; int *g_meta = nullptr;       // device
+    char *gh = nullptr;                                                               // pinned host block
+    RowDesc *gh_rows = nullptr; PcmDesc *gh_pcm = nullptr; int *gh_meta = nullptr, *gh_collect = nullptr, *gh_active = nullptr;
+    int64_t graph_replays = 0, eager_steps = 0;
     void *a, *hbuf, *ctx, *cbuf, *sub_b;
     float *jact;
     unsigned long long *key;
@@ -429,7 +436,10 @@ static int load_weights(nasr_engine *e, const nasr_weight_desc *w, int n_w) {
             ld.vec(dp + "dec_rnn.lstm.bias_hh_l" + s, 4 * HID, &e->b_hh[l]))
             return -1;
     }
-    if (ld.vec("joint.enc.weight", (int64_t)JNT * D, &e->jenc_w) || ld.vec("joint.enc.bias", JNT, &e->jenc_b) ||
+    if (ld.get("joint.enc.weight", (int64_t)JNT * D, h)) return -1;
+    pack_f32_mfma(h, JNT, D, false, t);
+    if (ld.upload_vec(t, &e->jenc_w)) return -1;
+    if (ld.vec("joint.enc.bias", JNT, &e->jenc_b) ||
         ld.vec("joint.pred.bias", JNT, &e->pred_b) || ld.vec("joint.joint_net.2.bias", VOCAB, &e->out_b))
         return -1;
     if (ld.get("joint.pred.weight", (int64_t)JNT * HID, h)) return -1;
@@ -536,6 +546,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     rc |= dalloc(e, &e->ctrl, S);
     rc |= dalloc(e, &e->tok_ring, S * TOK_CAP);
     rc |= dalloc(e, &e->x, M * D);
+    rc |= dalloc(e, &e->x2, M * D);
     rc |= dalloc(e, &e->part, 8 * M * D);
     rc |= dalloc(e, &e->q, M * D);
     rc |= dalloc(e, &e->glu, M * D);
@@ -559,6 +570,14 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     if (hipHostMalloc((void **)&e->pin, e->pin_cap, hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
     e->ddesc_cap = 8u << 20;
     if (hipMalloc((void **)&e->ddesc, e->ddesc_cap) != hipSuccess) { nasr_engine_destroy(e); return fail("hipMalloc desc failed"); }
+    {
+        const size_t off_rows = 0, off_pcm = off_rows + S * sizeof(RowDesc), off_meta = off_pcm + S * sizeof(PcmDesc);
+        const size_t off_col = off_meta + 2 * S * sizeof(int), off_act = off_col + S * (1 + COLLECT_STRIDE) * sizeof(int);
+        if (hipHostMalloc((void **)&e->gh, off_act + 64, hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+        e->gh_rows = (RowDesc *)(e->gh + off_rows); e->gh_pcm = (PcmDesc *)(e->gh + off_pcm); e->gh_meta = (int *)(e->gh + off_meta);
+        e->gh_collect = (int *)(e->gh + off_col); e->gh_active = (int *)(e->gh + off_act);
+        if (dalloc(e, &e->g_rows, S) || dalloc(e, &e->g_pcm, S) || dalloc(e, &e->g_meta, 2 * S)) { nasr_engine_destroy(e); return -1; }
+    }
     e->slots.assign(S, nullptr);
     e->tap_mel_frames.assign(S, 0);
     e->tap_mel_row.assign(S, 0);
@@ -573,6 +592,8 @@ extern "C" void nasr_engine_destroy(nasr_engine *e) {
     if (e->st) hipStreamSynchronize(e->st);
     for (auto *s : e->slots) delete s;
     for (void *p : e->allocs) hipFree(p);
+    for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
+    if (e->gh) hipHostFree(e->gh);
     if (e->pin) hipHostFree(e->pin);
     if (e->ddesc) hipFree(e->ddesc);
     if (e->pcm_stage) hipFree(e->pcm_stage);
@@ -712,21 +733,91 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
     return s;
 }
 
-static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, const std::vector<int> &n_dec) {
-    const int B = (int)rows_s.size();
-    const int T = rows_s[0]->T, R = rows_s[0]->R;
+// ---- small-M form of the 24 layers: 8 launches per layer (kernels_fused.hip) ------------------------
+static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T) {
+    const int M = B * T, nL = e->hp.n_layers, ks = e->hp.kernel_size;
+    hipStream_t st = e->st;
+    float *X[2] = {e->x, e->x2};
+    int cur = 0;
+    int prev_splits = 0;          // split-K partials pending from the previous layer's FFN2
+    auto launch = [&](FusedParams &f, const char *name, double bytes, double flops) {
+        ProfScope ps(e, name, bytes, flops);
+        launch_fused_skinny(f, st);
+    };
+    auto wbytes = [&](int N, int K) { return (double)N * K * 2 + (double)M * (K + N) * 4; };
+    for (int l = 0; l < nL; l++) {
+        LayerW &L = e->L[l];
+        FusedParams f;
+        // K1: [norm_out of layer l-1] + LN_ff1 -> W1 -> SiLU
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = prev_splits; f.scale = 0.5f;
+        if (l > 0) { f.lno_w = e->L[l - 1].ln_out_w; f.lno_b = e->L[l - 1].ln_out_b; }
+        f.ln_w = L.ln_ff1_w; f.ln_b = L.ln_ff1_b;
+        f.g.W = L.ff1_w1; f.g.M = M; f.g.N = FF; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_SILU_ACT; f.g.out_act = e->hbuf; f.g.ldo_act = FF;
+        launch(f, "k_fused_ln_gemm", wbytes(FF, D), 2.0 * M * FF * D);
+        cur ^= 1;
+        // K2: W2 (split-K 4) -> partials
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_PLAIN; f.g.A = e->hbuf; f.g.lda = FF; f.g.W = L.ff1_w2; f.g.M = M; f.g.N = D; f.g.K = FF; f.g.splits = 4;
+        f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+        launch(f, "k_fused_plain_gemm", wbytes(D, FF), 2.0 * M * D * FF);
+        // K3: x += 0.5 * FFN1 ; LN_att -> QKV (K/V straight into the rings)
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = 4; f.scale = 0.5f;
+        f.ln_w = L.ln_att_w; f.ln_b = L.ln_att_b;
+        f.g.W = L.wqkv; f.g.M = M; f.g.N = 3 * D; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_QKV; f.g.q_out = e->q;
+        f.g.kv_pool = e->kv_pool[l]; f.g.kv_slot_stride = (int64_t)2 * KVC * D; f.g.rows = rows; f.g.T = T;
+        launch(f, "k_fused_ln_gemm", wbytes(3 * D, D), 2.0 * M * 3 * D * D);
+        cur ^= 1;
+        // K4: attention (one head per blockIdx.y) -> out projection, split-K over the 8 heads
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_ATTN; f.at.q = e->q; f.at.kv_pool = e->kv_pool[l]; f.at.kv_slot_stride = (int64_t)2 * KVC * D; f.at.act_bf16 = 1;
+        f.at.posproj = L.posproj[T]; f.at.bias_u = L.bias_u; f.at.bias_v = L.bias_v; f.at.rows = rows; f.at.B = B; f.at.T = T;
+        f.g.W = L.wo; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = NH; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+        launch(f, "k_fused_attn_gemm", wbytes(D, D) + (double)B * (3.0 * (LCTX + T)) * D * 2, 2.0 * M * D * D);
+        // K5: x += attn ; LN_conv -> pointwise conv 1 -> GLU
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = NH; f.scale = 1.0f;
+        f.ln_w = L.ln_conv_w; f.ln_b = L.ln_conv_b;
+        f.g.W = L.pw1; f.g.M = M; f.g.N = 2 * D; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_GLU; f.g.out_f32 = e->glu; f.g.ldo = D;
+        launch(f, "k_fused_ln_gemm", wbytes(2 * D, D), 2.0 * M * 2 * D * D);
+        cur ^= 1;
+        // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2 (split-K 4)
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_DWCONV; f.cv.glu = e->glu; f.cv.cc_pool = e->cc_pool[l]; f.cv.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
+        f.cv.dw = L.dw; f.cv.ln_w = L.cln_w; f.cv.ln_b = L.cln_b; f.cv.rows = rows; f.cv.B = B; f.cv.T = T; f.cv.ks = ks;
+        f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+        launch(f, "k_fused_dwconv_gemm", wbytes(D, D), 2.0 * M * D * D);
+        // K7: x += conv ; LN_ff2 -> W1 -> SiLU
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = 4; f.scale = 1.0f;
+        f.ln_w = L.ln_ff2_w; f.ln_b = L.ln_ff2_b;
+        f.g.W = L.ff2_w1; f.g.M = M; f.g.N = FF; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_SILU_ACT; f.g.out_act = e->hbuf; f.g.ldo_act = FF;
+        launch(f, "k_fused_ln_gemm", wbytes(FF, D), 2.0 * M * FF * D);
+        cur ^= 1;
+        // K8: W2 (split-K 4) -> partials, consumed by the next layer's K1 (or the final k_post)
+        memset(&f, 0, sizeof(f));
+        f.pro = PRO_PLAIN; f.g.A = e->hbuf; f.g.lda = FF; f.g.W = L.ff2_w2; f.g.M = M; f.g.N = D; f.g.K = FF; f.g.splits = 4;
+        f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+        launch(f, "k_fused_plain_gemm", wbytes(D, FF), 2.0 * M * D * FF);
+        prev_splits = 4;
+    }
+    // x = norm_out(x + 0.5 * FFN2) of the last layer (cur is back at X[0] = e->x: 4 flips per layer)
+    PostParams q;
+    memset(&q, 0, sizeof(q));
+    q.x = X[cur]; q.M = M; q.part = e->part; q.splits = prev_splits; q.scale = 0.5f; q.ln_out = 1;
+    q.ln1_w = e->L[nL - 1].ln_out_w; q.ln1_b = e->L[nL - 1].ln_out_b;
+    if (X[cur] != e->x) q.copy_out = e->x;
+    ProfScope ps(e, "k_post", (double)M * D * 24);
+    launch_post(q, st);
+    return 0;
+}
+
+// enqueue one chunk step up to (and including) the joint's encoder projection: no host syncs, no
+// host state changes -- capturable into a hipGraph.  tap_slots != null only in debug mode.
+static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const int *tap_slots, int B, int T, int R) {
     const int M = B * T;
     const int chunk_mel = PRE_CACHE + 8 * (1 + R);
-    const int shift = 8 * (1 + R);
-    std::vector<RowDesc> rd(B);
-    for (int b = 0; b < B; b++) {
-        nasr_stream *s = rows_s[b];
-        rd[b].slot = s->slot; rd[b].valid_len = s->valid_len; rd[b].kv_head = s->kv_head;
-        rd[b].mel_start = s->mel_start; rd[b].cc_par = s->cc_par; rd[b].n_dec = n_dec[b];
-        rd[b].prompt = s->prompt; rd[b].pad = 0;
-    }
-    const RowDesc *rows;
-    if (stage_desc(e, rd, &rows)) return -1;
     hipStream_t st = e->st;
     const int act = e->bf16 ? 1 : 0;
 
@@ -763,100 +854,105 @@ static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, c
     // debug taps are indexed by slot: [slot][TMAX][1024] (+ layers)
     auto tap_copy = [&](float *tap_base, size_t per_slot, size_t layer_off) -> int {
         for (int b = 0; b < B; b++)
-            HIPCHK(hipMemcpyAsync(tap_base + (size_t)rows_s[b]->slot * per_slot + layer_off, e->x + (size_t)b * T * D,
+            HIPCHK(hipMemcpyAsync(tap_base + (size_t)tap_slots[b] * per_slot + layer_off, e->x + (size_t)b * T * D,
                                   (size_t)T * D * 4, hipMemcpyDeviceToDevice, st));
         return 0;
     };
     if (e->debug && tap_copy(e->tap_sub, (size_t)TMAX * D, 0)) return -1;
 
+    const bool fused = e->bf16 && e->opt_fused && !e->debug && M <= 16;
+    if (fused) {
+        if (run_layers_fused(e, rows, B, T)) return -1;
+    } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
-    PostParams pp;
-    memset(&pp, 0, sizeof(pp));
-    pp.x = e->x; pp.M = M; pp.ln2_w = e->L[0].ln_ff1_w; pp.ln2_b = e->L[0].ln_ff1_b; pp.a_out = e->a; pp.act_bf16 = act;
-    { ProfScope ps(e, "k_post", (double)M * D * (4 + e->esz)); launch_post(pp, st); }
+        PostParams pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.x = e->x; pp.M = M; pp.ln2_w = e->L[0].ln_ff1_w; pp.ln2_b = e->L[0].ln_ff1_b; pp.a_out = e->a; pp.act_bf16 = act;
+        { ProfScope ps(e, "k_post", (double)M * D * (4 + e->esz)); launch_post(pp, st); }
 
-    const int nL = e->hp.n_layers, ks = e->hp.kernel_size;
-    for (int l = 0; l < nL; l++) {
-        LayerW &L = e->L[l];
-        auto ffn = [&](void *w1, void *w2, const float *nln_w, const float *nln_b, bool last) {
-            GemmParams a;
-            memset(&a, 0, sizeof(a));
-            a.A = e->a; a.W = w1; a.M = M; a.N = FF; a.K = D; a.lda = D; a.splits = 1;
-            a.epi = EPI_SILU_ACT; a.out_act = e->hbuf; a.ldo_act = FF;
-            run_gemm(e, a, false, "ffn_w1");
-            memset(&a, 0, sizeof(a));
-            a.A = e->hbuf; a.W = w2; a.M = M; a.N = D; a.K = FF; a.lda = FF; a.splits = pick_splits(e, M, D, FF);
-            a.epi = EPI_PART_F32; a.out_f32 = e->part; a.ldo = D;
-            run_gemm(e, a, false, "ffn_w2");
-            PostParams q;
-            memset(&q, 0, sizeof(q));
-            q.x = e->x; q.M = M; q.part = e->part; q.splits = a.splits; q.scale = 0.5f;   // :633-634
-            q.a_out = e->a; q.act_bf16 = act;
-            if (last) { q.ln_out = 1; q.ln1_w = L.ln_out_w; q.ln1_b = L.ln_out_b; }       // :687
-            q.ln2_w = nln_w; q.ln2_b = nln_b;
-            ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * a.splits + e->esz));
-            launch_post(q, st);
-        };
-        // 1. FFN1 (:631-634) -> a = LN_att(x)
-        ffn(L.ff1_w1, L.ff1_w2, L.ln_att_w, L.ln_att_b, false);
-        // 2. attention (:637-643)
-        memset(&g, 0, sizeof(g));
-        g.A = e->a; g.W = L.wqkv; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.splits = 1;
-        g.epi = EPI_QKV; g.q_out = e->q; g.kv_pool = e->kv_pool[l]; g.kv_slot_stride = (int64_t)2 * KVC * D;
-        g.rows = rows; g.T = T;
-        run_gemm(e, g, false, "qkv");
-        {
-            AttnParams ap;
-            memset(&ap, 0, sizeof(ap));
-            ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = act;
-            ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T;
-            ap.ctx_out = e->ctx;
-            const int KV = LCTX + T;
-            ProfScope ps(e, "k_attention", (double)B * (2.0 * KV + KV + T - 1) * D * e->esz, 2.0 * B * T * KV * D * 3);
-            launch_attention(ap, st);
+        const int nL = e->hp.n_layers, ks = e->hp.kernel_size;
+        for (int l = 0; l < nL; l++) {
+            LayerW &L = e->L[l];
+            auto ffn = [&](void *w1, void *w2, const float *nln_w, const float *nln_b, bool last) {
+                GemmParams a;
+                memset(&a, 0, sizeof(a));
+                a.A = e->a; a.W = w1; a.M = M; a.N = FF; a.K = D; a.lda = D; a.splits = 1;
+                a.epi = EPI_SILU_ACT; a.out_act = e->hbuf; a.ldo_act = FF;
+                run_gemm(e, a, false, "ffn_w1");
+                memset(&a, 0, sizeof(a));
+                a.A = e->hbuf; a.W = w2; a.M = M; a.N = D; a.K = FF; a.lda = FF; a.splits = pick_splits(e, M, D, FF);
+                a.epi = EPI_PART_F32; a.out_f32 = e->part; a.ldo = D;
+                run_gemm(e, a, false, "ffn_w2");
+                PostParams q;
+                memset(&q, 0, sizeof(q));
+                q.x = e->x; q.M = M; q.part = e->part; q.splits = a.splits; q.scale = 0.5f;   // :633-634
+                q.a_out = e->a; q.act_bf16 = act;
+                if (last) { q.ln_out = 1; q.ln1_w = L.ln_out_w; q.ln1_b = L.ln_out_b; }       // :687
+                q.ln2_w = nln_w; q.ln2_b = nln_b;
+                ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * a.splits + e->esz));
+                launch_post(q, st);
+            };
+            // 1. FFN1 (:631-634) -> a = LN_att(x)
+            ffn(L.ff1_w1, L.ff1_w2, L.ln_att_w, L.ln_att_b, false);
+            // 2. attention (:637-643)
+            memset(&g, 0, sizeof(g));
+            g.A = e->a; g.W = L.wqkv; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.splits = 1;
+            g.epi = EPI_QKV; g.q_out = e->q; g.kv_pool = e->kv_pool[l]; g.kv_slot_stride = (int64_t)2 * KVC * D;
+            g.rows = rows; g.T = T;
+            run_gemm(e, g, false, "qkv");
+            {
+                AttnParams ap;
+                memset(&ap, 0, sizeof(ap));
+                ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = act;
+                ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T;
+                ap.ctx_out = e->ctx;
+                const int KV = LCTX + T;
+                ProfScope ps(e, "k_attention", (double)B * (2.0 * KV + KV + T - 1) * D * e->esz, 2.0 * B * T * KV * D * 3);
+                launch_attention(ap, st);
+            }
+            memset(&g, 0, sizeof(g));
+            g.A = e->ctx; g.W = L.wo; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
+            g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
+            run_gemm(e, g, false, "attn_out");
+            {
+                PostParams q;
+                memset(&q, 0, sizeof(q));
+                q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
+                q.ln2_w = L.ln_conv_w; q.ln2_b = L.ln_conv_b; q.a_out = e->a; q.act_bf16 = act;
+                ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
+                launch_post(q, st);
+            }
+            // 3. conv module (:646-679)
+            memset(&g, 0, sizeof(g));
+            g.A = e->a; g.W = L.pw1; g.M = M; g.N = 2 * D; g.K = D; g.lda = D; g.splits = 1;
+            g.epi = EPI_GLU; g.out_f32 = e->glu; g.ldo = D;
+            run_gemm(e, g, false, "pw1");
+            {
+                ConvParams cp;
+                memset(&cp, 0, sizeof(cp));
+                cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
+                cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = T; cp.ks = ks;
+                cp.c_out = e->cbuf; cp.act_bf16 = act;
+                ProfScope ps(e, "k_dwconv", (double)M * D * (4 + e->esz) + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks);
+                launch_dwconv(cp, st);
+            }
+            memset(&g, 0, sizeof(g));
+            g.A = e->cbuf; g.W = L.pw2; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
+            g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
+            run_gemm(e, g, false, "pw2");
+            {
+                PostParams q;
+                memset(&q, 0, sizeof(q));
+                q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
+                q.ln2_w = L.ln_ff2_w; q.ln2_b = L.ln_ff2_b; q.a_out = e->a; q.act_bf16 = act;
+                ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
+                launch_post(q, st);
+            }
+            // 4. FFN2 (:682-685) + norm_out (:687); then the next layer's first LayerNorm
+            const bool has_next = l + 1 < nL;
+            ffn(L.ff2_w1, L.ff2_w2, has_next ? e->L[l + 1].ln_ff1_w : nullptr, has_next ? e->L[l + 1].ln_ff1_b : nullptr, true);
+            if (e->debug && tap_copy(e->tap_layers, (size_t)nL * TMAX * D, (size_t)l * TMAX * D)) return -1;
         }
-        memset(&g, 0, sizeof(g));
-        g.A = e->ctx; g.W = L.wo; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
-        g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
-        run_gemm(e, g, false, "attn_out");
-        {
-            PostParams q;
-            memset(&q, 0, sizeof(q));
-            q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
-            q.ln2_w = L.ln_conv_w; q.ln2_b = L.ln_conv_b; q.a_out = e->a; q.act_bf16 = act;
-            ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
-            launch_post(q, st);
-        }
-        // 3. conv module (:646-679)
-        memset(&g, 0, sizeof(g));
-        g.A = e->a; g.W = L.pw1; g.M = M; g.N = 2 * D; g.K = D; g.lda = D; g.splits = 1;
-        g.epi = EPI_GLU; g.out_f32 = e->glu; g.ldo = D;
-        run_gemm(e, g, false, "pw1");
-        {
-            ConvParams cp;
-            memset(&cp, 0, sizeof(cp));
-            cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
-            cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = T; cp.ks = ks;
-            cp.c_out = e->cbuf; cp.act_bf16 = act;
-            ProfScope ps(e, "k_dwconv", (double)M * D * (4 + e->esz) + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks);
-            launch_dwconv(cp, st);
-        }
-        memset(&g, 0, sizeof(g));
-        g.A = e->cbuf; g.W = L.pw2; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
-        g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
-        run_gemm(e, g, false, "pw2");
-        {
-            PostParams q;
-            memset(&q, 0, sizeof(q));
-            q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
-            q.ln2_w = L.ln_ff2_w; q.ln2_b = L.ln_ff2_b; q.a_out = e->a; q.act_bf16 = act;
-            ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
-            launch_post(q, st);
-        }
-        // 4. FFN2 (:682-685) + norm_out (:687); then the next layer's first LayerNorm
-        const bool has_next = l + 1 < nL;
-        ffn(L.ff2_w1, L.ff2_w2, has_next ? e->L[l + 1].ln_ff1_w : nullptr, has_next ? e->L[l + 1].ln_ff1_b : nullptr, true);
-        if (e->debug && tap_copy(e->tap_layers, (size_t)nL * TMAX * D, (size_t)l * TMAX * D)) return -1;
     }
     // ---- a-11 prompt fusion (multilingual only, src/nemo-ggml.cpp:1087-1105) ---------------------
     if (e->hp.num_prompts > 0) {
@@ -873,47 +969,74 @@ static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, c
     if (e->debug && tap_copy(e->tap_enc, (size_t)TMAX * D, 0)) return -1;
 
     // ---- a-13 encoder projection of the joint, hoisted out of the symbol loop --------------------
-    memset(&g, 0, sizeof(g));
-    g.A = e->x; g.W = e->jenc_w; g.M = M; g.N = JNT; g.K = D; g.lda = D; g.splits = 1;
-    g.epi = EPI_BIAS_F32; g.out_f32 = e->encproj; g.ldo = JNT; g.bias = e->jenc_b;
-    { ProfScope ps(e, "k_gemm_f32", (double)JNT * D * 4 + (double)M * (D + JNT) * 4, 2.0 * M * JNT * D); launch_gemm_f32(g, st); }
+    {
+        ProfScope ps(e, "k_encproj", (double)JNT * D * 4 + (double)M * (D + JNT) * 4, 2.0 * M * JNT * D);
+        launch_encproj(e->x, e->jenc_w, e->jenc_b, e->encproj, M, D, JNT, st);
+    }
+    return 0;
+}
 
-    // ---- a-12..a-14 greedy decode, device resident -----------------------------------------------
-    DecParams dp;
+static void make_dec_params(nasr_engine *e, const RowDesc *rows, int B, int T, DecParams &dp) {
     memset(&dp, 0, sizeof(dp));
     dp.rows = rows; dp.B = B; dp.T = T; dp.ctrl = e->ctrl; dp.h = e->dec_h; dp.c = e->dec_c; dp.encproj = e->encproj;
     dp.embed = e->embed;
     for (int i = 0; i < 2; i++) { dp.w_ih[i] = e->w_ih[i]; dp.w_hh[i] = e->w_hh[i]; dp.b_ih[i] = e->b_ih[i]; dp.b_hh[i] = e->b_hh[i]; }
     dp.pred_w = e->pred_w; dp.pred_b = e->pred_b; dp.out_w = e->out_w; dp.out_b = e->out_b;
     dp.jact = e->jact; dp.key = e->key; dp.n_active = e->n_active; dp.tok_ring = e->tok_ring;
+}
+
+static void enqueue_decode_iters(nasr_engine *e, const DecParams &dp, int B, int n, int &it) {
+    ProfScope ps(e, "k_dec_iter", (double)n * (4.0 * 4 * HID * HID * 4 + (double)JNT * HID * 4 + (double)VOCAB * JNT * 4),
+                 (double)n * 2.0 * B * (4.0 * 4 * HID * HID + JNT * HID + VOCAB * JNT));
+    for (int k = 0; k < n; k++) launch_decode_iter(dp, it++, e->st);
+}
+
+// host mirror of the stream manager bookkeeping after a chunk (:1085, :1189-1195)
+static void chunk_bookkeeping(nasr_stream *s, int row) {
+    const int T = s->T, shift = 8 * T;
+    s->valid_len = std::min(s->valid_len + T, LCTX);
+    s->kv_head = (s->kv_head + T) % KVC;
+    s->cc_par ^= 1;
+    s->mel_start = (s->mel_start + shift) & (MEL_RING - 1);
+    s->mel_count -= shift;
+    s->chunks++;
+    s->last_T = T;
+    s->last_row = row;
+}
+
+static void fill_row_desc(RowDesc &rd, const nasr_stream *s, int n_dec) {
+    rd.slot = s->slot; rd.valid_len = s->valid_len; rd.kv_head = s->kv_head;
+    rd.mel_start = s->mel_start; rd.cc_par = s->cc_par; rd.n_dec = n_dec;
+    rd.prompt = s->prompt; rd.pad = 0;
+}
+
+static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, const std::vector<int> &n_dec) {
+    const int B = (int)rows_s.size();
+    const int T = rows_s[0]->T, R = rows_s[0]->R;
+    std::vector<RowDesc> rd(B);
+    std::vector<int> slots(B);
+    for (int b = 0; b < B; b++) { fill_row_desc(rd[b], rows_s[b], n_dec[b]); slots[b] = rows_s[b]->slot; }
+    const RowDesc *rows;
+    if (stage_desc(e, rd, &rows)) return -1;
+    hipStream_t st = e->st;
+    if (enqueue_encoder(e, rows, e->debug ? slots.data() : nullptr, B, T, R)) return -1;
+    // ---- a-12..a-14 greedy decode, device resident -----------------------------------------------
+    DecParams dp;
+    make_dec_params(e, rows, B, T, dp);
     launch_decode_begin(dp, st);
     int max_dec = 0;
     for (int b = 0; b < B; b++) max_dec = std::max(max_dec, n_dec[b]);
     int it = 0, budget = max_dec + 2;
-    int *h_active = (int *)e->pin;   // first 64 bytes of the pinned arena are reserved (pin_off starts at 256)
+    int *h_active = (int *)e->pin;   // first 256 bytes of the pinned arena are reserved for this
     while (max_dec > 0) {
-        {
-            ProfScope ps(e, "k_dec_iter", (double)budget * (4.0 * 4 * HID * HID * 4 + (double)JNT * HID * 4 + (double)VOCAB * JNT * 4),
-                         (double)budget * 2.0 * B * (4.0 * 4 * HID * HID + JNT * HID + VOCAB * JNT));
-            for (int k = 0; k < budget; k++) launch_decode_iter(dp, it++, st);
-        }
+        enqueue_decode_iters(e, dp, B, budget, it);
         HIPCHK(hipMemcpyAsync(h_active, e->n_active, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (*h_active == 0) break;
         if (it > max_dec * MAX_SYMBOLS + 4) return fail("decode did not terminate");
         budget = 2;
     }
-    // ---- a-15 host mirror of the stream manager bookkeeping (:1085, :1189-1195) ---------------------
-    for (int b = 0; b < B; b++) {
-        nasr_stream *s = rows_s[b];
-        s->valid_len = std::min(s->valid_len + T, LCTX);
-        s->kv_head = (s->kv_head + T) % KVC;
-        s->cc_par ^= 1;
-        s->mel_start = (s->mel_start + shift) & (MEL_RING - 1);
-        s->mel_count -= shift;
-        s->chunks++;
-        s->last_T = T;
-    }
+    for (int b = 0; b < B; b++) chunk_bookkeeping(rows_s[b], b);
     return 0;
 }
 
@@ -952,6 +1075,9 @@ __global__ void k_collect(const int *slots, const int *tok_read, int B, const De
         out[(size_t)b * (1 + stride) + 1 + i] = tok_ring[(size_t)slot * TOK_CAP + ((rd + i) & (TOK_CAP - 1))];
 }
 
+static int consume_collect(nasr_engine *e, const int *host, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
+                           const int32_t *tokens_cap, int32_t *n_tokens);
+
 static int collect_tokens(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
                           const int32_t *tokens_cap, int32_t *n_tokens) {
     std::vector<int> meta(2 * (size_t)B);
@@ -962,6 +1088,11 @@ static int collect_tokens(nasr_engine *e, nasr_stream *const *streams, int B, in
     std::vector<int> host((size_t)B * (1 + COLLECT_STRIDE));
     HIPCHK(hipMemcpyAsync(host.data(), e->collect_dev, host.size() * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
+    return consume_collect(e, host.data(), streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+static int consume_collect(nasr_engine *e, const int *host, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
+                           const int32_t *tokens_cap, int32_t *n_tokens) {
     for (int b = 0; b < B; b++) {
         const int *rec = &host[(size_t)b * (1 + COLLECT_STRIDE)];
         const int n_new = rec[0];
@@ -992,12 +1123,125 @@ static int ensure_debug_buffers(nasr_engine *e) {
     return 0;
 }
 
+extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value) {
+    if (!e || !key) return fail("null argument");
+    if (!strcmp(key, "fused")) e->opt_fused = value != 0;
+    else if (!strcmp(key, "graph")) e->opt_graph = value != 0;
+    else return fail("unknown option '%s'", key);
+    return 0;
+}
+
 extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
     if (enable && ensure_debug_buffers(e)) return -1;
     e->debug = enable != 0;
     return 0;
+}
+
+// ---- hipGraph replay of the steady-state step ----------------------------------------------------
+// Eligible when every stream of the call receives one sub-push that completes exactly one chunk
+// (the normal streaming cadence: 1280*(1+R) samples per push).  The launch sequence is then fixed
+// for a given (B, T): descriptors live at fixed addresses and are refreshed by memcpy nodes.
+static int max_frames_per_push(int T) { return 8 * T + 2; }
+
+static int build_step_graph(nasr_engine *e, int B, int T, int R, hipGraphExec_t *out) {
+    hipStream_t st = e->st;
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    auto body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(e->g_pcm, e->gh_pcm, (size_t)B * sizeof(PcmDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->g_rows, e->gh_rows, (size_t)B * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->g_meta, e->gh_meta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, st));
+        MelParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.desc = e->g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+        launch_mel(mp, 0, st);
+        if (enqueue_encoder(e, e->g_rows, nullptr, B, T, R)) return -1;
+        DecParams dp;
+        make_dec_params(e, e->g_rows, B, T, dp);
+        launch_decode_begin(dp, st);
+        int it = 0;
+        enqueue_decode_iters(e, dp, B, T + 2, it);
+        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, st, e->g_meta, e->g_meta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE);
+        HIPCHK(hipMemcpyAsync(e->gh_collect, e->collect_dev, (size_t)B * (1 + COLLECT_STRIDE) * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+        return 0;
+    };
+    rc = body();
+    hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+    if (ce != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ie != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    return 0;
+}
+
+// returns 1 if the step was executed through the graph, 0 if not eligible, <0 on error
+static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev,
+                          const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
+    const int T = streams[0]->T, R = streams[0]->R;
+    const int chunk_mel = PRE_CACHE + 8 * T, shift = 8 * T;
+    for (int b = 0; b < B; b++) {
+        const nasr_stream *s = streams[b];
+        const int n = n_samples[b];
+        if (n <= 0 || n > MAX_PUSH) return 0;
+        const int avail = s->abuf_cnt + n;
+        const int nf = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
+        if (nf > max_frames_per_push(T)) return 0;
+        const int mc = s->mel_count + nf;
+        if (mc < chunk_mel || mc >= chunk_mel + shift) return 0;   // exactly one chunk must become ready
+    }
+    const int key = B * 64 + T;
+    auto it = e->graphs.find(key);
+    if (it == e->graphs.end()) {
+        HIPCHK(hipStreamSynchronize(e->st));
+        hipGraphExec_t ex = nullptr;
+        if (build_step_graph(e, B, T, R, &ex)) return -1;
+        it = e->graphs.emplace(key, ex).first;
+    }
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = streams[b];
+        PcmDesc &d = e->gh_pcm[b];
+        memset(&d, 0, sizeof(d));
+        d.pcm = pcm_dev[b]; d.slot = s->slot; d.n = n_samples[b]; d.cnt = s->abuf_cnt; d.par = s->abuf_par;
+        const int avail = d.cnt + d.n;
+        d.n_frames = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
+        d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
+        d.consumed = d.n_frames * HOP;
+        fill_row_desc(e->gh_rows[b], s, T);
+        e->gh_meta[b] = s->slot;
+        e->gh_meta[B + b] = s->tok_read;
+    }
+    HIPCHK(hipGraphLaunch(it->second, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    e->graph_replays++;
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = streams[b];
+        const PcmDesc &d = e->gh_pcm[b];
+        s->abuf_cnt = d.cnt + d.n - d.consumed;
+        if (d.n_frames > 0) s->abuf_par ^= 1;
+        s->mel_count += d.n_frames;
+    }
+    if (*e->gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
+        DecParams dp;
+        make_dec_params(e, e->g_rows, B, T, dp);
+        int itn = T + 2;
+        for (;;) {
+            enqueue_decode_iters(e, dp, B, 2, itn);
+            HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st));
+            HIPCHK(hipStreamSynchronize(e->st));
+            if (*e->gh_active == 0) break;
+            if (itn > T * MAX_SYMBOLS + 8) return fail("decode did not terminate");
+        }
+        for (int b = 0; b < B; b++) chunk_bookkeeping(streams[b], b);
+        return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens) ? -1 : 1;
+    }
+    for (int b = 0; b < B; b++) chunk_bookkeeping(streams[b], b);
+    return consume_collect(e, e->gh_collect, streams, B, tokens_out, tokens_cap, n_tokens) ? -1 : 1;
 }
 
 extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm,
@@ -1034,6 +1278,12 @@ extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int
     }
     if (e->debug) for (int b = 0; b < B; b++) { e->tap_mel_frames[streams[b]->slot] = 0; e->tap_mel_row[streams[b]->slot] = b; }
     for (int b = 0; b < B; b++) streams[b]->samples_in += n_samples[b];
+    if (e->opt_graph && !e->debug && !e->prof.on && !(flags & NASR_FLAG_NO_SYNC)) {
+        const int gr = try_graph_step(e, streams, B, base.data(), n_samples, tokens_out, tokens_cap, n_tokens);
+        if (gr < 0) return -1;
+        if (gr == 1) return 0;
+    }
+    e->eager_steps++;
     // sub-pushes of at most MAX_PUSH samples keep the audio buffer and the mel ring bounded
     for (;;) {
         std::vector<PcmDesc> pd;
@@ -1219,8 +1469,14 @@ extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, flo
     case NASR_TAP_SUBSAMPLED:
     case NASR_TAP_ENCODER_OUT:
     case NASR_TAP_LAYER_OUT: {
-        if (!need_debug()) return fail("debug taps not enabled");
         if ((int64_t)T * D > cap) return fail("tap buffer too small");
+        if (which == NASR_TAP_ENCODER_OUT && !(e->debug && need_debug())) {
+            // without debug buffers: valid until the next chunk step of this engine
+            if (e->hp.num_prompts > 0 || T == 0) return fail("encoder-out tap needs debug mode here");
+            HIPCHK(hipMemcpy(out, e->x + (size_t)s->last_row * T * D, (size_t)T * D * 4, hipMemcpyDeviceToHost));
+            return (int64_t)T * D;
+        }
+        if (!need_debug()) return fail("debug taps not enabled");
         const float *src = which == NASR_TAP_SUBSAMPLED ? e->tap_sub + slot * TMAX * D
                          : which == NASR_TAP_ENCODER_OUT ? e->tap_enc + slot * TMAX * D
                          : e->tap_layers + (slot * e->hp.n_layers + (size_t)index) * TMAX * D;

@@ -178,6 +178,21 @@ struct DecParams {
 };
 void launch_decode_begin(const DecParams &p, hipStream_t st);
 void launch_decode_iter(const DecParams &p, int iter, hipStream_t st);
+void launch_encproj(const float *x, const float *wpk, const float *bias, float *out, int M, int K, int N, hipStream_t st);
+
+// ---- fused small-M kernels (M <= 16): prologue + weight-streaming GEMM + epilogue in one launch ----
+enum Pro { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATTN = 2, PRO_DWCONV = 3 };
+struct FusedParams {
+    GemmParams g;                 // W (packed bf16), M, N, K, splits, epi + outputs (A unused unless PRO_PLAIN)
+    int pro;
+    // PRO_LN: a = LN( [LN_out]( x_in + scale * sum_s part[s] ) ); block (0,0) writes the updated x to x_out
+    const float *x_in; float *x_out; const float *part; int part_splits; float scale;
+    const float *lno_w, *lno_b;   // optional LayerNorm applied to the updated x first (norm_out of the previous layer)
+    const float *ln_w, *ln_b;
+    AttnParams at;                // PRO_ATTN (blockIdx.y = head; K range = that head's 128 columns)
+    ConvParams cv;                // PRO_DWCONV
+};
+void launch_fused_skinny(const FusedParams &p, hipStream_t st);
 
 void launch_prompt_add_relu(float *h, const float *w1p, const RowDesc *rows, int M, int T, int P, hipStream_t st);
 void launch_relu(float *x, int64_t n, hipStream_t st);
