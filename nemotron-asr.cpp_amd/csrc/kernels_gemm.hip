@@ -18,6 +18,7 @@
 // f32 path (parity mode): plain LDS-tiled FMA kernel, k ascending, deterministic.
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
+#include <cstdlib>
 
 namespace nasr {
 
@@ -146,27 +147,37 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(GemmParams p, int n_groups, 
         for (int i = 0; i < 4; i++) *(uint4 *)(panel[buf] + panel_off(lrow, lhalf * 4 + i)) = pre[i];
     };
     int cur = 0;
-    if (c0 < c1) { gload(c0); lstore(0); }
-    __syncthreads();
-    for (int kc = c0; kc < c1; kc++) {
-        const bool more = kc + 1 < c1;
-        if (more) gload(kc + 1);
-        uint4 w[2][2];
+    // software pipeline: chunk kc+1's activation panel (global -> regs) and weight tiles (global -> regs)
+    // are in flight while chunk kc is multiplied out of LDS.
+    uint4 wc[2][2], wn[2][2];
+    auto wload = [&](uint4 (&w)[2][2], int kc) {
         w[0][0] = wp0[(size_t)(2 * kc) * 64];
         w[0][1] = wp0[(size_t)(2 * kc + 1) * 64];
         w[1][0] = wp1[(size_t)(2 * kc) * 64];
         w[1][1] = wp1[(size_t)(2 * kc + 1) * 64];
+    };
+    if (c0 < c1) { gload(c0); wload(wc, c0); lstore(0); }
+    __syncthreads();
+    for (int kc = c0; kc < c1; kc++) {
+        const bool more = kc + 1 < c1;
+        if (more) { gload(kc + 1); wload(wn, kc + 1); }
 #pragma unroll
         for (int k2 = 0; k2 < 2; k2++) {
 #pragma unroll
             for (int mt = 0; mt < 8; mt++) {
                 uint4 bv = *(const uint4 *)(panel[cur] + panel_off(mt * 16 + r, k2 * 4 + q));
                 bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
-                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
-                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[1][k2]), bf, acc[1][mt], 0, 0, 0);
             }
         }
-        if (more) lstore(cur ^ 1);
+        if (more) {
+            lstore(cur ^ 1);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) wc[j][k2] = wn[j][k2];
+        }
         __syncthreads();
         cur ^= 1;
     }
@@ -175,6 +186,114 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(GemmParams p, int n_groups, 
 #pragma unroll
         for (int mt = 0; mt < 8; mt++)
             epi_quad<true>(p, split, m0 + mt * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1],
+                           acc[j][mt][2], acc[j][mt][3]);
+}
+
+// ------------------------------------------------------------------------------------
+// tiled, LDS-DMA pipelined (the large-M kernel): same 128 x 128 tile / 4 waves x (2 n-tiles x 8
+// m-tiles) decomposition, but BOTH operands arrive by global_load_lds into a 4-slot LDS ring
+// (slot = 16 KiB activation panel + 16 KiB weight tiles per 64-deep K chunk) with three chunks in
+// flight per workgroup and one raw s_barrier per chunk.  With ~1 workgroup per CU (M = 896 gives
+// 224 tiles) there is no other wave to hide the ~1 us L2/HBM latency behind, so the depth has to
+// come from the pipeline itself; the DMA needs no staging registers.
+//  * weight tiles are lane-linear in HBM already -> LDS image is linear, ds_read_b128 conflict-free
+//  * the activation panel is stored linear too; the bank swizzle is applied to the per-lane SOURCE
+//    address and again on the read (same involution), cdna_hip_programming.md rule 21
+//  * the DMA is issued from inline asm (M0 = wave-uniform LDS base), so hipcc does not see a pending
+//    LDS write and does not drain vmcnt(0) in front of every ds_read; completion is counted by hand
+//    (8 DMA instructions per wave per chunk).
+// ------------------------------------------------------------------------------------
+constexpr int G2_P = 3, G2_NS = 4, G2_SLOT = 32768;
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups, int m_chunks) {
+    // 8 waves = 2 per SIMD: wave w owns n-tile pair (w & 3) x m-tiles [(w >> 2) * 4, +4).  One wave's
+    // LDS-DMA issue (expensive: ~100+ cycles per 1 KiB instruction) overlaps its SIMD partner's MFMAs.
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks;
+    const int rest = id / m_chunks;
+    const int ng = rest % n_groups, split = rest / n_groups;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ng4 = wave & 3, mh = wave >> 2;
+    const int q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5;
+    const int kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = c1 - c0;
+    const int m0 = mc * TM;
+    const int ntile0 = (ng * 4 + ng4) * 2;
+    // this wave DMAs weight tile ntile0 + mh (both k-tiles of the chunk) and panel rows [wave*16, +16)
+    const uint4 *wpd = (const uint4 *)p.W + (size_t)(ntile0 + mh) * KT * 64 + lane;
+    const int prow = lane >> 3, pc = lane & 7;
+    const char *asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = wave * 16 + i * 8 + prow;
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;   // LDS byte address
+    auto issue = [&](int kc, int slot) {
+        const unsigned sb = ring_base + slot * G2_SLOT;
+#pragma unroll
+        for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+        const unsigned wb = sb + 16384 + ng4 * 4096 + mh * 2048;
+        glds16(wpd + (size_t)(2 * kc) * 64, wb);
+        glds16(wpd + (size_t)(2 * kc + 1) * 64, wb + 1024);
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < G2_P; i++)
+        if (i < nchunks) issue(c0 + i, i);
+    for (int i = 0; i < nchunks; i++) {
+        const int rem = nchunks - 1 - i < G2_P - 1 ? nchunks - 1 - i : G2_P - 1;   // chunks allowed to stay in flight
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // 4 DMA instructions per wave per chunk
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i-1 is fully consumed
+        const char *sp = ring + (i & (G2_NS - 1)) * G2_SLOT;
+        const char *wl = sp + 16384 + ng4 * 4096 + lane * 16;
+        uint4 w[2][2];
+        w[0][0] = *(const uint4 *)(wl);
+        w[0][1] = *(const uint4 *)(wl + 1024);
+        w[1][0] = *(const uint4 *)(wl + 2048);
+        w[1][1] = *(const uint4 *)(wl + 3072);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const uint4 bv = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+            }
+        }
+        if (i + G2_P < nchunks) issue(c0 + i + G2_P, (i + G2_P) & (G2_NS - 1));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1],
                            acc[j][mt][2], acc[j][mt][3]);
 }
 
@@ -189,7 +308,17 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     } else {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
         dim3 grid(n_groups * m_chunks * p.splits);
-        hipLaunchKernelGGL(k_gemm_tiled, grid, dim3(256), 0, st, p, n_groups, m_chunks);
+        static bool use_dma = getenv("NASR_GEMM_NODMA") == nullptr;
+        if (use_dma) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute((const void *)k_gemm_tiled2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+        } else {
+            hipLaunchKernelGGL(k_gemm_tiled, grid, dim3(256), 0, st, p, n_groups, m_chunks);
+        }
     }
 }
 

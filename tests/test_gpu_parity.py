@@ -185,6 +185,26 @@ def test_graph_replay_equals_eager(W, om32, dtype, R, B):
     eng.close()
 
 
+def test_large_m_tiled_gemm_path(W, om16):
+    """B = 10 streams x T = 14 rows = 140 rows: the LDS-DMA tiled GEMM (2 m-chunks, ragged tail rows)."""
+    R, T, B = 13, 14, 10
+    eng = capi.Engine(W, n_layers=N_LAYERS, dtype=capi.DTYPE_BF16, max_streams=B)
+    eng.set_debug(True)
+    sts = [eng.stream(R) for _ in range(B)]
+    mels = [_mel_stream(8 * T * 7, seed=300 + b) for b in range(B)]
+    osts = {b: ob.OracleStream(om16, R) for b in (0, B - 1)}
+    taps = {b: osts[b].enable_taps() for b in osts}
+    worst = 0.0
+    for c in range(7):
+        eng.step_mel(sts, [m[c * 8 * T:(c + 1) * 8 * T] for m in mels])
+        for b in osts:
+            osts[b].push_mel(mels[b][c * 8 * T:(c + 1) * 8 * T])
+            got = sts[b].tap(capi.TAP_LAYER_OUT, N_LAYERS - 1).reshape(T, 1024)
+            worst = max(worst, np.abs(got - taps[b][1][N_LAYERS - 1]).max())
+    assert worst < 3e-2, worst
+    eng.close()
+
+
 def test_pcm_end_to_end_tokens_f32(eng32, om32):
     """PCM in, tokens out, R=0, incl. the tail flush; token-for-token vs the oracle."""
     pcm = synth.make_pcm(2, 6.0)
