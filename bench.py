@@ -37,6 +37,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16
 
 
+# HIP-event category (engine) -> rocprofv3 kernel symbol, for the committed PMC traffic summary
+_SYMBOL = {"k_fused_ln_gemm": "void nasr::k_fused_skinny<0>(nasr::FusedParams)",
+           "k_fused_plain_gemm": "void nasr::k_fused_skinny<1>(nasr::FusedParams)",
+           "k_fused_attn_gemm": "void nasr::k_fused_skinny<2>(nasr::FusedParams)",
+           "k_fused_dwconv_gemm": "void nasr::k_fused_skinny<3>(nasr::FusedParams)"}
+
+
+def pmc_traffic(category, B, R, dtype, layers):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes committed under
+    profiles/ (FETCH_SIZE x2 correction + WRITE_SIZE, MI355X_MICROARCH.md).  PMC counters cannot be
+    collected from inside this process; the number is reported only for the configuration it was
+    measured on (batch 1, R 0, bf16, 24 layers) and is null otherwise."""
+    f = ROOT / "profiles" / "r1_pmc_traffic_batch1_R0.json"
+    if (B, R, dtype, layers) != (1, 0, "bf16", 24) or not f.exists() or category not in _SYMBOL:
+        return None
+    k = json.loads(f.read_text())["kernels"].get(_SYMBOL[category])
+    return k.get("hbm_bytes_per_launch_corrected") if k else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,7 +151,7 @@ def main():
             run_step(k)
         kernels = eng.profile_read()
         eng.profile(False)
-        dom = max((k for k in kernels if k["name"].startswith("k_gemm")), key=lambda k: k["total_ms"], default=None)
+        dom = max((k for k in kernels if "gemm" in k["name"]), key=lambda k: k["total_ms"], default=None)
         if dom and dom["total_ms"] > 0:
             avg_ms = dom["total_ms"] / dom["launches"]
             if dom["name"] == "k_gemm_tiled":
@@ -141,9 +160,10 @@ def main():
                                 unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
                                 avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps)
             else:
+                traffic = pmc_traffic(dom["name"], B, R, args.dtype, args.layers)
                 ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
                 roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                 avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps,
                                 alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]))
 

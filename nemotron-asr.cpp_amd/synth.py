@@ -228,3 +228,67 @@ def chunk_mel_frames(right_context: int) -> int:
 
 def shift_samples(right_context: int) -> int:
     return HOP * 8 * (1 + right_context)            # reference src/nemo-stream.h:76-81
+
+
+# ---- GGUF tensor flavours (layouts: reference scripts/convert_to_gguf.py:118-204) -----------------
+QUANT_PATTERN = r"encoder\.layers\.\d+\.(feed_forward\d+|self_attn|conv)\.[^.]+\.weight$"   # :246-251
+TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q8_0 = 0, 1, 2, 8
+
+
+def pack_q8_0(x: np.ndarray) -> np.ndarray:
+    """34-byte blocks: f16 scale (amax/127) + 32 int8."""
+    b = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    sc = (np.abs(b).max(axis=1) / 127.0).astype(np.float16)
+    s32 = sc.astype(np.float32)[:, None]
+    q = np.where(s32 != 0, np.round(b / np.where(s32 != 0, s32, 1.0)), 0).astype(np.int8)
+    out = np.empty(b.shape[0], dtype=np.dtype([("d", np.float16), ("q", np.int8, 32)]))
+    out["d"], out["q"] = sc, q
+    return out.view(np.uint8)
+
+
+def unpack_q8_0(raw: np.ndarray, shape) -> np.ndarray:
+    blk = np.ascontiguousarray(raw).view(np.dtype([("d", np.float16), ("q", np.int8, 32)]))
+    return (blk["d"].astype(np.float32)[:, None] * blk["q"].astype(np.float32)).reshape(shape)
+
+
+def pack_q4_0(x: np.ndarray) -> np.ndarray:
+    """18-byte blocks: f16 scale (amax/7) + 16 bytes, low nibble = elements 0..15, high = 16..31."""
+    b = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    sc = (np.abs(b).max(axis=1) / 7.0).astype(np.float16)
+    s32 = sc.astype(np.float32)[:, None]
+    q = np.clip(np.where(s32 != 0, np.round(b / np.where(s32 != 0, s32, 1.0)), 0), -8, 7).astype(np.int8)
+    u = (q + 8).astype(np.uint8)
+    out = np.empty(b.shape[0], dtype=np.dtype([("d", np.float16), ("q", np.uint8, 16)]))
+    out["d"], out["q"] = sc, (u[:, :16] & 0xF) | ((u[:, 16:] & 0xF) << 4)
+    return out.view(np.uint8)
+
+
+def unpack_q4_0(raw: np.ndarray, shape) -> np.ndarray:
+    blk = np.ascontiguousarray(raw).view(np.dtype([("d", np.float16), ("q", np.uint8, 16)]))
+    lo = (blk["q"] & 0xF).astype(np.int32) - 8
+    hi = (blk["q"] >> 4).astype(np.int32) - 8
+    q = np.concatenate([lo, hi], axis=1).astype(np.float32)
+    return (blk["d"].astype(np.float32)[:, None] * q).reshape(shape)
+
+
+def quantize_weights(W: dict, kind: str):
+    """Returns (engine_weights, dequantised_f32_weights): tensors matching QUANT_PATTERN (except the
+    depthwise conv, convert_to_gguf.py:237-243) are stored as `kind` in {"f16","q8_0","q4_0"}."""
+    import re
+    eng, deq = {}, {}
+    for name, a in W.items():
+        if re.search(QUANT_PATTERN, name) and "depthwise_conv" not in name and a.size % 32 == 0:
+            if kind == "f16":
+                h = a.astype(np.float16)
+                eng[name], deq[name] = (TYPE_F16, h, a.shape), h.astype(np.float32)
+            elif kind == "q8_0":
+                raw = pack_q8_0(a)
+                eng[name], deq[name] = (TYPE_Q8_0, raw, a.shape), unpack_q8_0(raw, a.shape)
+            elif kind == "q4_0":
+                raw = pack_q4_0(a)
+                eng[name], deq[name] = (TYPE_Q4_0, raw, a.shape), unpack_q4_0(raw, a.shape)
+            else:
+                raise ValueError(kind)
+        else:
+            eng[name], deq[name] = a, a
+    return eng, deq

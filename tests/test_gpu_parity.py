@@ -205,6 +205,24 @@ def test_large_m_tiled_gemm_path(W, om16):
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["q8_0", "f16", "q4_0"])
+def test_quantised_gguf_flavours(W, kind):
+    """F16 / Q8_0 / Q4_0 tensors at the seam (scripts/convert_to_gguf.py:118-204) are dequantised at
+    upload: the engine fed the packed bytes == the oracle fed the dequantised f32 values."""
+    engW, deqW = synth.quantize_weights(W, kind)
+    assert sum(isinstance(v, tuple) for v in engW.values()) == N_LAYERS * 12   # FFN 2x2, attention 5, conv pw1/pw2/batch_norm.weight
+    om = ob.OracleModel(deqW, N_LAYERS)
+    eng = capi.Engine(engW, n_layers=N_LAYERS, dtype=capi.DTYPE_F32, max_streams=1)
+    pcm = synth.make_pcm(2, 3.0)
+    st, ost = eng.stream(0), ob.OracleStream(om, 0)
+    tg, to = [], []
+    for o in range(0, pcm.size, 1280):
+        tg += eng.step([st], [pcm[o:o + 1280]])[0]
+        to += ost.process(pcm[o:o + 1280])
+    assert tg == to and st.stats().chunks == ost.total_chunks
+    eng.close()
+
+
 def test_pcm_end_to_end_tokens_f32(eng32, om32):
     """PCM in, tokens out, R=0, incl. the tail flush; token-for-token vs the oracle."""
     pcm = synth.make_pcm(2, 6.0)

@@ -94,3 +94,15 @@ def test_live_reference_agrees_with_golden(golden, weights1):
                          gi.split_pcm(gi.pcm()))
     assert np.array_equal(mel, golden["mel"])
     assert ob.ref_greedy(weights1, gi.enc_frames(64)) == golden["greedy_tokens"].tolist()
+
+
+def test_quant_pack_roundtrip():
+    """Packers follow the reference block layouts; dequantised error bounded by half a step."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((64, 96)).astype(np.float32)
+    q8 = synth.unpack_q8_0(synth.pack_q8_0(x), x.shape)
+    assert synth.pack_q8_0(x).size == x.size // 32 * 34
+    assert np.abs(q8 - x).max() <= np.abs(x).max() / 127 * 0.51 + 1e-3
+    q4 = synth.unpack_q4_0(synth.pack_q4_0(x), x.shape)
+    assert synth.pack_q4_0(x).size == x.size // 32 * 18
+    assert np.abs(q4 - x).max() <= np.abs(x).max() / 7 * 1.01 + 1e-3
