@@ -47,11 +47,33 @@ __global__ void k_dec_begin(DecParams p) {
     }
 }
 
-// acc[mt] += W_tile(nt, kg range) . X   for MT m-tiles; xrow[mt] = this lane's stream vector
+// acc[mt] += W_tile(nt, kg range) . X   for MT m-tiles; xrow[mt] = this lane's stream vector.
+// The k-groups are processed in blocks of 5 with every load of the block (weights + stream vectors)
+// issued before its MFMAs, so a wave has ~25 independent 16-byte loads in flight instead of one.
 template <int MT>
 __device__ __forceinline__ void mfma_range(const float4 *wt, int kg0, int kg1, const float *const *xrow, int q,
                                            f32x4 *acc) {
-    for (int kg = kg0; kg < kg1; kg++) {
+    constexpr int KB = 5;
+    int kg = kg0;
+    for (; kg + KB <= kg1; kg += KB) {
+        float4 w[KB], x[KB][MT];
+#pragma unroll
+        for (int u = 0; u < KB; u++) {
+            w[u] = wt[(size_t)(kg + u) * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) x[u][mt] = *(const float4 *)(xrow[mt] + (kg + u) * 16 + q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < KB; u++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].x, x[u][mt].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].y, x[u][mt].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].z, x[u][mt].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].w, x[u][mt].w, acc[mt], 0, 0, 0);
+            }
+    }
+    for (; kg < kg1; kg++) {
         const float4 w = wt[(size_t)kg * 64];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {

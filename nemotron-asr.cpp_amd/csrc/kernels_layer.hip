@@ -160,8 +160,121 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
         else ((float *)p.ctx_out)[o] = acc;
     }
 }
+// ---- attention on the matrix cores (bf16, 4 <= T <= 16): one workgroup per (head, stream) ----------
+// scores^T tiles  S[j][i] = K[j].(q_i+u)   (A = 16 cached keys straight from the ring, B = queries)
+// pos-score tiles P[r][i] = Pp[r].(q_i+v)  for every relative row r, rel-shift = an LDS gather
+// context^T       O[d][i] = sum_j V^T[d][j] w[i][j]   (V tile transposed into LDS once per workgroup)
+// q+u / q+v and the softmax weights are rounded to bf16 for the MFMA (two extra rounding points vs the
+// VALU kernel; within the stated bf16 tolerance).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char qu_s[16 * 256], qv_s[16 * 256], w_s[16 * 256];
+    __shared__ __attribute__((aligned(16))) char vt_s[128 * 256];
+    __shared__ float sk[16 * 96], sp[16 * 112];
+    const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
+    const RowDesc rd = p.rows[b];
+    const bf16_t *kbase = (const bf16_t *)p.kv_pool + (size_t)rd.slot * p.kv_slot_stride + h * DH;
+    const bf16_t *vbase = kbase + (size_t)KVC * D;
+    const bf16_t *pbase = (const bf16_t *)p.posproj + h * DH;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    // ---- phase 0: queries (+u, +v) -> bf16 LDS; V tile -> transposed LDS (zero padded to 96 keys) ----
+    for (int e = threadIdx.x; e < 16 * DH; e += 256) {
+        const int i = e >> 7, d = e & 127;
+        const float qq = i < T ? p.q[((size_t)b * T + i) * D + h * DH + d] : 0.0f;
+        const int off = i * 256 + ((((d >> 3) ^ i) & 15) << 4) + (d & 7) * 2;
+        *(bf16_t *)(qu_s + off) = f32_to_bf16(qq + p.bias_u[h * DH + d]);
+        *(bf16_t *)(qv_s + off) = f32_to_bf16(qq + p.bias_v[h * DH + d]);
+    }
+    for (int e = threadIdx.x; e < 96 * 16; e += 256) {
+        const int c = e & 15, j = e >> 4;               // 8 consecutive d of key j
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (j < KV) {
+            int ring = rd.kv_head + j;
+            if (ring >= KVC) ring -= KVC;
+            v = *(const uint4 *)(vbase + (size_t)ring * D + c * 8);
+        }
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int d = c * 8 + u;
+            const bf16_t val = (bf16_t)((u & 1) ? (w4[u >> 1] >> 16) : (w4[u >> 1] & 0xffffu));
+            *(bf16_t *)(vt_s + d * 256 + ((((j >> 3) ^ d) & 15) << 4) + (j & 7) * 2) = val;
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: 6 key tiles + 7 relative-position tiles on the MFMA -------------------------------
+    for (int t = wave; t < 13; t += 4) {
+        const bool isk = t < 6;
+        const bf16_t *arow;
+        if (isk) {
+            int j = t * 16 + r;
+            if (j >= KV) j = KV - 1;
+            int ring = rd.kv_head + j;
+            if (ring >= KVC) ring -= KVC;
+            arow = kbase + (size_t)ring * D;
+        } else {
+            int rr = (t - 6) * 16 + r;
+            if (rr >= n_rel) rr = n_rel - 1;
+            arow = pbase + (size_t)rr * D;
+        }
+        const char *bq = isk ? qu_s : qv_s;
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        uint4 av[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) av[ks] = *(const uint4 *)(arow + ks * 32 + q * 8);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const uint4 bv = *(const uint4 *)(bq + r * 256 + ((((ks << 2) | q) ^ r) << 4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[ks]), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+        }
+        // D[j][i]: lane holds query i = r, rows 4q + reg
+        float *dst = isk ? sk + r * 96 + t * 16 + q * 4 : sp + r * 112 + (t - 6) * 16 + q * 4;
+        *(float4 *)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    // ---- phase 2: rel-shift gather + mask + softmax -> bf16 weights (zero padded to 128 keys) ---------
+    const float scale = 0.08838834764831845f;
+    const int mask_upto = LCTX - rd.valid_len;
+    for (int i = wave; i < 16; i += 4) {
+        float v0 = -INFINITY, v1 = -INFINITY;
+        if (i < T) {
+            if (lane < KV) { v0 = (sk[i * 96 + lane] + sp[i * 112 + lane + T - 1 - i]) * scale; if (lane < mask_upto) v0 += -1e9f; }
+            if (lane + 64 < KV) { v1 = (sk[i * 96 + lane + 64] + sp[i * 112 + lane + 64 + T - 1 - i]) * scale; if (lane + 64 < mask_upto) v1 += -1e9f; }
+        }
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = (i < T && lane < KV) ? __expf(v0 - mx) : 0.0f;
+        const float e1 = (i < T && lane + 64 < KV) ? __expf(v1 - mx) : 0.0f;
+        const float sum = wave_sum(e0 + e1);
+        const float inv = i < T ? 1.0f / sum : 0.0f;
+        const int j0 = lane, j1 = lane + 64;
+        *(bf16_t *)(w_s + i * 256 + ((((j0 >> 3) ^ i) & 15) << 4) + (j0 & 7) * 2) = f32_to_bf16(e0 * inv);
+        *(bf16_t *)(w_s + i * 256 + ((((j1 >> 3) ^ i) & 15) << 4) + (j1 & 7) * 2) = f32_to_bf16(e1 * inv);
+    }
+    __syncthreads();
+    // ---- phase 3: O^T[d][i] = V^T . w^T, 8 d-tiles x 3 k-steps ---------------------------------------
+    for (int dt = wave * 2; dt < wave * 2 + 2; dt++) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            const int d = dt * 16 + r;
+            const uint4 av = *(const uint4 *)(vt_s + d * 256 + (((((ks << 2) | q) ^ d) & 15) << 4));
+            const uint4 bv = *(const uint4 *)(w_s + r * 256 + (((((ks << 2) | q) ^ r) & 15) << 4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+        }
+        if (r < T) {   // D[d][i]: lane holds query i = r, d = dt*16 + 4q + reg
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
+            *(uint2 *)((bf16_t *)p.ctx_out + ((size_t)b * T + r) * D + h * DH + dt * 16 + q * 4) = o;
+        }
+    }
+}
+
 void launch_attention(const AttnParams &p, hipStream_t st) {
-    if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, dim3(NH, p.B), dim3(256), 0, st, p);
+    if (p.act_bf16 && p.T >= 4 && p.T <= 16) hipLaunchKernelGGL(k_attention_mfma, dim3(NH, p.B), dim3(256), 0, st, p);
+    else if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, dim3(NH, p.B), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_attention<false>, dim3(NH, p.B), dim3(256), 0, st, p);
 }
 
