@@ -1,0 +1,234 @@
+// nemo_amd.cpp -- see nemo_amd.h
+#include "nemo_amd.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include "gguf_reader.h"
+#include "nemotron_asr_amd.h"
+
+using nasr_host::GgufFile;
+using nasr_host::GgufValue;
+
+std::string tokens_to_text(const std::vector<int> &tokens, const std::vector<std::string> &vocab) {
+    std::string out;
+    for (int id : tokens) {
+        if (id < 0 || id >= (int)vocab.size()) continue;
+        const std::string &piece = vocab[(size_t)id];
+        if (piece.compare(0, 3, "\xe2\x96\x81") == 0) {   // U+2581
+            out += ' ';
+            out.append(piece, 3, std::string::npos);
+        } else {
+            out += piece;
+        }
+    }
+    return out;
+}
+
+nemo_context *nemo_init_with_device(const char *model_path, int device, int dtype, int max_streams) {
+    if (!model_path) return nullptr;
+    GgufFile g;
+    std::string err;
+    if (!g.open(model_path, err)) {
+        fprintf(stderr, "%s: failed to open GGUF file: %s\n", __func__, err.c_str());
+        return nullptr;
+    }
+    nemo_context *ctx = new nemo_context();
+    nemo_hparams &hp = ctx->hparams;
+    uint32_t v;
+    // nemo.* keys (reference src/nemo-ggml.cpp:108-142); absent keys keep their defaults
+    if (g.get_u32("nemo.n_mels", v)) hp.n_mels = (int32_t)v;
+    if (g.get_u32("nemo.d_model", v)) hp.d_model = (int32_t)v;
+    if (g.get_u32("nemo.n_heads", v)) hp.n_heads = (int32_t)v;
+    if (g.get_u32("nemo.d_head", v)) hp.d_head = (int32_t)v;
+    if (g.get_u32("nemo.d_ff", v)) hp.d_ff = (int32_t)v;
+    if (g.get_u32("nemo.n_layers", v)) hp.n_layers = (int32_t)v;
+    if (g.get_u32("nemo.vocab_size", v)) hp.vocab_size = (int32_t)v;
+    if (g.get_u32("nemo.decoder_dim", v)) hp.decoder_dim = (int32_t)v;
+    if (g.get_u32("nemo.joint_dim", v)) hp.joint_dim = (int32_t)v;
+    if (g.get_u32("nemo.subsampling_factor", v)) hp.subsampling_factor = (int32_t)v;
+    if (g.get_u32("nemo.att_left_context", v)) hp.att_left_context = (int32_t)v;
+    if (g.get_u32("nemo.num_prompts", v)) hp.num_prompts = (int32_t)v;
+    // vocabulary: string array preferred, legacy 8-byte-record blob otherwise (:149-169)
+    if (const GgufValue *vl = g.find("tokenizer.vocab_list"); vl && vl->type == 9) {
+        ctx->vocab = vl->arr_s;
+    } else if (const GgufValue *vb = g.find("tokenizer.vocab"); vb && vb->type == 8) {
+        const size_t n = (size_t)hp.vocab_size - 1;
+        for (size_t i = 0; i < n && (i + 1) * 8 <= vb->s.size(); i++) {
+            const char *rec = vb->s.data() + i * 8;
+            ctx->vocab.emplace_back(rec, strnlen(rec, 8));
+        }
+    } else {
+        fprintf(stderr, "%s: no vocabulary in GGUF (need tokenizer.vocab_list or tokenizer.vocab)\n", __func__);
+        delete ctx;
+        return nullptr;
+    }
+    // language prompt dictionary (:171-182)
+    const GgufValue *pl = g.find("nemo.prompt_langs"), *pi = g.find("nemo.prompt_ids");
+    if (pl && pi && pl->arr_s.size() == pi->arr_i.size())
+        for (size_t i = 0; i < pl->arr_s.size(); i++) ctx->prompt_dict[pl->arr_s[i]] = (int)pi->arr_i[i];
+    if (hp.num_prompts > 0) ctx->prompt_index = 101;   // "auto" (:459-462)
+    // kernel size from the depthwise conv weight, stored (k, C) -> ne[1] = k (:357-360)
+    if (const nasr_host::GgufTensor *dw = g.tensor("encoder.layers.0.conv.depthwise_conv.weight")) hp.kernel_size = (int32_t)dw->ne[1];
+
+    std::vector<nasr_weight_desc> descs;
+    descs.reserve(g.tensors().size());
+    for (const auto &t : g.tensors()) {
+        nasr_weight_desc d;
+        d.name = t.name.c_str();
+        d.type = t.type;
+        d.n_dims = t.n_dims;
+        for (int i = 0; i < 4; i++) d.ne[i] = t.ne[i];
+        d.data = t.data;
+        descs.push_back(d);
+    }
+    nasr_hparams nh;
+    nh.n_mels = hp.n_mels; nh.d_model = hp.d_model; nh.n_heads = hp.n_heads; nh.d_head = hp.d_head; nh.d_ff = hp.d_ff;
+    nh.n_layers = hp.n_layers; nh.vocab_size = hp.vocab_size; nh.decoder_dim = hp.decoder_dim; nh.joint_dim = hp.joint_dim;
+    nh.subsampling_factor = hp.subsampling_factor; nh.att_left_context = hp.att_left_context; nh.kernel_size = hp.kernel_size;
+    nh.num_prompts = hp.num_prompts;
+    if (nasr_engine_create(&ctx->engine, device, dtype, &nh, descs.data(), (int)descs.size(), max_streams) < 0) {
+        fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+        delete ctx;
+        return nullptr;
+    }
+    ctx->max_streams = max_streams;
+    return ctx;
+}
+
+nemo_context *nemo_init(const char *model_path) { return nemo_init_with_device(model_path, 0, NASR_DTYPE_BF16, 64); }
+
+void nemo_free(nemo_context *ctx) {
+    if (!ctx) return;
+    nasr_engine_destroy(ctx->engine);
+    delete ctx;
+}
+
+static bool lookup_lang(nemo_context *ctx, const char *lang, const char *who, int &idx) {
+    if (ctx->hparams.num_prompts <= 0) {
+        fprintf(stderr, "%s: model is not multilingual (num_prompts=0)\n", who);
+        return false;
+    }
+    auto it = ctx->prompt_dict.find(lang);
+    if (it == ctx->prompt_dict.end()) {
+        fprintf(stderr, "%s: unknown language code '%s'\n", who, lang);
+        return false;
+    }
+    idx = it->second;
+    return true;
+}
+
+bool nemo_set_language(nemo_context *ctx, const char *lang) {
+    if (!ctx || !lang) return false;
+    return lookup_lang(ctx, lang, __func__, ctx->prompt_index);
+}
+
+nemo_stream_context *nemo_stream_init(nemo_context *ctx, const nemo_cache_config *config) {
+    if (!ctx) return nullptr;
+    nemo_stream_context *s = new nemo_stream_context();
+    s->nctx = ctx;
+    if (config) s->config = *config;
+    // architecture fields always come from the loaded header (reference src/nemo-stream.cpp:704-728)
+    s->config.att_left_context = ctx->hparams.att_left_context;
+    s->config.subsampling_factor = ctx->hparams.subsampling_factor;
+    s->config.n_mels = ctx->hparams.n_mels;
+    s->prompt_index = ctx->hparams.num_prompts > 0 ? ctx->prompt_index : -1;
+    if (nasr_stream_create(ctx->engine, s->config.att_right_context, s->prompt_index, &s->stream) < 0) {
+        fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+bool nemo_stream_set_language(nemo_stream_context *sctx, const char *lang) {
+    if (!sctx || !lang) return false;
+    int idx;
+    if (!lookup_lang(sctx->nctx, lang, __func__, idx)) return false;
+    if (nasr_stream_set_prompt(sctx->stream, idx) < 0) return false;
+    sctx->prompt_index = idx;
+    return true;
+}
+
+static std::string absorb(nemo_stream_context *s, const int32_t *tok, int n) {
+    if (n <= 0) return "";
+    std::vector<int> ids(tok, tok + n);
+    s->tokens.insert(s->tokens.end(), ids.begin(), ids.end());
+    std::string text = tokens_to_text(ids, s->nctx->vocab);
+    s->transcript += text;
+    return text;
+}
+
+bool nemo_stream_process_batch(nemo_stream_context *const *sctx, int B, const int16_t *const *audio,
+                               const int *n_samples, std::string *out) {
+    if (!sctx || B <= 0 || !audio || !n_samples) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<nasr_stream *> st((size_t)B);
+    std::vector<std::vector<int32_t>> buf((size_t)B);
+    std::vector<int32_t *> ptr((size_t)B);
+    std::vector<int32_t> cap((size_t)B), cnt((size_t)B), ns((size_t)B);
+    for (int b = 0; b < B; b++) {
+        if (!sctx[b]) return false;
+        st[b] = sctx[b]->stream;
+        ns[b] = n_samples[b] > 0 ? n_samples[b] : 0;
+        cap[b] = (ns[b] / 1280 + 16) * 10;                   // <= 10 symbols per 80 ms frame
+        buf[b].resize((size_t)cap[b]);
+        ptr[b] = buf[b].data();
+    }
+    if (nasr_engine_step(sctx[0]->nctx->engine, st.data(), B, audio, ns.data(), ptr.data(), cap.data(), cnt.data(), 0) < 0) {
+        fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+        return false;
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int b = 0; b < B; b++) {
+        nemo_stream_context *s = sctx[b];
+        s->total_audio_seconds += (double)ns[b] / s->config.sample_rate;
+        s->total_compute_seconds += dt / B;
+        std::string text = absorb(s, buf[b].data(), cnt[b] < cap[b] ? cnt[b] : cap[b]);
+        if (out) out[b] = text;
+        nasr_stream_stats stt;
+        if (nasr_stream_get_stats(s->stream, &stt) == 0) s->total_chunks_processed = stt.chunks;
+    }
+    return true;
+}
+
+std::string nemo_stream_process_incremental(nemo_stream_context *sctx, const int16_t *audio, int n_samples) {
+    if (!sctx || !audio || n_samples <= 0) return "";         // reference src/nemo-stream.cpp:1150
+    std::string out;
+    if (!nemo_stream_process_batch(&sctx, 1, &audio, &n_samples, &out)) return "";
+    return out;
+}
+
+std::string nemo_stream_finalize(nemo_stream_context *sctx) {
+    if (!sctx) return "";
+    int32_t tok[256], cap = 256, cnt = 0;
+    int32_t *tp = tok;
+    if (nasr_engine_finalize(sctx->nctx->engine, &sctx->stream, 1, &tp, &cap, &cnt) < 0) {
+        fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+        return "";
+    }
+    return absorb(sctx, tok, cnt < cap ? cnt : cap);       // only the text produced by the tail flush (:1292)
+}
+
+std::string nemo_stream_get_transcript(nemo_stream_context *sctx) { return sctx ? sctx->transcript : ""; }
+
+const std::vector<int> &nemo_stream_get_tokens(nemo_stream_context *sctx) {
+    static const std::vector<int> empty;
+    return sctx ? sctx->tokens : empty;
+}
+
+void nemo_stream_reset(nemo_stream_context *sctx) {
+    if (!sctx) return;
+    nasr_stream_reset(sctx->stream);
+    sctx->tokens.clear();
+    sctx->transcript.clear();
+    sctx->total_audio_seconds = sctx->total_compute_seconds = 0;
+    sctx->total_chunks_processed = 0;
+}
+
+void nemo_stream_free(nemo_stream_context *sctx) {
+    if (!sctx) return;
+    nasr_stream_destroy(sctx->stream);
+    delete sctx;
+}

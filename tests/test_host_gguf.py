@@ -1,0 +1,116 @@
+"""Host side above the C ABI: the ggml-free GGUF v3 reader and the CLI.
+CPU tests cover the file format; the GPU test runs the CLI end to end."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from nemotron_asr_amd import gguf_io, synth
+
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "nemotron-asr.cpp_amd" / "bin"
+
+
+def _fnv(data: bytes) -> str:
+    h = 0
+    for b in data:
+        h = (h * 1099511628211 + b) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def _ensure_built():
+    if not (BIN / "gguf_dump").exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "nemotron-asr.cpp_amd" / "host"), "../bin/gguf_dump"])
+
+
+def _small_file(tmp_path, legacy=False):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((4, 64)).astype(np.float32)
+    w = {
+        "encoder.layers.0.conv.depthwise_conv.weight": rng.standard_normal((9, 32)).astype(np.float32),
+        "t.f32": a,
+        "t.f16": (gguf_io.GGML_F16, a.astype(np.float16), a.shape),
+        "t.q8": (gguf_io.GGML_Q8_0, synth.pack_q8_0(a), a.shape),
+        "t.q4": (gguf_io.GGML_Q4_0, synth.pack_q4_0(a), a.shape),
+        "t.vec": np.arange(7, dtype=np.float32),
+    }
+    path = tmp_path / "small.gguf"
+    gguf_io.write_gguf(path, w, gguf_io.default_hparams(n_layers=3, num_prompts=2), gguf_io.synthetic_vocab(),
+                       prompt_dict={"en-US": 0, "auto": 1}, legacy_vocab_blob=legacy)
+    return path, w
+
+
+def test_cpp_reader_matches_python_writer(tmp_path):
+    _ensure_built()
+    path, w = _small_file(tmp_path)
+    out = json.loads(subprocess.check_output([str(BIN / "gguf_dump"), str(path)]))
+    kv, tensors, start = gguf_io.read_gguf(path)
+    assert out["version"] == 3 and out["data_start"] == start and start % 32 == 0
+    assert out["kv"]["nemo.n_layers"] == 3 and out["kv"]["nemo.num_prompts"] == 2 and out["kv"]["nemo.d_model"] == 1024
+    assert out["vocab_list"] == 1024 == len(kv["tokenizer.vocab_list"])
+    raw = path.read_bytes()
+    assert [t["name"] for t in out["tensors"]] == list(w)
+    for t in out["tensors"]:
+        ty, dims, off, nb = tensors[t["name"]]
+        assert (t["type"], t["ne"][:t["n_dims"]], t["offset"], t["nbytes"]) == (ty, dims, off, nb)
+        assert off % 32 == 0
+        assert t["hash"] == _fnv(raw[start + off:start + off + nb])
+    dw = next(t for t in out["tensors"] if "depthwise" in t["name"])
+    assert dw["ne"][:2] == [32, 9]          # (k, C) stored -> ne[1] = kernel size (src/nemo-ggml.cpp:357-360)
+    q8 = next(t for t in out["tensors"] if t["name"] == "t.q8")
+    assert q8["nbytes"] == 4 * 64 // 32 * 34
+
+
+def test_cpp_reader_rejects_bad_files(tmp_path):
+    _ensure_built()
+    path, _ = _small_file(tmp_path)
+    raw = path.read_bytes()
+    (tmp_path / "trunc.gguf").write_bytes(raw[:len(raw) - 100])
+    (tmp_path / "magic.gguf").write_bytes(b"GGML" + raw[4:])
+    for name in ("trunc.gguf", "magic.gguf", "missing.gguf"):
+        r = subprocess.run([str(BIN / "gguf_dump"), str(tmp_path / name)], capture_output=True)
+        assert r.returncode == 2 and b"error" in r.stderr
+
+
+def test_cache_config_arithmetic_in_header():
+    """nemo_cache_config mirrors reference src/nemo-stream.h:65-100."""
+    hdr = (ROOT / "nemotron-asr.cpp_amd" / "host" / "nemo_amd.h").read_text()
+    for name in ("nemo_stream_init", "nemo_stream_process_incremental", "nemo_stream_finalize", "nemo_stream_get_transcript",
+                 "nemo_stream_get_tokens", "nemo_stream_reset", "nemo_stream_free", "nemo_stream_set_language", "tokens_to_text"):
+        assert name in hdr
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path):
+    """GGUF file -> C++ loader -> engine -> transcript; tokens equal the oracle's, text follows the U+2581 rule."""
+    from oracle import binding as ob
+    n_layers = 2
+    W = synth.make_weights(n_layers=n_layers)
+    engW, deqW = synth.quantize_weights(W, "q8_0")
+    vocab = gguf_io.synthetic_vocab()
+    model = tmp_path / "model-q8.gguf"
+    gguf_io.write_gguf(model, engW, gguf_io.default_hparams(n_layers=n_layers), vocab, legacy_vocab_blob=True)
+    pcm = synth.make_pcm(2, 5.0)
+    audio = tmp_path / "a.pcm"
+    pcm.tofile(audio)
+    cli = BIN / "nemotron-asr-amd"
+    assert cli.exists(), "run __graft_entry__.build()"
+    for R in (0, 13):
+        r = subprocess.run([str(cli), str(model), str(audio), "80", str(R), "--f32", "--print-tokens"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.splitlines()
+        toks = [int(x) for x in lines[-1].split()[1:]]
+        ost = ob.OracleStream(ob.OracleModel(deqW, n_layers), R)
+        ref = []
+        n = synth.chunk_mel_frames(R) * 160            # the CLI reads get_chunk_samples() per fread
+        for o in range(0, pcm.size, n):
+            ref += ost.process(pcm[o:o + n])
+        ref += ost.finalize()
+        assert toks == ref and len(ref) > 0
+        text = "".join((" " + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t] for t in toks)
+        assert lines[0] == text
+        assert "Real-time factor" in r.stderr
+    r = subprocess.run([str(cli), str(model), str(audio), "80", "5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "right_context" in r.stderr
