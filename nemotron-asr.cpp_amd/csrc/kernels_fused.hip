@@ -132,15 +132,15 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
     }
 
-    if (PRO == PRO_LN && M <= 4) {
+    if (PRO == PRO_LN && M <= 2) {
         // block-per-row: every global load of the prologue is issued up front (one memory round trip)
         const int c4 = threadIdx.x * 4;
         const float4 lw = *(const float4 *)(p.ln_w + c4), lb = *(const float4 *)(p.ln_b + c4);
         float4 ow = make_float4(0.f, 0.f, 0.f, 0.f), ob = ow;
         if (p.lno_w) { ow = *(const float4 *)(p.lno_w + c4); ob = *(const float4 *)(p.lno_b + c4); }
-        float4 xv[4], t[4][8];
+        float4 xv[2], t[2][8];
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
+        for (int m = 0; m < 2; m++) {
             if (m < M) {
                 xv[m] = *(const float4 *)(p.x_in + (size_t)m * D + c4);
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             }
         }
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
+        for (int m = 0; m < 2; m++) {
             if (m < M) {
                 float4 v = xv[m];
                 if (p.part_splits > 0) {
@@ -167,28 +167,48 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         }
         __syncthreads();
     } else if (PRO == PRO_LN) {
+        // M > 2, two phases.  A: every thread forms x + scale * sum(partials) for a strip of all rows (all
+        // loads independent) and parks it in LDS; B: one wave per row does the LayerNorm(s) out of LDS.
+        float *xs = (float *)(panel + 16 * KP * 2);            // [M][1024] f32
+        const int c4 = threadIdx.x * 4;
+        for (int m0 = 0; m0 < M; m0 += 4) {                    // 4 rows per round: all their loads in flight together
+            float4 xv[4], t[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = m0 + u < M ? m0 + u : M - 1;
+                xv[u] = *(const float4 *)(p.x_in + (size_t)m * D + c4);
+#pragma unroll
+                for (int sI = 0; sI < 8; sI++)
+                    t[u][sI] = sI < p.part_splits ? *(const float4 *)(p.part + ((size_t)sI * M + m) * D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = m0 + u;
+                if (m < M) {
+                    float4 v = xv[u];
+                    if (p.part_splits > 0) {
+                        float4 o = t[u][0];
+#pragma unroll
+                        for (int sI = 1; sI < 8; sI++)
+                            if (sI < p.part_splits) { o.x += t[u][sI].x; o.y += t[u][sI].y; o.z += t[u][sI].z; o.w += t[u][sI].w; }
+                        v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
+                    }
+                    *(float4 *)(xs + (size_t)m * D + c4) = v;
+                    if (writer && p.x_out && !p.lno_w) *(float4 *)(p.x_out + (size_t)m * D + c4) = v;
+                }
+            }
+        }
+        __syncthreads();
         for (int m = wave; m < M; m += 4) {
             float4 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int e = lane * 4 + 256 * i;
-                v[i] = *(const float4 *)(p.x_in + (size_t)m * D + e);
-                if (p.part_splits > 0) {
-                    float4 t[8];
+            for (int i = 0; i < 4; i++) v[i] = *(const float4 *)(xs + (size_t)m * D + lane * 4 + 256 * i);
+            if (p.lno_w) {
+                wave_ln(v, p.lno_w, p.lno_b, lane);                // previous layer's norm_out (:687)
+                if (writer && p.x_out) {
 #pragma unroll
-                    for (int s = 0; s < 8; s++)      // independent loads: issued together, summed in order
-                        t[s] = s < p.part_splits ? *(const float4 *)(p.part + ((size_t)s * M + m) * D + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    float4 o = t[0];
-#pragma unroll
-                    for (int s = 1; s < 8; s++)
-                        if (s < p.part_splits) { o.x += t[s].x; o.y += t[s].y; o.z += t[s].z; o.w += t[s].w; }
-                    v[i].x += p.scale * o.x; v[i].y += p.scale * o.y; v[i].z += p.scale * o.z; v[i].w += p.scale * o.w;
+                    for (int i = 0; i < 4; i++) *(float4 *)(p.x_out + (size_t)m * D + lane * 4 + 256 * i) = v[i];
                 }
-            }
-            if (p.lno_w) wave_ln(v, p.lno_w, p.lno_b, lane);           // previous layer's norm_out (:687)
-            if (writer && p.x_out) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) *(float4 *)(p.x_out + (size_t)m * D + lane * 4 + 256 * i) = v[i];
             }
             wave_ln(v, p.ln_w, p.ln_b, lane);
 #pragma unroll
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     } else if (PRO == PRO_ATTN) {
         // one head (= split) of the cached rel-pos attention for all M rows (src/nemo-stream.cpp:463-573)
         const AttnParams &a = p.at;
-        const int h = split, T = a.T, KV = LCTX + T;
+        const int h = split, T = a.T, KV = LCTX + T, TS = a.TS > 0 ? a.TS : a.T;
         float *qu = (float *)(panel + 16 * KP * 2);                  // [16][128]
         float *qv = qu + 16 * DH;                                    // [16][128]
         float *sc = qv + 16 * DH;                                    // [16][KVC]
@@ -214,9 +234,11 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         for (int pr = threadIdx.x >> 1; pr < ((M * KV + 127) & ~127); pr += 128) {   // uniform trip count
             const bool ok = pr < M * KV;
             const int m = ok ? pr / KV : 0, j = ok ? pr - m * KV : 0;
-            const int b = m / T, i = m - b * T;
+            // row m = (stream b, chunk g of this launch, frame i); its key window starts g*T rows later
+            const int b = m / TS, il = m - b * TS, gch = il / T, i = il - gch * T;
             const RowDesc rd = a.rows[b];
-            int ring = rd.kv_head + j;
+            int ring = rd.kv_head + gch * T + j;
+            if (ring >= KVC) ring -= KVC;
             if (ring >= KVC) ring -= KVC;
             const bf16_t *krow = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)ring * D + h * DH + sub * 64;
             const bf16_t *prow = (const bf16_t *)a.posproj + (size_t)(j + T - 1 - i) * D + h * DH + sub * 64;
@@ -240,7 +262,8 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             v += __shfl_xor(v, 1);
             if (ok && sub == 0) {
                 v *= scale;
-                if (j < LCTX - rd.valid_len) v += -1e9f;
+                const int valid = rd.valid_len + gch * T < LCTX ? rd.valid_len + gch * T : LCTX;
+                if (j < LCTX - valid) v += -1e9f;
                 sc[m * KVC + j] = v;
             }
         }
@@ -261,15 +284,17 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             float *pv = qu;                                   // reuse: [8 groups][16 rows... handled per row][128]
             const int dq = threadIdx.x & 31, kgp = threadIdx.x >> 5;
             for (int m = 0; m < M; m++) {
-                const int b = m / T;
+                const int b = m / TS, gch = (m - b * TS) / T;
                 const RowDesc rd = a.rows[b];
+                const int head0 = rd.kv_head + gch * T;
                 const bf16_t *vbase = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)KVC * D + h * DH + dq * 4;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 uint2 vv[11];
 #pragma unroll
                 for (int u = 0; u < 11; u++) {                // KV <= 84 -> at most 11 keys per group
                     const int j = kgp + 8 * u;
-                    int ring = rd.kv_head + (j < KV ? j : 0);
+                    int ring = head0 + (j < KV ? j : 0);
+                    if (ring >= KVC) ring -= KVC;
                     if (ring >= KVC) ring -= KVC;
                     vv[u] = *(const uint2 *)(vbase + (size_t)ring * D);
                 }
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         const ConvParams &c = p.cv;
         const int T = c.T, ks1 = c.ks - 1;
         const int k0 = t0 * 32;
-        if (M <= 4) {
+        if (M <= 2) {
             // block-per-row, 4 channels per thread; taps unrolled so all loads are in flight together
             const int c4 = threadIdx.x * 4;
             const float4 lw = *(const float4 *)(c.ln_w + c4), lb = *(const float4 *)(c.ln_b + c4);
@@ -343,46 +368,62 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
                     }
                 }
             }
-        } else
-        for (int m = wave; m < M; m += 4) {
-            const int b = m / T, i = m - b * T;
-            const RowDesc rd = c.rows[b];
-            const float *cc_in = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)rd.cc_par * ks1 * D;
-            float *cc_out = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
-            const float *gl = c.glu + (size_t)b * T * D;
-            float4 v[4];
+        } else {
+            // M > 2, two phases: A = taps for a 4-channel strip of every row (independent loads) -> LDS,
+            // B = one wave per row: LayerNorm + SiLU out of LDS.
+            float *cs = (float *)(panel + 16 * KP * 2);        // [M][1024] f32
+            const int c4 = threadIdx.x * 4;
+            for (int m = 0; m < M; m++) {
+                const int b = m / T, i = m - b * T;
+                const RowDesc rd = c.rows[b];
+                const float *cc_in = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)rd.cc_par * ks1 * D;
+                float *cc_out = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
+                const float *gl = c.glu + (size_t)b * T * D;
+                float4 acc;
+                if (c.ks == 9) {
+                    float4 z[9], w[9];
 #pragma unroll
-            for (int ii = 0; ii < 4; ii++) {
-                const int e = lane * 4 + 256 * ii;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = 0; k < c.ks; k++) {
-                    const int rr = i + k;
-                    const float4 z = rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + e) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + e);
-                    const float4 w = *(const float4 *)(c.dw + (size_t)k * D + e);
-                    if (k == 0) acc = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
-                    else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
+                    for (int k = 0; k < 9; k++) {
+                        const int rr = i + k;
+                        z[k] = rr < 8 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - 8) * D + c4);
+                        w[k] = *(const float4 *)(c.dw + (size_t)k * D + c4);
+                    }
+                    acc = make_float4(z[0].x * w[0].x, z[0].y * w[0].y, z[0].z * w[0].z, z[0].w * w[0].w);
+#pragma unroll
+                    for (int k = 1; k < 9; k++) { acc.x += z[k].x * w[k].x; acc.y += z[k].y * w[k].y; acc.z += z[k].z * w[k].z; acc.w += z[k].w * w[k].w; }
+                } else {
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int k = 0; k < c.ks; k++) {
+                        const int rr = i + k;
+                        const float4 z = rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + c4);
+                        const float4 w = *(const float4 *)(c.dw + (size_t)k * D + c4);
+                        if (k == 0) acc = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
+                        else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
+                    }
                 }
-                v[ii] = acc;
-            }
-            wave_ln(v, c.ln_w, c.ln_b, lane);
-#pragma unroll
-            for (int ii = 0; ii < 4; ii++) {
-                const int e = lane * 4 + 256 * ii;
-                if (e >= k0 && e < k0 + KP) {
-                    float4 n = v[ii];
-                    n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));
-                    n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
-                    store4_panel(panel, m, e - k0, KP, n.x, n.y, n.z, n.w);
+                *(float4 *)(cs + (size_t)m * D + c4) = acc;
+                if (writer && i == 0) {
+                    for (int r2 = 0; r2 < ks1; r2++) {
+                        const int rr = T + r2;
+                        *(float4 *)(cc_out + (size_t)r2 * D + c4) =
+                            rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + c4);
+                    }
                 }
             }
-            if (writer && i == 0) {   // new conv cache = last ks-1 rows of [cache ; glu] -> other parity buffer
-                for (int r2 = 0; r2 < ks1; r2++) {
-                    const int rr = T + r2;
+            __syncthreads();
+            for (int m = wave; m < M; m += 4) {
+                float4 v[4];
 #pragma unroll
-                    for (int ii = 0; ii < 4; ii++) {
-                        const int e = lane * 4 + 256 * ii;
-                        const float4 z = rr < ks1 ? *(const float4 *)(cc_in + (size_t)rr * D + e) : *(const float4 *)(gl + (size_t)(rr - ks1) * D + e);
-                        *(float4 *)(cc_out + (size_t)r2 * D + e) = z;
+                for (int ii = 0; ii < 4; ii++) v[ii] = *(const float4 *)(cs + (size_t)m * D + lane * 4 + 256 * ii);
+                wave_ln(v, c.ln_w, c.ln_b, lane);
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++) {
+                    const int e = lane * 4 + 256 * ii;
+                    if (e >= k0 && e < k0 + KP) {
+                        float4 n = v[ii];
+                        n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));
+                        n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
+                        store4_panel(panel, m, e - k0, KP, n.x, n.y, n.z, n.w);
                     }
                 }
             }
@@ -416,11 +457,17 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     }
 }
 
+void init_fused_kernel_attributes() {   // LN / dwconv row staging can exceed the 64 KiB default dynamic-LDS limit at M = 16
+    hipFuncSetAttribute((const void *)k_fused_skinny<PRO_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
+    hipFuncSetAttribute((const void *)k_fused_skinny<PRO_DWCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
+}
+
 void launch_fused_skinny(const FusedParams &p, hipStream_t st) {
     const GemmParams &g = p.g;
     const int KP = (g.K / g.splits);
     size_t lds = 4096 + (size_t)16 * KP * 2;
     if (p.pro == PRO_ATTN) lds += (size_t)(2 * 16 * DH + 16 * KVC) * 4;
+    if ((p.pro == PRO_LN || p.pro == PRO_DWCONV) && g.M > 2) lds += (size_t)g.M * D * 4;   // f32 row staging
     dim3 grid(g.N / 16, g.splits);
     switch (p.pro) {
     case PRO_LN: hipLaunchKernelGGL(k_fused_skinny<PRO_LN>, grid, dim3(256), lds, st, p); break;

@@ -297,6 +297,10 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
                            acc[j][mt][2], acc[j][mt][3]);
 }
 
+void init_gemm_kernel_attributes() {
+    hipFuncSetAttribute((const void *)k_gemm_tiled2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+}
+
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     if (p.splits < 1) p.splits = 1;
@@ -310,11 +314,6 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         dim3 grid(n_groups * m_chunks * p.splits);
         static bool use_dma = getenv("NASR_GEMM_NODMA") == nullptr;
         if (use_dma) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipFuncSetAttribute((const void *)k_gemm_tiled2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
-                attr_set = true;
-            }
             hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
         } else {
             hipLaunchKernelGGL(k_gemm_tiled, grid, dim3(256), 0, st, p, n_groups, m_chunks);

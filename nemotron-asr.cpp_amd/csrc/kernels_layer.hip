@@ -102,60 +102,65 @@ __device__ __forceinline__ float dot128(const float *qs, const void *row) {
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
+    // TS rows of this stream = G chunks x T frames (G = 1 unless a multi-chunk step): row il = (chunk g, frame i)
+    // attends the 70 + T keys starting g*T rows into the ring.
     __shared__ float qu[TMAX][DH], qv[TMAX][DH];
     __shared__ float sc[TMAX][KVC];
-    const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T;
+    const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, TS = p.TS > 0 ? p.TS : p.T;
     const RowDesc rd = p.rows[b];
     const int esz = BF16 ? 2 : 4;
     const char *kbase = (const char *)p.kv_pool + ((size_t)rd.slot * p.kv_slot_stride) * esz;
     const char *vbase = kbase + (size_t)KVC * D * esz;
-    for (int e = threadIdx.x; e < T * DH; e += 256) {
-        const int i = e >> 7, d = e & 127;
-        const float q = p.q[((size_t)b * T + i) * D + h * DH + d];
-        qu[i][d] = q + p.bias_u[h * DH + d];     // src/nemo-stream.cpp:531-535
-        qv[i][d] = q + p.bias_v[h * DH + d];
+    for (int e = threadIdx.x; e < TS * DH; e += 256) {
+        const int il = e >> 7, d = e & 127;
+        const float q = p.q[((size_t)b * TS + il) * D + h * DH + d];
+        qu[il][d] = q + p.bias_u[h * DH + d];     // src/nemo-stream.cpp:531-535
+        qv[il][d] = q + p.bias_v[h * DH + d];
     }
     __syncthreads();
     const float scale = 0.08838834764831845f;    // 1/sqrt(128), :545
-    const int mask_upto = LCTX - rd.valid_len;   // :1037-1043
-    for (int e = threadIdx.x; e < T * KV; e += 256) {
-        const int i = e / KV, j = e - i * KV;
-        int ring = rd.kv_head + j;
+    for (int e = threadIdx.x; e < TS * KV; e += 256) {
+        const int il = e / KV, j = e - il * KV, g = il / T, i = il - g * T;
+        int ring = rd.kv_head + g * T + j;
+        if (ring >= KVC) ring -= KVC;
         if (ring >= KVC) ring -= KVC;
         const char *krow = kbase + ((size_t)ring * D + h * DH) * esz;
         // rel-shift folded into indexing: slice row j + T - 1 - i  <->  rel = (70 + i) - j  (:419-461)
         const char *prow = (const char *)p.posproj + ((size_t)(j + T - 1 - i) * D + h * DH) * esz;
-        const float s1 = dot128<BF16>(qu[i], krow);   // :538
-        const float s2 = dot128<BF16>(qv[i], prow);   // :541-542
-        float v = (s1 + s2) * scale;                  // :546-547
-        if (j < mask_upto) v += -1e9f;                // :552-556
-        sc[i][j] = v;
+        const float s1 = dot128<BF16>(qu[il], krow);   // :538
+        const float s2 = dot128<BF16>(qv[il], prow);   // :541-542
+        float v = (s1 + s2) * scale;                   // :546-547
+        const int valid = rd.valid_len + g * T < LCTX ? rd.valid_len + g * T : LCTX;
+        if (j < LCTX - valid) v += -1e9f;              // :552-556, :1037-1043
+        sc[il][j] = v;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = wave; i < T; i += 4) {               // softmax, :559
-        float v0 = lane < KV ? sc[i][lane] : -INFINITY;
-        float v1 = lane + 64 < KV ? sc[i][lane + 64] : -INFINITY;
+    for (int il = wave; il < TS; il += 4) {           // softmax, :559
+        float v0 = lane < KV ? sc[il][lane] : -INFINITY;
+        float v1 = lane + 64 < KV ? sc[il][lane + 64] : -INFINITY;
         const float mx = wave_max(fmaxf(v0, v1));
         const float e0 = lane < KV ? __expf(v0 - mx) : 0.0f;
         const float e1 = lane + 64 < KV ? __expf(v1 - mx) : 0.0f;
         const float inv = 1.0f / wave_sum(e0 + e1);
-        if (lane < KV) sc[i][lane] = e0 * inv;
-        if (lane + 64 < KV) sc[i][lane + 64] = e1 * inv;
+        if (lane < KV) sc[il][lane] = e0 * inv;
+        if (lane + 64 < KV) sc[il][lane + 64] = e1 * inv;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < T * DH; e += 256) { // context = P.V, :563
-        const int i = e >> 7, d = e & 127;
+    for (int e = threadIdx.x; e < TS * DH; e += 256) { // context = P.V, :563
+        const int il = e >> 7, d = e & 127, g = il / T;
         float acc = 0.0f;
-        int ring = rd.kv_head;
+        int ring = rd.kv_head + g * T;
+        if (ring >= KVC) ring -= KVC;
+#pragma unroll 4
         for (int j = 0; j < KV; j++) {
             float vv;
             if (BF16) vv = bf16_to_f32(((const bf16_t *)vbase)[(size_t)ring * D + h * DH + d]);
             else vv = ((const float *)vbase)[(size_t)ring * D + h * DH + d];
-            acc += sc[i][j] * vv;
+            acc += sc[il][j] * vv;
             if (++ring == KVC) ring = 0;
         }
-        const size_t o = ((size_t)b * T + i) * D + h * DH + d;
+        const size_t o = ((size_t)b * TS + il) * D + h * DH + d;
         if (BF16) ((bf16_t *)p.ctx_out)[o] = f32_to_bf16(acc);
         else ((float *)p.ctx_out)[o] = acc;
     }
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
 }
 
 void launch_attention(const AttnParams &p, hipStream_t st) {
-    if (p.act_bf16 && p.T >= 4 && p.T <= 16) hipLaunchKernelGGL(k_attention_mfma, dim3(NH, p.B), dim3(256), 0, st, p);
+    if (p.act_bf16 && p.T >= 4 && p.T <= 16 && (p.TS == 0 || p.TS == p.T)) hipLaunchKernelGGL(k_attention_mfma, dim3(NH, p.B), dim3(256), 0, st, p);
     else if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, dim3(NH, p.B), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_attention<false>, dim3(NH, p.B), dim3(256), 0, st, p);
 }

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -101,7 +102,9 @@ struct nasr_engine {
     bool opt_fused = true, opt_graph = true;
     // hipGraph replay of the steady-state step: fixed descriptor buffers + one exec per (B, T)
     std::map<int, hipGraphExec_t> graphs;
-    RowDesc *g_rows = nullptr; PcmDesc *g_pcm = nullptr; int *g_meta = nullptr;       // device
+    RowDesc *g_rows = nullptr, *g_vrows = nullptr; PcmDesc *g_pcm = nullptr; int *g_meta = nullptr;       // device
+    RowDesc *gh_vrows = nullptr;
+    bool opt_multichunk = true;
     char *gh = nullptr;                                                               // pinned host block
     RowDesc *gh_rows = nullptr; PcmDesc *gh_pcm = nullptr; int *gh_meta = nullptr, *gh_collect = nullptr, *gh_active = nullptr;
     int64_t graph_replays = 0, eager_steps = 0;
@@ -526,6 +529,8 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     e->device = device_id; e->dtype = dtype; e->max_streams = max_streams; e->hp = *hp;
     e->bf16 = dtype == NASR_DTYPE_BF16; e->esz = e->bf16 ? 2 : 4;
     if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
+    init_gemm_kernel_attributes();
+    init_fused_kernel_attributes();
     if (load_weights(e, weights, n_weights)) { nasr_engine_destroy(e); return -1; }
 
     const size_t S = (size_t)max_streams, Lr = (size_t)hp->n_layers, ks1 = (size_t)hp->kernel_size - 1;
@@ -556,10 +561,12 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     { char *p; rc |= dalloc(e, &p, M * FF * e->esz); e->hbuf = p; }
     { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->ctx = p; }
     { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->cbuf = p; }
-    // subsampling ping-pong buffers, sized for R = 13: H1 = 61, W1 = 65
-    const size_t sub_elems = S * 61 * 65 * SUBC;
+    // subsampling ping-pong buffers.  Per stream the worst case is NOT R = 13 (H1 = 61 rows) but a
+    // multi-chunk step at R = 0: 14 chunks x H1 = 9 rows = 126 rows of 65 x 256 after conv0, 14 x 5 = 70 rows of
+    // 33 x 256 after the first depthwise conv (G * T <= 14, H1 = 4T + 5, H2 = 2T + 3).
+    const size_t sub_elems = S * 126 * 65 * SUBC;
     rc |= dalloc(e, &e->sub_a, sub_elems);
-    { char *p; rc |= dalloc(e, &p, (S * 31 * 33 * SUBC) * 4); e->sub_b = p; }
+    { char *p; rc |= dalloc(e, &p, (S * 70 * 33 * SUBC) * 4); e->sub_b = p; }
     rc |= dalloc(e, &e->jact, S * JNT);
     rc |= dalloc(e, &e->key, 2 * S);
     rc |= dalloc(e, &e->n_active, 4);
@@ -573,7 +580,10 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     {
         const size_t off_rows = 0, off_pcm = off_rows + S * sizeof(RowDesc), off_meta = off_pcm + S * sizeof(PcmDesc);
         const size_t off_col = off_meta + 2 * S * sizeof(int), off_act = off_col + S * (1 + COLLECT_STRIDE) * sizeof(int);
-        if (hipHostMalloc((void **)&e->gh, off_act + 64, hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+        const size_t off_vr = off_act + 64;
+        if (hipHostMalloc((void **)&e->gh, off_vr + S * TMAX * sizeof(RowDesc), hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+        e->gh_vrows = (RowDesc *)(e->gh + off_vr);
+        if (dalloc(e, &e->g_vrows, S * TMAX)) { nasr_engine_destroy(e); return -1; }
         e->gh_rows = (RowDesc *)(e->gh + off_rows); e->gh_pcm = (PcmDesc *)(e->gh + off_pcm); e->gh_meta = (int *)(e->gh + off_meta);
         e->gh_collect = (int *)(e->gh + off_col); e->gh_active = (int *)(e->gh + off_act);
         if (dalloc(e, &e->g_rows, S) || dalloc(e, &e->g_pcm, S) || dalloc(e, &e->g_meta, 2 * S)) { nasr_engine_destroy(e); return -1; }
@@ -734,8 +744,9 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
 }
 
 // ---- small-M form of the 24 layers: 8 launches per layer (kernels_fused.hip) ------------------------
-static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T) {
-    const int M = B * T, nL = e->hp.n_layers, ks = e->hp.kernel_size;
+static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G) {
+    const int TS = G * T;                      // rows per stream in this launch (G chunks batched)
+    const int M = B * TS, nL = e->hp.n_layers, ks = e->hp.kernel_size;
     hipStream_t st = e->st;
     float *X[2] = {e->x, e->x2};
     int cur = 0;
@@ -766,28 +777,59 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T) {
         f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = 4; f.scale = 0.5f;
         f.ln_w = L.ln_att_w; f.ln_b = L.ln_att_b;
         f.g.W = L.wqkv; f.g.M = M; f.g.N = 3 * D; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_QKV; f.g.q_out = e->q;
-        f.g.kv_pool = e->kv_pool[l]; f.g.kv_slot_stride = (int64_t)2 * KVC * D; f.g.rows = rows; f.g.T = T;
+        f.g.kv_pool = e->kv_pool[l]; f.g.kv_slot_stride = (int64_t)2 * KVC * D; f.g.rows = rows; f.g.T = TS;
         launch(f, "k_fused_ln_gemm", wbytes(3 * D, D), 2.0 * M * 3 * D * D);
         cur ^= 1;
-        // K4: attention (one head per blockIdx.y) -> out projection, split-K over the 8 heads
-        memset(&f, 0, sizeof(f));
-        f.pro = PRO_ATTN; f.at.q = e->q; f.at.kv_pool = e->kv_pool[l]; f.at.kv_slot_stride = (int64_t)2 * KVC * D; f.at.act_bf16 = 1;
-        f.at.posproj = L.posproj[T]; f.at.bias_u = L.bias_u; f.at.bias_v = L.bias_v; f.at.rows = rows; f.at.B = B; f.at.T = T;
-        f.g.W = L.wo; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = NH; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
-        launch(f, "k_fused_attn_gemm", wbytes(D, D) + (double)B * (3.0 * (LCTX + T)) * D * 2, 2.0 * M * D * D);
+        // K4: attention -> out projection.  M <= 2: fused (one head per blockIdx.y recomputes the tiny attention,
+        // split-K over the 8 heads).  Larger M: the redundancy (64 workgroups per head) stops paying, so attention is
+        // its own launch (one workgroup per (head, stream)) followed by the plain weight-streaming GEMM.
+        static const int fuse_max_m = getenv("NASR_FUSE_MAXM") ? atoi(getenv("NASR_FUSE_MAXM")) : 2;
+        int wo_splits = NH;
+        if (M <= fuse_max_m) {
+            memset(&f, 0, sizeof(f));
+            f.pro = PRO_ATTN; f.at.q = e->q; f.at.kv_pool = e->kv_pool[l]; f.at.kv_slot_stride = (int64_t)2 * KVC * D; f.at.act_bf16 = 1;
+            f.at.posproj = L.posproj[T]; f.at.bias_u = L.bias_u; f.at.bias_v = L.bias_v; f.at.rows = rows; f.at.B = B; f.at.T = T; f.at.TS = TS;
+            f.g.W = L.wo; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = NH; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+            launch(f, "k_fused_attn_gemm", wbytes(D, D) + (double)B * (3.0 * (LCTX + T)) * D * 2, 2.0 * M * D * D);
+        } else {
+            AttnParams ap;
+            memset(&ap, 0, sizeof(ap));
+            ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = 1;
+            ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T; ap.TS = TS;
+            ap.ctx_out = e->ctx;
+            { ProfScope ps(e, "k_attention", (double)B * (3.0 * (LCTX + T)) * D * 2, 2.0 * M * (LCTX + T) * D * 3); launch_attention(ap, st); }
+            wo_splits = 4;
+            memset(&f, 0, sizeof(f));
+            f.pro = PRO_PLAIN; f.g.A = e->ctx; f.g.lda = D; f.g.W = L.wo; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4;
+            f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+            launch(f, "k_fused_plain_gemm", wbytes(D, D), 2.0 * M * D * D);
+        }
         // K5: x += attn ; LN_conv -> pointwise conv 1 -> GLU
         memset(&f, 0, sizeof(f));
-        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = NH; f.scale = 1.0f;
+        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = wo_splits; f.scale = 1.0f;
         f.ln_w = L.ln_conv_w; f.ln_b = L.ln_conv_b;
         f.g.W = L.pw1; f.g.M = M; f.g.N = 2 * D; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_GLU; f.g.out_f32 = e->glu; f.g.ldo = D;
         launch(f, "k_fused_ln_gemm", wbytes(2 * D, D), 2.0 * M * 2 * D * D);
         cur ^= 1;
-        // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2 (split-K 4)
-        memset(&f, 0, sizeof(f));
-        f.pro = PRO_DWCONV; f.cv.glu = e->glu; f.cv.cc_pool = e->cc_pool[l]; f.cv.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
-        f.cv.dw = L.dw; f.cv.ln_w = L.cln_w; f.cv.ln_b = L.cln_b; f.cv.rows = rows; f.cv.B = B; f.cv.T = T; f.cv.ks = ks;
-        f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
-        launch(f, "k_fused_dwconv_gemm", wbytes(D, D), 2.0 * M * D * D);
+        // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2 (split-K 4); same rule as K4
+        if (M <= fuse_max_m) {
+            memset(&f, 0, sizeof(f));
+            f.pro = PRO_DWCONV; f.cv.glu = e->glu; f.cv.cc_pool = e->cc_pool[l]; f.cv.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
+            f.cv.dw = L.dw; f.cv.ln_w = L.cln_w; f.cv.ln_b = L.cln_b; f.cv.rows = rows; f.cv.B = B; f.cv.T = TS; f.cv.ks = ks;
+            f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+            launch(f, "k_fused_dwconv_gemm", wbytes(D, D), 2.0 * M * D * D);
+        } else {
+            ConvParams cp;
+            memset(&cp, 0, sizeof(cp));
+            cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
+            cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = TS; cp.ks = ks;
+            cp.c_out = e->cbuf; cp.act_bf16 = 1;
+            { ProfScope ps(e, "k_dwconv", (double)M * D * 6 + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks); launch_dwconv(cp, st); }
+            memset(&f, 0, sizeof(f));
+            f.pro = PRO_PLAIN; f.g.A = e->cbuf; f.g.lda = D; f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4;
+            f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+            launch(f, "k_fused_plain_gemm", wbytes(D, D), 2.0 * M * D * D);
+        }
         // K7: x += conv ; LN_ff2 -> W1 -> SiLU
         memset(&f, 0, sizeof(f));
         f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = 4; f.scale = 1.0f;
@@ -815,8 +857,11 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T) {
 
 // enqueue one chunk step up to (and including) the joint's encoder projection: no host syncs, no
 // host state changes -- capturable into a hipGraph.  tap_slots != null only in debug mode.
-static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const int *tap_slots, int B, int T, int R) {
-    const int M = B * T;
+// G > 1: G consecutive chunks of every stream in one launch sequence (rows of a stream are (chunk, frame)-major;
+// vrows has one descriptor per (stream, chunk) for the subsampling stage).  Only the fused small-M path does this.
+static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, const int *tap_slots, int B, int T, int R, int G = 1) {
+    const int Bs = B * G;                      // subsampling batch: one entry per (stream, chunk)
+    const int M = Bs * T;
     const int chunk_mel = PRE_CACHE + 8 * (1 + R);
     hipStream_t st = e->st;
     const int act = e->bf16 ? 1 : 0;
@@ -824,24 +869,24 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const int *tap_s
     // ---- a-2 subsampling ------------------------------------------------------------------
     const int H1 = chunk_mel / 2 + 1, W1 = 65, H2 = H1 / 2 + 1, W2 = 33, H3 = H2 / 2 + 1, W3 = 17;
     {
-        ProfScope ps(e, "k_sub_conv0", (double)B * H1 * W1 * SUBC * 4, 2.0 * B * H1 * W1 * SUBC * 9);
-        launch_sub_conv0(rows, B, chunk_mel, e->mel_ring, e->w0t, e->b0, e->sub_a, H1, W1, st);
+        ProfScope ps(e, "k_sub_conv0", (double)Bs * H1 * W1 * SUBC * 4, 2.0 * Bs * H1 * W1 * SUBC * 9);
+        launch_sub_conv0(vrows, Bs, chunk_mel, e->mel_ring, e->w0t, e->b0, e->sub_a, H1, W1, st);
     }
     {
         ProfScope ps(e, "k_sub_dw", (double)B * H1 * W1 * SUBC * 4, 2.0 * B * H2 * W2 * SUBC * 9);
-        launch_sub_dw(e->sub_a, B, H1, W1, e->w2t, e->b2, e->sub_b, act, st);
+        launch_sub_dw(e->sub_a, Bs, H1, W1, e->w2t, e->b2, e->sub_b, act, st);
     }
     GemmParams g;
     memset(&g, 0, sizeof(g));
-    g.A = e->sub_b; g.W = e->w3; g.M = B * H2 * W2; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
+    g.A = e->sub_b; g.W = e->w3; g.M = Bs * H2 * W2; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
     g.epi = EPI_BIAS_RELU_F32; g.out_f32 = e->sub_a; g.ldo = SUBC; g.bias = e->b3;
     run_gemm(e, g, false, "sub_pw3");
     {
         ProfScope ps(e, "k_sub_dw", (double)B * H2 * W2 * SUBC * 4, 2.0 * B * H3 * W3 * SUBC * 9);
-        launch_sub_dw(e->sub_a, B, H2, W2, e->w5t, e->b5, e->sub_b, act, st);
+        launch_sub_dw(e->sub_a, Bs, H2, W2, e->w5t, e->b5, e->sub_b, act, st);
     }
     memset(&g, 0, sizeof(g));
-    g.A = e->sub_b; g.W = e->w6; g.M = B * H3 * W3; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
+    g.A = e->sub_b; g.W = e->w6; g.M = Bs * H3 * W3; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
     g.epi = EPI_BIAS_RELU_ACT; g.out_act = e->sub_a; g.ldo_act = SUBC; g.bias = e->b6;
     run_gemm(e, g, false, "sub_pw6");
     // out projection on the last T of the T+2 frames (drop 2: src/nemo-stream.cpp:154-162,:303)
@@ -861,8 +906,9 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const int *tap_s
     if (e->debug && tap_copy(e->tap_sub, (size_t)TMAX * D, 0)) return -1;
 
     const bool fused = e->bf16 && e->opt_fused && !e->debug && M <= 16;
+    if (G > 1 && !fused) return fail("internal: multi-chunk step needs the fused small-M path");
     if (fused) {
-        if (run_layers_fused(e, rows, B, T)) return -1;
+        if (run_layers_fused(e, rows, B, T, G)) return -1;
     } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
         PostParams pp;
@@ -1019,7 +1065,7 @@ static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, c
     const RowDesc *rows;
     if (stage_desc(e, rd, &rows)) return -1;
     hipStream_t st = e->st;
-    if (enqueue_encoder(e, rows, e->debug ? slots.data() : nullptr, B, T, R)) return -1;
+    if (enqueue_encoder(e, rows, rows, e->debug ? slots.data() : nullptr, B, T, R)) return -1;
     // ---- a-12..a-14 greedy decode, device resident -----------------------------------------------
     DecParams dp;
     make_dec_params(e, rows, B, T, dp);
@@ -1127,6 +1173,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     if (!e || !key) return fail("null argument");
     if (!strcmp(key, "fused")) e->opt_fused = value != 0;
     else if (!strcmp(key, "graph")) e->opt_graph = value != 0;
+    else if (!strcmp(key, "multichunk")) e->opt_multichunk = value != 0;
     else return fail("unknown option '%s'", key);
     return 0;
 }
@@ -1143,9 +1190,9 @@ extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
 // Eligible when every stream of the call receives one sub-push that completes exactly one chunk
 // (the normal streaming cadence: 1280*(1+R) samples per push).  The launch sequence is then fixed
 // for a given (B, T): descriptors live at fixed addresses and are refreshed by memcpy nodes.
-static int max_frames_per_push(int T) { return 8 * T + 2; }
+static int max_frames_per_push(int TS) { return 8 * TS + 2; }   // TS = frames of encoder output the push completes
 
-static int build_step_graph(nasr_engine *e, int B, int T, int R, hipGraphExec_t *out) {
+static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraphExec_t *out) {
     hipStream_t st = e->st;
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1154,17 +1201,18 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, hipGraphExec_t 
         HIPCHK(hipMemcpyAsync(e->g_pcm, e->gh_pcm, (size_t)B * sizeof(PcmDesc), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(e->g_rows, e->gh_rows, (size_t)B * sizeof(RowDesc), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(e->g_meta, e->gh_meta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, st));
+        if (G > 1) HIPCHK(hipMemcpyAsync(e->g_vrows, e->gh_vrows, (size_t)B * G * sizeof(RowDesc), hipMemcpyHostToDevice, st));
         MelParams mp;
         memset(&mp, 0, sizeof(mp));
-        mp.desc = e->g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+        mp.desc = e->g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
         mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
         launch_mel(mp, 0, st);
-        if (enqueue_encoder(e, e->g_rows, nullptr, B, T, R)) return -1;
+        if (enqueue_encoder(e, e->g_rows, G > 1 ? e->g_vrows : e->g_rows, nullptr, B, T, R, G)) return -1;
         DecParams dp;
-        make_dec_params(e, e->g_rows, B, T, dp);
+        make_dec_params(e, e->g_rows, B, T * G, dp);
         launch_decode_begin(dp, st);
         int it = 0;
-        enqueue_decode_iters(e, dp, B, T + 2, it);
+        enqueue_decode_iters(e, dp, B, T * G + 2, it);
         hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, st, e->g_meta, e->g_meta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE);
         HIPCHK(hipMemcpyAsync(e->gh_collect, e->collect_dev, (size_t)B * (1 + COLLECT_STRIDE) * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1185,22 +1233,32 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
                           const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     const int T = streams[0]->T, R = streams[0]->R;
     const int chunk_mel = PRE_CACHE + 8 * T, shift = 8 * T;
+    int G = -1;
     for (int b = 0; b < B; b++) {
         const nasr_stream *s = streams[b];
         const int n = n_samples[b];
         if (n <= 0 || n > MAX_PUSH) return 0;
         const int avail = s->abuf_cnt + n;
         const int nf = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
-        if (nf > max_frames_per_push(T)) return 0;
         const int mc = s->mel_count + nf;
-        if (mc < chunk_mel || mc >= chunk_mel + shift) return 0;   // exactly one chunk must become ready
+        if (mc < chunk_mel) return 0;
+        const int g = (mc - chunk_mel) / shift + 1;               // chunks this push completes
+        if (G < 0) G = g;
+        if (g != G) return 0;                                     // every stream must complete the same number
+        if (nf > max_frames_per_push(T * G)) return 0;
     }
-    const int key = B * 64 + T;
+    if (G > 1) {
+        // G consecutive chunks of a stream are one launch sequence (same results: a chunk's layer-l
+        // inputs do not depend on the previous chunk's layer-l outputs, only on its K/V and conv state).
+        // Needs the fused small-M path and the new rows to fit in the K/V ring next to the 70-row window.
+        if (!e->opt_multichunk || !e->bf16 || !e->opt_fused || B * G * T > 16 || G * T > KVC - LCTX) return 0;
+    }
+    const int key = (B * 64 + T) * 16 + G;
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         HIPCHK(hipStreamSynchronize(e->st));
         hipGraphExec_t ex = nullptr;
-        if (build_step_graph(e, B, T, R, &ex)) return -1;
+        if (build_step_graph(e, B, T, R, G, &ex)) return -1;
         it = e->graphs.emplace(key, ex).first;
     }
     for (int b = 0; b < B; b++) {
@@ -1212,7 +1270,12 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         d.n_frames = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
         d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
         d.consumed = d.n_frames * HOP;
-        fill_row_desc(e->gh_rows[b], s, T);
+        fill_row_desc(e->gh_rows[b], s, T * G);
+        for (int g = 0; g < G; g++) {
+            RowDesc &v = e->gh_vrows[b * G + g];
+            v = e->gh_rows[b];
+            v.mel_start = (s->mel_start + g * shift) & (MEL_RING - 1);
+        }
         e->gh_meta[b] = s->slot;
         e->gh_meta[B + b] = s->tok_read;
     }
@@ -1228,19 +1291,29 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
     }
     if (*e->gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
         DecParams dp;
-        make_dec_params(e, e->g_rows, B, T, dp);
-        int itn = T + 2;
+        make_dec_params(e, e->g_rows, B, T * G, dp);
+        int itn = T * G + 2;
         for (;;) {
             enqueue_decode_iters(e, dp, B, 2, itn);
             HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st));
             HIPCHK(hipStreamSynchronize(e->st));
             if (*e->gh_active == 0) break;
-            if (itn > T * MAX_SYMBOLS + 8) return fail("decode did not terminate");
+            if (itn > T * G * MAX_SYMBOLS + 8) return fail("decode did not terminate");
         }
-        for (int b = 0; b < B; b++) chunk_bookkeeping(streams[b], b);
+        for (int b = 0; b < B; b++) {
+            const int par = streams[b]->cc_par;
+            for (int g = 0; g < G; g++) chunk_bookkeeping(streams[b], b);
+            streams[b]->cc_par = par ^ 1;          // one launch = one conv-cache buffer flip, whatever G is
+            streams[b]->last_T = T * G; streams[b]->last_row = b;
+        }
         return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens) ? -1 : 1;
     }
-    for (int b = 0; b < B; b++) chunk_bookkeeping(streams[b], b);
+    for (int b = 0; b < B; b++) {
+        const int par = streams[b]->cc_par;
+        for (int g = 0; g < G; g++) chunk_bookkeeping(streams[b], b);
+        streams[b]->cc_par = par ^ 1;
+        streams[b]->last_T = T * G; streams[b]->last_row = b;
+    }
     return consume_collect(e, e->gh_collect, streams, B, tokens_out, tokens_cap, n_tokens) ? -1 : 1;
 }
 

@@ -108,6 +108,8 @@ struct GemmParams {
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
+void init_gemm_kernel_attributes();    // one-time hipFuncSetAttribute calls (never inside a stream capture)
+void init_fused_kernel_attributes();
 void launch_gemm_bf16(const GemmParams &p, hipStream_t st);
 void launch_gemm_f32(const GemmParams &p, hipStream_t st);
 void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st);
@@ -149,6 +151,7 @@ struct AttnParams {
     const void *posproj;  // [n_rel][1024] act dtype, row r <-> rel = (70+T-1) - r
     const float *bias_u, *bias_v;  // [8][128]
     const RowDesc *rows; int B; int T;
+    int TS;               // rows per stream in this launch = G*T when G chunks of a stream are batched (0: = T)
     void *ctx_out;        // [M][1024] act dtype
 };
 void launch_attention(const AttnParams &p, hipStream_t st);
