@@ -255,6 +255,35 @@ def test_multi_chunk_push_equals_chunk_by_chunk(W, R, B, k):
     eng.close()
 
 
+def test_single_huge_push_and_many_streams(eng32, om32, W):
+    """(i) 6 s of PCM in ONE call: more than the internal 17,920-sample sub-push, several chunks per sub-push;
+    (ii) 48 streams x R=13 in one launch (M = 672 rows) -- spot-check two streams against the oracle."""
+    pcm = synth.make_pcm(11, 6.0)
+    st, ost = eng32.stream(0), ob.OracleStream(om32, 0)
+    tg = eng32.step([st], [pcm])[0] + eng32.finalize([st])[0]
+    to = ost.process(pcm) + ost.finalize()
+    assert tg == to and st.stats().chunks == ost.total_chunks == 74
+    st.destroy()
+    B, R = 48, 13
+    eng = capi.Engine(W, n_layers=N_LAYERS, dtype=capi.DTYPE_F32, max_streams=B)
+    sts = [eng.stream(R) for _ in range(B)]
+    pcms = [synth.make_pcm(200 + b, 3.0) for b in range(B)]
+    toks = [[] for _ in range(B)]
+    for o in range(0, 48000, 17920):
+        out = eng.step(sts, [p[o:o + 17920] for p in pcms])
+        for b in range(B):
+            toks[b] += out[b]
+    out = eng.finalize(sts)
+    for b in (0, 31, 47):
+        os_ = ob.OracleStream(om32, R)
+        ref = []
+        for o in range(0, 48000, 17920):
+            ref += os_.process(pcms[b][o:o + 17920])
+        ref += os_.finalize()
+        assert toks[b] + out[b] == ref
+    eng.close()
+
+
 def test_pcm_end_to_end_tokens_f32(eng32, om32):
     """PCM in, tokens out, R=0, incl. the tail flush; token-for-token vs the oracle."""
     pcm = synth.make_pcm(2, 6.0)

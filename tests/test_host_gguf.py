@@ -1,6 +1,7 @@
 """Host side above the C ABI: the ggml-free GGUF v3 reader and the CLI.
 CPU tests cover the file format; the GPU test runs the CLI end to end."""
 import json
+import struct
 import subprocess
 from pathlib import Path
 
@@ -114,3 +115,103 @@ def test_cli_end_to_end(tmp_path):
         assert "Real-time factor" in r.stderr
     r = subprocess.run([str(cli), str(model), str(audio), "80", "5"], capture_output=True, text=True)
     assert r.returncode == 1 and "right_context" in r.stderr
+
+
+def _send(sock, op, sid, payload=b""):
+    sock.sendall(struct.pack("<BII", op, sid, len(payload)) + payload)
+
+
+def _recv(sock):
+    def full(n):
+        buf = b""
+        while len(buf) < n:
+            part = sock.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("server closed the connection")
+            buf += part
+        return buf
+    op, sid, n = struct.unpack("<BII", full(9))
+    return op, sid, full(n)
+
+
+@pytest.mark.gpu
+def test_server_batches_streams(tmp_path):
+    """Wire protocol of the reference server (src/server-protocol.h:24-41) served by the batch-forming worker:
+    3 streams on 2 connections (two right_context groups), text == oracle tokens -> text, errors are framed."""
+    import socket
+    import time
+    from oracle import binding as ob
+    n_layers = 2
+    W = synth.make_weights(n_layers=n_layers)
+    vocab = gguf_io.synthetic_vocab()
+    model = tmp_path / "model.gguf"
+    gguf_io.write_gguf(model, W, gguf_io.default_hparams(n_layers=n_layers), vocab)
+    srv = BIN / "nemo-server-amd"
+    assert srv.exists(), "run __graft_entry__.build()"
+    path = str(tmp_path / "asr.sock")
+    proc = subprocess.Popen([str(srv), str(model), "--unix", path, "--f32", "--max-streams", "8"], stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(600):
+            if Path(path).exists() or proc.poll() is not None:
+                break
+            time.sleep(0.1)
+        assert proc.poll() is None, proc.stderr.read()
+        conns = [socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) for _ in range(2)]
+        for c in conns:
+            c.settimeout(60)
+            c.connect(path)
+        plan = [(conns[0], 0, 3), (conns[0], 13, 4), (conns[1], 0, 5)]      # (connection, right_context, pcm seed)
+        ids, pcms, text = [], [], {}
+        for c, R, seed in plan:
+            _send(c, 0x01, 0, json.dumps({"lang": "auto", "right_context": R}).encode())
+            op, sid, payload = _recv(c)
+            assert op == 0x81 and json.loads(payload)["id"] == sid and sid not in ids
+            ids.append(sid)
+            pcms.append(synth.make_pcm(seed, 4.0))
+            text[sid] = ""
+        # interleave pushes of uneven sizes over all streams, then end them
+        step = [2000, 5120, 7777]
+        off = [0, 0, 0]
+        while any(off[i] < pcms[i].size for i in range(3)):
+            for i, (c, _, _) in enumerate(plan):
+                if off[i] < pcms[i].size:
+                    _send(c, 0x02, ids[i], pcms[i][off[i]:off[i] + step[i]].tobytes())
+                    off[i] += step[i]
+        for i, (c, _, _) in enumerate(plan):
+            _send(c, 0x03, ids[i])
+        ended = set()
+        for c in conns:
+            want = {ids[i] for i in range(3) if plan[i][0] is c}
+            while not want <= ended:
+                op, sid, payload = _recv(c)
+                assert op in (0x82, 0x83, 0x84), (hex(op), payload)
+                if op == 0x82:
+                    assert "queued_samples" in json.loads(payload)
+                else:
+                    text[sid] += payload.decode()
+                    if op == 0x84:
+                        ended.add(sid)
+        for i, (_, R, _) in enumerate(plan):
+            ost = ob.OracleStream(ob.OracleModel(W, n_layers), R)
+            ref = ost.process(pcms[i]) + ost.finalize()
+            want = "".join((" " + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t] for t in ref)
+            assert len(ref) > 0 and text[ids[i]] == want, (i, R)
+        # protocol errors come back as ERROR frames and the connection stays usable
+        _send(conns[1], 0x7E, 0)
+        op, _, payload = _recv(conns[1])
+        assert op == 0x8F and b"opcode" in payload
+        _send(conns[1], 0x01, 0, b"{}")
+        op, sid, _ = _recv(conns[1])
+        assert op == 0x81
+        _send(conns[1], 0x04, sid, b"xx-XX")
+        op, _, payload = _recv(conns[1])
+        assert op == 0x8F and b"language" in payload
+        for c in conns:
+            c.close()
+    finally:
+        proc.terminate()
+        try:
+            proc.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+    assert "streams per call" in proc.stderr.read()
