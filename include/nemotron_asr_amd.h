@@ -113,6 +113,10 @@ int nasr_stream_reset(nasr_stream *s);
 int nasr_stream_destroy(nasr_stream *s);
 int nasr_stream_set_prompt(nasr_stream *s, int prompt_index);
 int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out);
+/* timed_token.frame_idx (src/nemo-ggml.h:383-395; time = frame * 1280 / 16000 s): absolute encoder-frame
+ * index of tokens [first, first + count) of this stream, counted from create/reset.  Only the most recent
+ * 4096 tokens are kept on the device.  Returns the number written, < 0 on error. */
+int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first, int32_t count, int32_t *frames_out);
 
 /* ---- the step: replaces nemo_stream_process_incremental (src/nemo-stream.cpp:1145-1206)
  * for B streams at once = nemo_preprocessor_process (src/preprocessor.cpp:330-395) +

@@ -20,7 +20,7 @@ TAP_MEL, TAP_SUBSAMPLED, TAP_LAYER_OUT, TAP_ENCODER_OUT, TAP_K_CACHE, TAP_V_CACH
 EXPORTS = [
     "nasr_last_error", "nasr_abi_version", "nasr_engine_create", "nasr_engine_destroy",
     "nasr_stream_create", "nasr_stream_reset", "nasr_stream_destroy", "nasr_stream_set_prompt",
-    "nasr_stream_get_stats", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
+    "nasr_stream_get_stats", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize",
@@ -68,6 +68,7 @@ def lib():
             getattr(L, f"nasr_stream_{n}").argtypes = [vp]
         L.nasr_stream_set_prompt.argtypes = [vp, C.c_int]
         L.nasr_stream_get_stats.argtypes = [vp, C.POINTER(StreamStats)]
+        L.nasr_stream_get_token_frames.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
         L.nasr_engine_step.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
         L.nasr_engine_step_mel.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
         L.nasr_engine_finalize.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, ip]
@@ -133,6 +134,14 @@ class Stream:
         s = StreamStats()
         _chk(lib().nasr_stream_get_stats(self.h, C.byref(s)))
         return s
+
+    def token_frames(self, first=0, count=None) -> list:
+        """absolute encoder-frame index (x 80 ms) of tokens [first, first + count) since create/reset"""
+        if count is None:
+            count = max(int(self.stats().tokens) - first, 0)
+        out = np.zeros(max(count, 1), np.int32)
+        n = _chk(lib().nasr_stream_get_token_frames(self.h, first, count, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:n].tolist()
 
     def tap(self, which, index=0, cap=None) -> np.ndarray:
         cap = cap or 128 * 128

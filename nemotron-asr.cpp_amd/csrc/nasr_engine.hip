@@ -107,11 +107,12 @@ struct nasr_engine {
     bool opt_multichunk = true;
     char *gh = nullptr;                                                               // pinned host block
     RowDesc *gh_rows = nullptr; PcmDesc *gh_pcm = nullptr; int *gh_meta = nullptr, *gh_collect = nullptr, *gh_active = nullptr;
-    int64_t graph_replays = 0, eager_steps = 0;
+    int64_t graph_replays = 0, eager_steps = 0, decode_fallbacks = 0, decode_fallback_rounds = 0;
     void *a, *hbuf, *ctx, *cbuf, *sub_b;
-    float *jact;
+    float *predg;                    // [slot][640] cached joint.pred output of the LSTM candidate
     unsigned long long *key;
-    int *n_active;
+    int *n_active;                   // [3] = n_active, n_dirty, n_rows
+    int *dlist; unsigned *rowmap; int *tok_frame;
     int *collect_dev;                // [B][1+COLLECT_STRIDE]
     // descriptor staging
     char *pin = nullptr; size_t pin_cap = 0, pin_off = 0;
@@ -567,9 +568,12 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     const size_t sub_elems = S * 126 * 65 * SUBC;
     rc |= dalloc(e, &e->sub_a, sub_elems);
     { char *p; rc |= dalloc(e, &p, (S * 70 * 33 * SUBC) * 4); e->sub_b = p; }
-    rc |= dalloc(e, &e->jact, S * JNT);
-    rc |= dalloc(e, &e->key, 2 * S);
+    rc |= dalloc(e, &e->predg, S * JNT);
+    rc |= dalloc(e, &e->key, S * TMAX);
     rc |= dalloc(e, &e->n_active, 4);
+    rc |= dalloc(e, &e->dlist, S);
+    rc |= dalloc(e, &e->rowmap, S * TMAX);
+    rc |= dalloc(e, &e->tok_frame, S * TOK_CAP);
     rc |= dalloc(e, &e->collect_dev, S * (1 + COLLECT_STRIDE));
     if (rc) { nasr_engine_destroy(e); return -1; }
     e->pin_cap = 8u << 20;
@@ -600,6 +604,9 @@ extern "C" void nasr_engine_destroy(nasr_engine *e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->st) hipStreamSynchronize(e->st);
+    if (getenv("NASR_STATS"))
+        fprintf(stderr, "nasr: graph replays %lld, eager steps %lld, decode fallbacks %lld (%lld rounds)\n", (long long)e->graph_replays,
+                (long long)e->eager_steps, (long long)e->decode_fallbacks, (long long)e->decode_fallback_rounds);
     for (auto *s : e->slots) delete s;
     for (void *p : e->allocs) hipFree(p);
     for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
@@ -653,6 +660,7 @@ static int stream_zero_state(nasr_stream *s) {
     DecCtrl c;
     memset(&c, 0, sizeof(c));
     c.prev_token = BLANK;                      // src/nemo-stream.cpp:55-56
+    c.dirty = 1;                               // no LSTM candidate computed yet
     std::vector<DecCtrl> cv(1, c);
     const DecCtrl *dsrc;
     if (stage_desc(e, cv, &dsrc)) return -1;
@@ -1028,7 +1036,8 @@ static void make_dec_params(nasr_engine *e, const RowDesc *rows, int B, int T, D
     dp.embed = e->embed;
     for (int i = 0; i < 2; i++) { dp.w_ih[i] = e->w_ih[i]; dp.w_hh[i] = e->w_hh[i]; dp.b_ih[i] = e->b_ih[i]; dp.b_hh[i] = e->b_hh[i]; }
     dp.pred_w = e->pred_w; dp.pred_b = e->pred_b; dp.out_w = e->out_w; dp.out_b = e->out_b;
-    dp.jact = e->jact; dp.key = e->key; dp.n_active = e->n_active; dp.tok_ring = e->tok_ring;
+    dp.predg = e->predg; dp.key = e->key; dp.n_active = e->n_active; dp.n_dirty = e->n_active + 1; dp.n_rows = e->n_active + 2;
+    dp.dlist = e->dlist; dp.rowmap = e->rowmap; dp.tok_ring = e->tok_ring; dp.tok_frame = e->tok_frame;
 }
 
 static void enqueue_decode_iters(nasr_engine *e, const DecParams &dp, int B, int n, int &it) {
@@ -1072,15 +1081,15 @@ static int run_chunk(nasr_engine *e, const std::vector<nasr_stream *> &rows_s, c
     launch_decode_begin(dp, st);
     int max_dec = 0;
     for (int b = 0; b < B; b++) max_dec = std::max(max_dec, n_dec[b]);
-    int it = 0, budget = max_dec + 2;
+    int it = 0, budget = decode_blind_iterations(max_dec);
     int *h_active = (int *)e->pin;   // first 256 bytes of the pinned arena are reserved for this
     while (max_dec > 0) {
         enqueue_decode_iters(e, dp, B, budget, it);
         HIPCHK(hipMemcpyAsync(h_active, e->n_active, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (*h_active == 0) break;
-        if (it > max_dec * MAX_SYMBOLS + 4) return fail("decode did not terminate");
-        budget = 2;
+        if (it > max_dec * MAX_SYMBOLS + 64) return fail("decode did not terminate");
+        budget = std::min(2 * budget, 32);      // a burst (up to 10 symbols per frame): double the round, few syncs
     }
     for (int b = 0; b < B; b++) chunk_bookkeeping(rows_s[b], b);
     return 0;
@@ -1212,7 +1221,7 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraph
         make_dec_params(e, e->g_rows, B, T * G, dp);
         launch_decode_begin(dp, st);
         int it = 0;
-        enqueue_decode_iters(e, dp, B, T * G + 2, it);
+        enqueue_decode_iters(e, dp, B, decode_blind_iterations(T * G), it);
         hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, st, e->g_meta, e->g_meta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE);
         HIPCHK(hipMemcpyAsync(e->gh_collect, e->collect_dev, (size_t)B * (1 + COLLECT_STRIDE) * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1292,13 +1301,16 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
     if (*e->gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
         DecParams dp;
         make_dec_params(e, e->g_rows, B, T * G, dp);
-        int itn = T * G + 2;
+        int itn = decode_blind_iterations(T * G), round = 4;
+        e->decode_fallbacks++;
         for (;;) {
-            enqueue_decode_iters(e, dp, B, 2, itn);
+            e->decode_fallback_rounds++;
+            enqueue_decode_iters(e, dp, B, round, itn);
             HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st));
             HIPCHK(hipStreamSynchronize(e->st));
             if (*e->gh_active == 0) break;
-            if (itn > T * G * MAX_SYMBOLS + 8) return fail("decode did not terminate");
+            if (itn > T * G * MAX_SYMBOLS + 64) return fail("decode did not terminate");
+            round = std::min(2 * round, 32);
         }
         for (int b = 0; b < B; b++) {
             const int par = streams[b]->cc_par;
@@ -1504,6 +1516,23 @@ extern "C" int nasr_engine_collect(nasr_engine *e, nasr_stream *const *streams, 
     if (validate_batch(e, streams, B)) return -1;
     HIPCHK(hipSetDevice(e->device));
     return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+extern "C" int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first, int32_t count, int32_t *frames_out) {
+    if (!s || (count > 0 && !frames_out)) return fail("null argument");
+    if (first < 0 || count < 0) return fail("negative token range");
+    nasr_engine *e = s->e;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->st));
+    DecCtrl c;
+    HIPCHK(hipMemcpy(&c, e->ctrl + s->slot, sizeof(c), hipMemcpyDeviceToHost));
+    if (first + count > c.n_tok) count = first < c.n_tok ? (int32_t)(c.n_tok - first) : 0;
+    if (count > 0 && c.n_tok - first > TOK_CAP) return fail("token %lld is older than the %d-token device ring", (long long)first, TOK_CAP);
+    if (count <= 0) return 0;
+    std::vector<int> ring(TOK_CAP);
+    HIPCHK(hipMemcpy(ring.data(), e->tok_frame + (size_t)s->slot * TOK_CAP, TOK_CAP * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++) frames_out[i] = ring[(size_t)((first + i) & (TOK_CAP - 1))];
+    return count;
 }
 
 extern "C" int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out) {

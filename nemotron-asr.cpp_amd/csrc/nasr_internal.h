@@ -72,7 +72,9 @@ struct DecCtrl {          // per-slot decoder control block (device resident)
     int active;
     int iterations;       // total LSTM+joint evaluations (stat)
     int row;              // batch row of this slot in the current step
-    int pad[3];
+    int dirty;            // the uncommitted LSTM candidate / joint.pred vector is stale (committed state changed)
+    int frame0;           // absolute encoder-frame index of frame 0 of the current step (token timestamps)
+    int frame_next;       // absolute index of the first frame of the next step
 };
 
 // ---- epilogues of the GEMM kernels ------------------------------------------------------
@@ -174,13 +176,19 @@ struct DecParams {
     const float *embed;          // [1025][640]
     const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
     const float *pred_w, *pred_b, *out_w, *out_b;
-    float *jact;                 // [B][640]
-    unsigned long long *key;     // [2][B] packed argmax keys
-    int *n_active;               // device counter
+    float *predg;                // [slot][640]  joint.pred(h1') + b_pred of the current LSTM candidate
+    unsigned long long *key;     // [B * T] packed argmax keys, one per (row, frame)
+    int *n_active;               // device counters: streams with frames left,
+    int *n_dirty;                //   entries of dlist,
+    int *n_rows;                 //   entries of rowmap
+    int *dlist;                  // [B] batch rows whose LSTM candidate must be recomputed
+    unsigned *rowmap;            // [B * T] (frame << 16 | batch row) of every frame still to decode
     int *tok_ring;               // [slot][TOK_CAP]
+    int *tok_frame;              // [slot][TOK_CAP] absolute encoder frame of each token
 };
 void launch_decode_begin(const DecParams &p, hipStream_t st);
 void launch_decode_iter(const DecParams &p, int iter, hipStream_t st);
+int decode_blind_iterations(int frames);
 void launch_encproj(const float *x, const float *wpk, const float *bias, float *out, int M, int K, int N, hipStream_t st);
 
 // ---- fused small-M kernels (M <= 16): prologue + weight-streaming GEMM + epilogue in one launch ----

@@ -33,7 +33,13 @@ HIDDEN = 640
 JOINT = 640
 LEFT_CTX = 70
 PRE_CACHE = 9
-PRED_GAIN = 16.0
+# synthetic decoder (see _make): token-specific refractory suppression through the prediction network
+EMBED_GAIN = 7.0      # embed[v] = EMBED_GAIN * joint_out[v]
+DEC_NOISE = 0.25      # amplitude of the dense random part of the LSTM / joint.pred matrices (x sqrt(3/fan_in))
+SUPPRESS = 0.6        # joint.pred = -SUPPRESS * I + noise
+GATE_OPEN = 3.0       # bias of the input / output gates
+BLANK_GAIN = 4.5      # at 24 layers; shallow test models use BLANK_GAIN_SHALLOW (see default_blank_gain)
+BLANK_GAIN_SHALLOW = 5.0
 SAMPLE_RATE = 16000
 
 _GOLDEN = np.uint64(0x9E3779B97F4A7C15)
@@ -141,10 +147,10 @@ def global_tensor_specs(num_prompts: int = 0):
     ]
     for l in (0, 1):
         p = "decoder.prediction.dec_rnn.lstm."
-        specs += [(p + f"weight_ih_l{l}", (4 * HIDDEN, HIDDEN), "mat", HIDDEN),
-                  (p + f"weight_hh_l{l}", (4 * HIDDEN, HIDDEN), "mat", HIDDEN),
-                  (p + f"bias_ih_l{l}", (4 * HIDDEN,), "bias", 0),
-                  (p + f"bias_hh_l{l}", (4 * HIDDEN,), "bias", 0)]
+        specs += [(p + f"weight_ih_l{l}", (4 * HIDDEN, HIDDEN), "lstm_ih", HIDDEN),
+                  (p + f"weight_hh_l{l}", (4 * HIDDEN, HIDDEN), "lstm_hh", HIDDEN),
+                  (p + f"bias_ih_l{l}", (4 * HIDDEN,), "lstm_bias", 0),
+                  (p + f"bias_hh_l{l}", (4 * HIDDEN,), "lstm_bias", 0)]
     specs += [
         ("joint.enc.weight", (JOINT, D_MODEL), "mat", D_MODEL), ("joint.enc.bias", (JOINT,), "bias", 0),
         ("joint.pred.weight", (JOINT, HIDDEN), "jpred", HIDDEN), ("joint.pred.bias", (JOINT,), "bias", 0),
@@ -160,11 +166,15 @@ def global_tensor_specs(num_prompts: int = 0):
     return specs
 
 
+def _jout_random(seed):
+    return _tensor(seed, "joint.joint_net.2.weight", (VOCAB, JOINT), float(np.sqrt(3.0 / JOINT)))
+
+
 def _make(seed, name, shape, kind, fan_in, blank_bias):
     if kind == "mat":
         return _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)))
     if kind == "embed":
-        w = _tensor(seed, name, shape, float(np.sqrt(3.0)))
+        w = (EMBED_GAIN * _jout_random(seed)).astype(np.float32)
         w[BLANK] = 0.0  # padding row (nn.Embedding padding_idx = blank)
         return w
     if kind == "ln_w":
@@ -173,28 +183,64 @@ def _make(seed, name, shape, kind, fan_in, blank_bias):
         return _tensor(seed, name, shape, 0.05)
     if kind == "posbias":
         return _tensor(seed, name, shape, 0.3)
+    # ---- decoder: a hand-built stand-in for a TRAINED prediction network ---------------------------------
+    # With fully random weights the greedy loop has no refractory behaviour: a frame whose best token
+    # beats blank keeps beating it after the emission, so streams either stay silent or emit the
+    # 10-symbol cap on every frame (measured: tests/micro/burst_stats.py), and a saturated random LSTM
+    # is chaotic, which would turn token-for-token parity into a coin toss.  The structure below keeps
+    # every matrix dense (a random part of amplitude DEC_NOISE rides on all of them, so the GEMM
+    # arithmetic is exercised in full) but gives the recurrent path a meaning:
+    #   embed[v]            = EMBED_GAIN * joint_out[v]          (the token's own output row)
+    #   LSTM layer          : g-gate = identity on its input, input/output gates open (bias GATE_OPEN),
+    #                         forget gate 0.5  ->  c' = 0.5 c + 0.95 tanh(x): a leaky sum of the last tokens' rows
+    #   joint.pred          = -SUPPRESS * I                      ->  g = -SUPPRESS * h1'
+    # so after emitting v the joint input is pushed against joint_out[v] (and, at half strength each, against
+    # the tokens before it): v's logit drops by ~2 sigma, blank usually wins the next evaluation, and the same
+    # token is not re-emitted on the following, similar frames.  The dynamics are contractive (forget 0.5).
+    if kind in ("lstm_ih", "lstm_hh"):
+        w = _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)) * DEC_NOISE)
+        if kind == "lstm_ih":
+            w[2 * HIDDEN:3 * HIDDEN] += np.eye(HIDDEN, dtype=np.float32)          # gate order i, f, g, o
+        return w
+    if kind == "lstm_bias":
+        b = _tensor(seed, name, shape, 0.05)
+        if name.endswith(("bias_ih_l0", "bias_ih_l1")):
+            b[0:HIDDEN] += np.float32(GATE_OPEN)
+            b[3 * HIDDEN:4 * HIDDEN] += np.float32(GATE_OPEN)
+        return b
     if kind == "jpred":
-        # The 2-layer LSTM output of a random network is small (rms ~0.06); a gain of 16 makes the
-        # prediction-network term as large as the encoder term, so an emission re-randomises the
-        # next decision (otherwise a frame that emits once emits the 10-symbol cap every time).
-        return _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)) * PRED_GAIN)
+        w = _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)) * DEC_NOISE)
+        w -= np.float32(SUPPRESS) * np.eye(JOINT, HIDDEN, dtype=np.float32)
+        return w
     if kind == "jout":
-        # Random joint weights give ~N(0, s^2) logits over 1024 tokens whose maximum scales with the
-        # activation level s.  A trained model emits blank on most frames: the blank row is a
-        # constant g/640, i.e. blank logit = g * mean(relu(.)), which scales with s too, so the
-        # blank/non-blank balance does not drift with the decoder state.  g = blank_gain = 5.5
-        # gives ~0.1-0.4 tokens per 80 ms frame with 0-10 symbols per emitting frame (measured).
-        w = _tensor(seed, name, shape, float(np.sqrt(3.0 / fan_in)))
+        # ~N(0, s^2) logits over 1024 tokens whose maximum scales with the activation level s; the blank row
+        # is a constant g/640, i.e. blank logit = g * mean(relu(.)), which scales with s too, so the
+        # blank/non-blank balance does not drift with the decoder state.  Measured on 64 streams x 39 s, R = 13
+        # (tests/micro/burst_stats.py): g = BLANK_GAIN = 4.5 with SUPPRESS 0.6 -> 0.047 tokens per 80 ms frame,
+        # the busiest of 64 streams emits 4.7 tokens per 1.12 s step on average and 18 at most; g = 4.4 -> 0.08
+        # tokens/frame with a few 30-token steps; SUPPRESS = 0 -> 6 tokens/frame (the 10-symbol cap on most frames).
+        w = _jout_random(seed)
         w[BLANK, :] = np.float32(blank_bias / fan_in)
         return w
     raise ValueError(kind)
 
 
+def default_blank_gain(n_layers: int) -> float:
+    """The emission rate of the synthetic joint depends on the statistics of the (random) encoder's output,
+    which differ between the 1-4 layer models of the tests and the 24-layer model (measured with the CPU oracle
+    and tests/micro/burst_stats.py): 4.5 gives ~0.05 tokens/frame at 24 layers but the 10-symbol cap on most frames
+    at 1-4 layers, where 5.0 gives 0.1-0.7 tokens/frame."""
+    return BLANK_GAIN if n_layers > 8 else BLANK_GAIN_SHALLOW
+
+
 def make_weights(n_layers: int = 24, seed: int = 0xC0FFEE, kernel_size: int = 9,
-                 num_prompts: int = 0, blank_bias: float = 5.5, layers=None) -> dict:
+                 num_prompts: int = 0, blank_bias: float = None, layers=None) -> dict:
     """name -> float32 ndarray for the whole model (2.4 GB at 24 layers).
 
-    `layers`: optional iterable of layer indices to materialise (default: all)."""
+    `layers`: optional iterable of layer indices to materialise (default: all).
+    `blank_bias`: blank gain of the synthetic joint (default: default_blank_gain(n_layers))."""
+    if blank_bias is None:
+        blank_bias = default_blank_gain(n_layers)
     w = {
         "preprocessor.featurizer.fb": mel_filterbank(),
         "preprocessor.featurizer.window": hann_window(),

@@ -78,6 +78,7 @@ def lib():
         L.orc_stream_process.argtypes = [C.c_void_p, C.POINTER(C.c_int16), C.c_int, _ip, C.c_int]
         L.orc_stream_finalize.argtypes = [C.c_void_p, _ip, C.c_int]
         L.orc_stream_set_taps.argtypes = [C.c_void_p, _fp, _fp]
+        L.orc_stream_token_frames.argtypes = [C.c_void_p, _ip, C.c_int]
         L.orc_stream_get_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp]
         L.orc_stream_get_decoder_state.argtypes = [C.c_void_p, _fp, _fp, _ip]
         L.orc_round_bf16.restype = C.c_float
@@ -217,6 +218,13 @@ class OracleStream:
     @property
     def decode_iterations(self):
         return lib().orc_stream_decode_iterations(self.h)
+
+    def token_frames(self) -> list:
+        """absolute encoder-frame index (x 80 ms) of every token since create/reset"""
+        n = lib().orc_stream_token_frames(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.int32)
+        lib().orc_stream_token_frames(self.h, out.ctypes.data_as(_ip), n)
+        return out[:n].tolist()
 
     def get_cache(self, which: int, layer: int) -> np.ndarray:
         rows = 70 if which < 2 else self.model.kernel_size - 1

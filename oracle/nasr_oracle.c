@@ -516,6 +516,8 @@ struct orc_stream {
     float *mel_buf; /* [frames][128], starts with 9 zero frames :73-74 */
     int n_mel, cap_mel;
     int total_chunks, decode_iterations;
+    int frames_total;       /* encoder frames decoded so far: timed_token.frame_idx (src/nemo-ggml.h:383-395) */
+    int *tok_frames; int n_tok_frames, cap_tok_frames;
     float *tap_sub, *tap_layers;
 };
 
@@ -550,6 +552,8 @@ void orc_stream_reset(orc_stream *s) {
     memset(s->mel_buf, 0, sizeof(float) * (size_t)ORC_PRE_CACHE * ORC_N_MELS);
     s->total_chunks = 0;
     s->decode_iterations = 0;
+    s->frames_total = 0;
+    s->n_tok_frames = 0;
     if (s->pp) orc_preproc_reset(s->pp);
 }
 
@@ -578,7 +582,7 @@ orc_stream *orc_stream_create(const orc_model *m, int right_context, int prompt_
 
 void orc_stream_free(orc_stream *s) {
     if (!s) return;
-    free(s->kcache); free(s->vcache); free(s->convcache); free(s->posproj); free(s->mel_buf);
+    free(s->kcache); free(s->vcache); free(s->convcache); free(s->posproj); free(s->mel_buf); free(s->tok_frames);
     orc_preproc_free(s->pp);
     free(s);
 }
@@ -588,6 +592,10 @@ int orc_stream_chunk_len(const orc_stream *s) { return s->T; }
 int orc_stream_cache_valid_len(const orc_stream *s) { return s->cache_valid_len; }
 int orc_stream_total_chunks(const orc_stream *s) { return s->total_chunks; }
 int orc_stream_decode_iterations(const orc_stream *s) { return s->decode_iterations; }
+int orc_stream_token_frames(const orc_stream *s, int *out, int cap) {
+    for (int i = 0; i < s->n_tok_frames && i < cap; i++) out[i] = s->tok_frames[i];
+    return s->n_tok_frames;
+}
 void orc_stream_set_taps(orc_stream *s, float *sub_out, float *layer_out) {
     s->tap_sub = sub_out;
     s->tap_layers = layer_out;
@@ -840,11 +848,17 @@ int orc_stream_decode(orc_stream *s, const float *enc, int n_frames, int *tokens
             if (best == ORC_BLANK) break;                          /* state untouched :908-911 */
             if (n_tok < cap) tokens_out[n_tok] = best;
             n_tok++;
+            if (s->n_tok_frames == s->cap_tok_frames) {
+                s->cap_tok_frames = s->cap_tok_frames ? 2 * s->cap_tok_frames : 256;
+                s->tok_frames = (int *)realloc(s->tok_frames, sizeof(int) * (size_t)s->cap_tok_frames);
+            }
+            s->tok_frames[s->n_tok_frames++] = s->frames_total + t;
             s->prev_token = best;                                  /* :921-926 */
             memcpy(s->h, hn, sizeof(hn));
             memcpy(s->c, cn, sizeof(cn));
         }
     }
+    s->frames_total += n_frames;
     return n_tok;
 }
 

@@ -301,6 +301,8 @@ def test_pcm_end_to_end_tokens_f32(eng32, om32):
         assert s.chunks == ost.total_chunks
         assert s.decode_iterations == ost.decode_iterations
         assert tg == to
+        assert st.token_frames() == ost.token_frames()     # timed_token.frame_idx (src/nemo-ggml.h:383-395)
+        assert st.token_frames(2, 3) == ost.token_frames()[2:5]
         n_tok += len(tg)
         h, c, p = ost.decoder_state()
         ds = st.tap(capi.TAP_DEC_STATE)
@@ -308,6 +310,34 @@ def test_pcm_end_to_end_tokens_f32(eng32, om32):
         assert np.abs(ds[:1280] - h).max() < 1e-4 and np.abs(ds[1280:2560] - c).max() < 1e-4
         st.destroy()
     assert n_tok > 10      # the comparison above is not vacuous
+
+
+def test_decode_many_rows_tokens_f32(W, om32):
+    """6 streams x 14 frames = 84 (stream, frame) rows per step: the tiled joint kernel and the multi-tile
+    LSTM passes; tokens, frames, iteration count and committed state equal the oracle's sequential loop."""
+    R, B = 13, 6
+    eng = capi.Engine(W, n_layers=N_LAYERS, dtype=capi.DTYPE_F32, max_streams=B)
+    sts = [eng.stream(R) for _ in range(B)]
+    pcms = [synth.make_pcm(40 + b, 5.0) for b in range(B)]
+    got = [[] for _ in range(B)]
+    for o in range(0, pcms[0].size, 17920):
+        for b, t in enumerate(eng.step(sts, [p[o:o + 17920] for p in pcms])):
+            got[b] += t
+    for b, t in enumerate(eng.finalize(sts)):
+        got[b] += t
+    total = 0
+    for b in (0, 3, 5):
+        ost = ob.OracleStream(om32, R)
+        ref = ost.process(pcms[b]) + ost.finalize()
+        assert got[b] == ref, b
+        assert sts[b].token_frames() == ost.token_frames()
+        assert sts[b].stats().decode_iterations == ost.decode_iterations
+        h, c, p = ost.decoder_state()
+        ds = sts[b].tap(capi.TAP_DEC_STATE)
+        assert int(ds[-1]) == p and np.abs(ds[:1280] - h).max() < 1e-4 and np.abs(ds[1280:2560] - c).max() < 1e-4
+        total += len(ref)
+    assert total > 10
+    eng.close()
 
 
 def test_batch_equals_single_stream(eng32):

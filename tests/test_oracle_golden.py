@@ -68,8 +68,10 @@ def test_decoder_joint(golden, model):
     for i, t in enumerate(gi.DEC_TOKENS):
         logits, h, c = model.decoder_joint(t, h, c, enc[i])
         assert np.abs(logits - golden["dec_logits"][i]).max() < 1e-4   # :2514, :2644
-    assert np.abs(h - golden["dec_h"]).max() < 1e-5
-    assert np.abs(c - golden["dec_c"]).max() < 1e-5
+    # saturated synthetic LSTM (synth.LSTM_GAIN = 8): |c| reaches ~2.5, pre-activations ~N(0, 8^2); the two
+    # implementations sum in different orders
+    assert np.abs(h - golden["dec_h"]).max() < 1e-4
+    assert np.abs(c - golden["dec_c"]).max() < 1e-4
 
 
 def test_greedy_tokens_exact(golden, model):
