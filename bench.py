@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--right-context", type=int, default=0, choices=[0, 1, 6, 13])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--chunks-per-step", type=int, default=1,
+                    help="audio pushed per step, in chunks: > 1 = buffered / file transcription (several chunks of a stream "
+                         "go through the layers as one launch sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.2, help="audio seconds of the CPU-baseline sample")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -88,7 +91,7 @@ def main():
 
     B, R = args.batch, args.right_context
     T = 1 + R
-    n_step = synth.shift_samples(R)
+    n_step = synth.shift_samples(R) * args.chunks_per_step
     total_steps = args.warmup + args.steps
     audio_per_step = B * n_step / synth.SAMPLE_RATE
 
@@ -107,7 +110,7 @@ def main():
 
     L = capi.lib()
     handles = (C.c_void_p * B)(*[s.h for s in streams])
-    tok_cap = 16 * T
+    tok_cap = 16 * T * args.chunks_per_step
     tok_bufs = [np.zeros(tok_cap, np.int32) for _ in range(B)]
     tptrs = (C.c_void_p * B)(*[b.ctypes.data for b in tok_bufs])
     caps = (C.c_int32 * B)(*([tok_cap] * B))
@@ -160,7 +163,7 @@ def main():
                                 unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
                                 avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps)
             else:
-                traffic = pmc_traffic(dom["name"], B, R, args.dtype, args.layers)
+                traffic = pmc_traffic(dom["name"], B * args.chunks_per_step, R, args.dtype, args.layers)
                 ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
                 roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                                 unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
@@ -204,7 +207,8 @@ def main():
             "config": {
                 "workload": f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}, batch={B} stream(s)/GPU, "
                             f"{80 * T} ms lookahead (R={R}), {world}xMI355X"
-                            + (" [BASELINE.json configs[1]]" if (B, R, args.dtype, args.layers) == (1, 0, "bf16", 24) else ""),
+                            + (f", {args.chunks_per_step} chunks pushed per step" if args.chunks_per_step > 1 else "")
+                            + (" [BASELINE.json configs[1]]" if (B, R, args.dtype, args.layers, args.chunks_per_step) == (1, 0, "bf16", 24, 1) else ""),
                 "streams_per_gpu": B, "right_context": R, "audio_s_per_step_per_gpu": audio_per_step,
                 "parallelism": f"stream-sharded x{world}, no collectives",
                 "pcm": "device-resident", "tokens_emitted": tokens_timed, "chunks": chunks_timed,

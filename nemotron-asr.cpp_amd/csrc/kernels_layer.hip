@@ -102,65 +102,67 @@ __device__ __forceinline__ float dot128(const float *qs, const void *row) {
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
-    // TS rows of this stream = G chunks x T frames (G = 1 unless a multi-chunk step): row il = (chunk g, frame i)
-    // attends the 70 + T keys starting g*T rows into the ring.
+    // One workgroup per (head, stream, chunk).  A launch carries TS = G * T rows per stream (G chunks of T frames,
+    // G = 1 unless a multi-chunk step): the T rows of chunk g attend the 70 + T keys that start g*T rows into the
+    // ring, with the cache validity that chunk would have seen (valid_len + g*T).
     __shared__ float qu[TMAX][DH], qv[TMAX][DH];
     __shared__ float sc[TMAX][KVC];
-    const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, TS = p.TS > 0 ? p.TS : p.T;
+    const int h = blockIdx.x, b = blockIdx.y, g = blockIdx.z, T = p.T, KV = LCTX + T, TS = p.TS > 0 ? p.TS : p.T;
     const RowDesc rd = p.rows[b];
     const int esz = BF16 ? 2 : 4;
     const char *kbase = (const char *)p.kv_pool + ((size_t)rd.slot * p.kv_slot_stride) * esz;
     const char *vbase = kbase + (size_t)KVC * D * esz;
-    for (int e = threadIdx.x; e < TS * DH; e += 256) {
-        const int il = e >> 7, d = e & 127;
-        const float q = p.q[((size_t)b * TS + il) * D + h * DH + d];
-        qu[il][d] = q + p.bias_u[h * DH + d];     // src/nemo-stream.cpp:531-535
-        qv[il][d] = q + p.bias_v[h * DH + d];
+    const size_t row0 = (size_t)b * TS + (size_t)g * T;
+    int head0 = rd.kv_head + g * T;
+    while (head0 >= KVC) head0 -= KVC;
+    for (int e = threadIdx.x; e < T * DH; e += 256) {
+        const int i = e >> 7, d = e & 127;
+        const float q = p.q[(row0 + i) * D + h * DH + d];
+        qu[i][d] = q + p.bias_u[h * DH + d];     // src/nemo-stream.cpp:531-535
+        qv[i][d] = q + p.bias_v[h * DH + d];
     }
     __syncthreads();
     const float scale = 0.08838834764831845f;    // 1/sqrt(128), :545
-    for (int e = threadIdx.x; e < TS * KV; e += 256) {
-        const int il = e / KV, j = e - il * KV, g = il / T, i = il - g * T;
-        int ring = rd.kv_head + g * T + j;
-        if (ring >= KVC) ring -= KVC;
+    const int valid = rd.valid_len + g * T < LCTX ? rd.valid_len + g * T : LCTX;
+    for (int e = threadIdx.x; e < T * KV; e += 256) {
+        const int i = e / KV, j = e - i * KV;
+        int ring = head0 + j;
         if (ring >= KVC) ring -= KVC;
         const char *krow = kbase + ((size_t)ring * D + h * DH) * esz;
         // rel-shift folded into indexing: slice row j + T - 1 - i  <->  rel = (70 + i) - j  (:419-461)
         const char *prow = (const char *)p.posproj + ((size_t)(j + T - 1 - i) * D + h * DH) * esz;
-        const float s1 = dot128<BF16>(qu[il], krow);   // :538
-        const float s2 = dot128<BF16>(qv[il], prow);   // :541-542
+        const float s1 = dot128<BF16>(qu[i], krow);   // :538
+        const float s2 = dot128<BF16>(qv[i], prow);   // :541-542
         float v = (s1 + s2) * scale;                   // :546-547
-        const int valid = rd.valid_len + g * T < LCTX ? rd.valid_len + g * T : LCTX;
         if (j < LCTX - valid) v += -1e9f;              // :552-556, :1037-1043
-        sc[il][j] = v;
+        sc[i][j] = v;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int il = wave; il < TS; il += 4) {           // softmax, :559
-        float v0 = lane < KV ? sc[il][lane] : -INFINITY;
-        float v1 = lane + 64 < KV ? sc[il][lane + 64] : -INFINITY;
+    for (int i = wave; i < T; i += 4) {               // softmax, :559
+        float v0 = lane < KV ? sc[i][lane] : -INFINITY;
+        float v1 = lane + 64 < KV ? sc[i][lane + 64] : -INFINITY;
         const float mx = wave_max(fmaxf(v0, v1));
         const float e0 = lane < KV ? __expf(v0 - mx) : 0.0f;
         const float e1 = lane + 64 < KV ? __expf(v1 - mx) : 0.0f;
         const float inv = 1.0f / wave_sum(e0 + e1);
-        if (lane < KV) sc[il][lane] = e0 * inv;
-        if (lane + 64 < KV) sc[il][lane + 64] = e1 * inv;
+        if (lane < KV) sc[i][lane] = e0 * inv;
+        if (lane + 64 < KV) sc[i][lane + 64] = e1 * inv;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < TS * DH; e += 256) { // context = P.V, :563
-        const int il = e >> 7, d = e & 127, g = il / T;
+    for (int e = threadIdx.x; e < T * DH; e += 256) { // context = P.V, :563
+        const int i = e >> 7, d = e & 127;
         float acc = 0.0f;
-        int ring = rd.kv_head + g * T;
-        if (ring >= KVC) ring -= KVC;
+        int ring = head0;
 #pragma unroll 4
         for (int j = 0; j < KV; j++) {
             float vv;
             if (BF16) vv = bf16_to_f32(((const bf16_t *)vbase)[(size_t)ring * D + h * DH + d]);
             else vv = ((const float *)vbase)[(size_t)ring * D + h * DH + d];
-            acc += sc[il][j] * vv;
+            acc += sc[i][j] * vv;
             if (++ring == KVC) ring = 0;
         }
-        const size_t o = ((size_t)b * TS + il) * D + h * DH + d;
+        const size_t o = (row0 + i) * D + h * DH + d;
         if (BF16) ((bf16_t *)p.ctx_out)[o] = f32_to_bf16(acc);
         else ((float *)p.ctx_out)[o] = acc;
     }
@@ -178,8 +180,12 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char qu_s[16 * 256], qv_s[16 * 256], w_s[16 * 256];
     __shared__ __attribute__((aligned(16))) char vt_s[128 * 256];
     __shared__ float sk[16 * 96], sp[16 * 112];
-    const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
+    const int h = blockIdx.x, b = blockIdx.y, g = blockIdx.z, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
+    const int TS = p.TS > 0 ? p.TS : p.T;
     const RowDesc rd = p.rows[b];
+    const size_t row0 = (size_t)b * TS + (size_t)g * T;      // chunk g of a multi-chunk step (see k_attention)
+    int head0 = rd.kv_head + g * T;
+    while (head0 >= KVC) head0 -= KVC;
     const bf16_t *kbase = (const bf16_t *)p.kv_pool + (size_t)rd.slot * p.kv_slot_stride + h * DH;
     const bf16_t *vbase = kbase + (size_t)KVC * D;
     const bf16_t *pbase = (const bf16_t *)p.posproj + h * DH;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     // ---- phase 0: queries (+u, +v) -> bf16 LDS; V tile -> transposed LDS (zero padded to 96 keys) ----
     for (int e = threadIdx.x; e < 16 * DH; e += 256) {
         const int i = e >> 7, d = e & 127;
-        const float qq = i < T ? p.q[((size_t)b * T + i) * D + h * DH + d] : 0.0f;
+        const float qq = i < T ? p.q[(row0 + i) * D + h * DH + d] : 0.0f;
         const int off = i * 256 + ((((d >> 3) ^ i) & 15) << 4) + (d & 7) * 2;
         *(bf16_t *)(qu_s + off) = f32_to_bf16(qq + p.bias_u[h * DH + d]);
         *(bf16_t *)(qv_s + off) = f32_to_bf16(qq + p.bias_v[h * DH + d]);
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         const int c = e & 15, j = e >> 4;               // 8 consecutive d of key j
         uint4 v = make_uint4(0, 0, 0, 0);
         if (j < KV) {
-            int ring = rd.kv_head + j;
+            int ring = head0 + j;
             if (ring >= KVC) ring -= KVC;
             v = *(const uint4 *)(vbase + (size_t)ring * D + c * 8);
         }
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         if (isk) {
             int j = t * 16 + r;
             if (j >= KV) j = KV - 1;
-            int ring = rd.kv_head + j;
+            int ring = head0 + j;
             if (ring >= KVC) ring -= KVC;
             arow = kbase + (size_t)ring * D;
         } else {
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     __syncthreads();
     // ---- phase 2: rel-shift gather + mask + softmax -> bf16 weights (zero padded to 128 keys) ---------
     const float scale = 0.08838834764831845f;
-    const int mask_upto = LCTX - rd.valid_len;
+    const int mask_upto = LCTX - (rd.valid_len + g * T < LCTX ? rd.valid_len + g * T : LCTX);
     for (int i = wave; i < 16; i += 4) {
         float v0 = -INFINITY, v1 = -INFINITY;
         if (i < T) {
@@ -272,15 +278,17 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
             uint2 o;
             o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
             o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
-            *(uint2 *)((bf16_t *)p.ctx_out + ((size_t)b * T + r) * D + h * DH + dt * 16 + q * 4) = o;
+            *(uint2 *)((bf16_t *)p.ctx_out + (row0 + r) * D + h * DH + dt * 16 + q * 4) = o;
         }
     }
 }
 
 void launch_attention(const AttnParams &p, hipStream_t st) {
-    if (p.act_bf16 && p.T >= 4 && p.T <= 16 && (p.TS == 0 || p.TS == p.T)) hipLaunchKernelGGL(k_attention_mfma, dim3(NH, p.B), dim3(256), 0, st, p);
-    else if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, dim3(NH, p.B), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_attention<false>, dim3(NH, p.B), dim3(256), 0, st, p);
+    const int G = p.TS > 0 ? p.TS / p.T : 1;
+    const dim3 grid(NH, p.B, G);
+    if (p.act_bf16 && p.T >= 4 && p.T <= 16) hipLaunchKernelGGL(k_attention_mfma, grid, dim3(256), 0, st, p);
+    else if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_attention<false>, grid, dim3(256), 0, st, p);
 }
 
 // ---- depthwise conv + LN + SiLU: one workgroup per (frame, stream) ------------------------------

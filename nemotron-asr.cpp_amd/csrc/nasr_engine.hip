@@ -913,8 +913,13 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     };
     if (e->debug && tap_copy(e->tap_sub, (size_t)TMAX * D, 0)) return -1;
 
-    const bool fused = e->bf16 && e->opt_fused && !e->debug && M <= 16;
-    if (G > 1 && !fused) return fail("internal: multi-chunk step needs the fused small-M path");
+    // Up to 4 rows the 8-launch fused layer wins; above, its per-workgroup prologues (every workgroup redoes the
+    // LayerNorm of all rows) cost more than the 6 extra launches of the unfused layer (measured at R = 0:
+    // 8 rows 2.13 vs 1.89 ms, 16 rows 2.78 vs 1.96 ms per step).
+    static const int fused_rows = getenv("NASR_FUSED_ROWS") ? atoi(getenv("NASR_FUSED_ROWS")) : 4;
+    const bool fused = e->bf16 && e->opt_fused && !e->debug && M <= fused_rows;
+    const int TS = G * T;                      // rows per stream in this launch
+    if (G > 1 && e->debug) return fail("internal: multi-chunk steps are not available in debug mode");
     if (fused) {
         if (run_layers_fused(e, rows, B, T, G)) return -1;
     } else {
@@ -952,13 +957,13 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
             memset(&g, 0, sizeof(g));
             g.A = e->a; g.W = L.wqkv; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.splits = 1;
             g.epi = EPI_QKV; g.q_out = e->q; g.kv_pool = e->kv_pool[l]; g.kv_slot_stride = (int64_t)2 * KVC * D;
-            g.rows = rows; g.T = T;
+            g.rows = rows; g.T = TS;
             run_gemm(e, g, false, "qkv");
             {
                 AttnParams ap;
                 memset(&ap, 0, sizeof(ap));
                 ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = act;
-                ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T;
+                ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T; ap.TS = TS;
                 ap.ctx_out = e->ctx;
                 const int KV = LCTX + T;
                 ProfScope ps(e, "k_attention", (double)B * (2.0 * KV + KV + T - 1) * D * e->esz, 2.0 * B * T * KV * D * 3);
@@ -985,7 +990,7 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
                 ConvParams cp;
                 memset(&cp, 0, sizeof(cp));
                 cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
-                cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = T; cp.ks = ks;
+                cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = TS; cp.ks = ks;
                 cp.c_out = e->cbuf; cp.act_bf16 = act;
                 ProfScope ps(e, "k_dwconv", (double)M * D * (4 + e->esz) + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks);
                 launch_dwconv(cp, st);
@@ -1014,7 +1019,7 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
         g.A = e->x; g.W = e->pk1a; g.M = M; g.N = 2048; g.K = D; g.lda = D; g.splits = 1;
         g.epi = EPI_BIAS_F32; g.out_f32 = e->hfuse; g.ldo = 2048; g.bias = e->pk1_b;
         { ProfScope ps(e, "k_gemm_f32", gemm_bytes(e, M, 2048, D, 4), 2.0 * M * 2048 * D); launch_gemm_f32(g, st); }
-        launch_prompt_add_relu(e->hfuse, e->pk1p, rows, M, T, e->hp.num_prompts, st);
+        launch_prompt_add_relu(e->hfuse, e->pk1p, rows, M, G * T, e->hp.num_prompts, st);
         memset(&g, 0, sizeof(g));
         g.A = e->hfuse; g.W = e->pk2_w; g.M = M; g.N = D; g.K = 2048; g.lda = 2048; g.splits = 1;
         g.epi = EPI_BIAS_F32; g.out_f32 = e->x; g.ldo = D; g.bias = e->pk2_b;
@@ -1260,7 +1265,7 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         // G consecutive chunks of a stream are one launch sequence (same results: a chunk's layer-l
         // inputs do not depend on the previous chunk's layer-l outputs, only on its K/V and conv state).
         // Needs the fused small-M path and the new rows to fit in the K/V ring next to the 70-row window.
-        if (!e->opt_multichunk || !e->bf16 || !e->opt_fused || B * G * T > 16 || G * T > KVC - LCTX) return 0;
+        if (!e->opt_multichunk || B * G * T > e->max_streams * TMAX || G * T > KVC - LCTX) return 0;
     }
     const int key = (B * 64 + T) * 16 + G;
     auto it = e->graphs.find(key);

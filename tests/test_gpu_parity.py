@@ -223,7 +223,7 @@ def test_quantised_gguf_flavours(W, kind):
     eng.close()
 
 
-@pytest.mark.parametrize("R,B,k", [(0, 1, 14), (0, 1, 5), (1, 1, 7), (0, 2, 8), (6, 1, 2)])
+@pytest.mark.parametrize("R,B,k", [(0, 1, 14), (0, 1, 3), (1, 1, 7), (0, 2, 8), (6, 1, 2), (0, 4, 14), (1, 3, 5)])
 def test_multi_chunk_push_equals_chunk_by_chunk(W, R, B, k):
     """A push that completes k chunks runs them as ONE launch sequence (M = B*k*T rows through every layer);
     the result equals pushing chunk by chunk: same tokens, same encoder output for the last frame."""
