@@ -144,7 +144,7 @@ class Stream:
         return out[:n].tolist()
 
     def tap(self, which, index=0, cap=None) -> np.ndarray:
-        cap = cap or 128 * 128
+        cap = cap or 1024 * 260          # up to MAXNEW = 256 encoder frames of one launch, or a 70-row cache
         out = np.zeros(cap, np.float32)
         n = _chk(lib().nasr_stream_get_tap(self.h, which, index, out.ctypes.data_as(C.POINTER(C.c_float)), cap))
         return out[:n].copy()

@@ -512,6 +512,6 @@ void launch_decode_iter(const DecParams &p, int iter, hipStream_t st) {
     hipLaunchKernelGGL(k_dec_commit, dim3(1), dim3(256), 0, st, p);
 }
 // iterations enqueued before the host looks at n_active: (symbols of the busiest stream) + 1 are needed
-int decode_blind_iterations(int frames) { return frames / 2 + 3; }
+int decode_blind_iterations(int frames) { return frames / 2 + 3 < 16 ? frames / 2 + 3 : 16; }
 
 }  // namespace nasr

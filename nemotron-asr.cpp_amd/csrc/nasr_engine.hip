@@ -101,7 +101,8 @@ struct nasr_engine {
     float *x, *x2, *part, *q, *glu, *encproj, *sub_a, *hfuse;
     bool opt_fused = true, opt_graph = true;
     // hipGraph replay of the steady-state step: fixed descriptor buffers + one exec per (B, T)
-    std::map<int, hipGraphExec_t> graphs;
+    std::map<int64_t, hipGraphExec_t> graphs;
+    int w_rows = 0;                  // workspace rows = max(max_streams x TMAX, MAXNEW)
     RowDesc *g_rows = nullptr, *g_vrows = nullptr; PcmDesc *g_pcm = nullptr; int *g_meta = nullptr;       // device
     RowDesc *gh_vrows = nullptr;
     bool opt_multichunk = true;
@@ -130,7 +131,7 @@ struct nasr_engine {
     Prof prof;
 };
 
-static const int COLLECT_STRIDE = 64;
+static const int COLLECT_STRIDE = 256;
 
 template <typename Tp>
 static int dalloc(nasr_engine *e, Tp **out, size_t n_elems) {
@@ -535,7 +536,8 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     if (load_weights(e, weights, n_weights)) { nasr_engine_destroy(e); return -1; }
 
     const size_t S = (size_t)max_streams, Lr = (size_t)hp->n_layers, ks1 = (size_t)hp->kernel_size - 1;
-    const size_t M = S * TMAX;
+    e->w_rows = std::max(max_streams * TMAX, MAXNEW);
+    const size_t M = (size_t)e->w_rows;
     int rc = 0;
     rc |= dalloc(e, &e->abuf, S * 2 * ABUF_CAP);
     rc |= dalloc(e, &e->last_sample, S);
@@ -565,14 +567,14 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     // subsampling ping-pong buffers.  Per stream the worst case is NOT R = 13 (H1 = 61 rows) but a
     // multi-chunk step at R = 0: 14 chunks x H1 = 9 rows = 126 rows of 65 x 256 after conv0, 14 x 5 = 70 rows of
     // 33 x 256 after the first depthwise conv (G * T <= 14, H1 = 4T + 5, H2 = 2T + 3).
-    const size_t sub_elems = S * 126 * 65 * SUBC;
+    const size_t sub_elems = M * 9 * 65 * SUBC;
     rc |= dalloc(e, &e->sub_a, sub_elems);
-    { char *p; rc |= dalloc(e, &p, (S * 70 * 33 * SUBC) * 4); e->sub_b = p; }
+    { char *p; rc |= dalloc(e, &p, (M * 5 * 33 * SUBC) * 4); e->sub_b = p; }
     rc |= dalloc(e, &e->predg, S * JNT);
-    rc |= dalloc(e, &e->key, S * TMAX);
+    rc |= dalloc(e, &e->key, M);
     rc |= dalloc(e, &e->n_active, 4);
     rc |= dalloc(e, &e->dlist, S);
-    rc |= dalloc(e, &e->rowmap, S * TMAX);
+    rc |= dalloc(e, &e->rowmap, M);
     rc |= dalloc(e, &e->tok_frame, S * TOK_CAP);
     rc |= dalloc(e, &e->collect_dev, S * (1 + COLLECT_STRIDE));
     if (rc) { nasr_engine_destroy(e); return -1; }
@@ -585,9 +587,9 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
         const size_t off_rows = 0, off_pcm = off_rows + S * sizeof(RowDesc), off_meta = off_pcm + S * sizeof(PcmDesc);
         const size_t off_col = off_meta + 2 * S * sizeof(int), off_act = off_col + S * (1 + COLLECT_STRIDE) * sizeof(int);
         const size_t off_vr = off_act + 64;
-        if (hipHostMalloc((void **)&e->gh, off_vr + S * TMAX * sizeof(RowDesc), hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+        if (hipHostMalloc((void **)&e->gh, off_vr + M * sizeof(RowDesc), hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
         e->gh_vrows = (RowDesc *)(e->gh + off_vr);
-        if (dalloc(e, &e->g_vrows, S * TMAX)) { nasr_engine_destroy(e); return -1; }
+        if (dalloc(e, &e->g_vrows, M)) { nasr_engine_destroy(e); return -1; }
         e->gh_rows = (RowDesc *)(e->gh + off_rows); e->gh_pcm = (PcmDesc *)(e->gh + off_pcm); e->gh_meta = (int *)(e->gh + off_meta);
         e->gh_collect = (int *)(e->gh + off_col); e->gh_active = (int *)(e->gh + off_act);
         if (dalloc(e, &e->g_rows, S) || dalloc(e, &e->g_pcm, S) || dalloc(e, &e->g_meta, 2 * S)) { nasr_engine_destroy(e); return -1; }
@@ -1265,9 +1267,9 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         // G consecutive chunks of a stream are one launch sequence (same results: a chunk's layer-l
         // inputs do not depend on the previous chunk's layer-l outputs, only on its K/V and conv state).
         // Needs the fused small-M path and the new rows to fit in the K/V ring next to the 70-row window.
-        if (!e->opt_multichunk || B * G * T > e->max_streams * TMAX || G * T > KVC - LCTX) return 0;
+        if (!e->opt_multichunk || B * G * T > e->w_rows || G * T > MAXNEW) return 0;
     }
-    const int key = (B * 64 + T) * 16 + G;
+    const int64_t key = ((int64_t)B << 32) | ((int64_t)T << 16) | (int64_t)G;
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
         HIPCHK(hipStreamSynchronize(e->st));
@@ -1334,42 +1336,13 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
     return consume_collect(e, e->gh_collect, streams, B, tokens_out, tokens_cap, n_tokens) ? -1 : 1;
 }
 
-extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm,
-                                const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap,
-                                int32_t *n_tokens, uint32_t flags) {
-    if (validate_batch(e, streams, B)) return -1;
-    if (!pcm || !n_samples) return fail("null pcm / n_samples");
-    HIPCHK(hipSetDevice(e->device));
+// one piece of a push (device-resident PCM): the graph-replayed launch sequence when eligible, else the eager
+// sub-push loop (mel -> chunk by chunk) -- then the new tokens of every stream
+static int push_piece(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *base, const int32_t *n_samples,
+                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens, uint32_t flags) {
     std::vector<int64_t> off(B, 0);
-    std::vector<const int16_t *> base(B, nullptr);
-    size_t total = 0;
-    for (int b = 0; b < B; b++) {
-        if (n_samples[b] < 0) return fail("negative n_samples");
-        if (n_samples[b] > 0 && !pcm[b]) return fail("null pcm for stream %d", b);
-        total += (size_t)n_samples[b];
-    }
-    if (!(flags & NASR_FLAG_PCM_DEVICE)) {
-        // hand-over of host buffers: one gather into the device staging area
-        if (total > e->pcm_stage_cap) {
-            HIPCHK(hipStreamSynchronize(e->st));
-            if (e->pcm_stage) hipFree(e->pcm_stage);
-            e->pcm_stage_cap = total + 65536;
-            HIPCHK(hipMalloc((void **)&e->pcm_stage, e->pcm_stage_cap * 2));
-        }
-        size_t o = 0;
-        ProfScope ps(e, "h2d_pcm", (double)total * 2);
-        for (int b = 0; b < B; b++) {
-            if (n_samples[b] > 0) HIPCHK(hipMemcpyAsync(e->pcm_stage + o, pcm[b], (size_t)n_samples[b] * 2, hipMemcpyHostToDevice, e->st));
-            base[b] = e->pcm_stage + o;
-            o += (size_t)n_samples[b];
-        }
-    } else {
-        for (int b = 0; b < B; b++) base[b] = pcm[b];
-    }
-    if (e->debug) for (int b = 0; b < B; b++) { e->tap_mel_frames[streams[b]->slot] = 0; e->tap_mel_row[streams[b]->slot] = b; }
-    for (int b = 0; b < B; b++) streams[b]->samples_in += n_samples[b];
     if (e->opt_graph && !e->debug && !e->prof.on && !(flags & NASR_FLAG_NO_SYNC)) {
-        const int gr = try_graph_step(e, streams, B, base.data(), n_samples, tokens_out, tokens_cap, n_tokens);
+        const int gr = try_graph_step(e, streams, B, base, n_samples, tokens_out, tokens_cap, n_tokens);
         if (gr < 0) return -1;
         if (gr == 1) return 0;
     }
@@ -1426,6 +1399,72 @@ extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int
         return 0;
     }
     return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
+}
+
+extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm,
+                                const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap,
+                                int32_t *n_tokens, uint32_t flags) {
+    if (validate_batch(e, streams, B)) return -1;
+    if (!pcm || !n_samples) return fail("null pcm / n_samples");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<const int16_t *> base(B, nullptr);
+    size_t total = 0;
+    for (int b = 0; b < B; b++) {
+        if (n_samples[b] < 0) return fail("negative n_samples");
+        if (n_samples[b] > 0 && !pcm[b]) return fail("null pcm for stream %d", b);
+        total += (size_t)n_samples[b];
+    }
+    if (!(flags & NASR_FLAG_PCM_DEVICE)) {
+        // hand-over of host buffers: one gather into the device staging area
+        if (total > e->pcm_stage_cap) {
+            HIPCHK(hipStreamSynchronize(e->st));
+            if (e->pcm_stage) hipFree(e->pcm_stage);
+            e->pcm_stage_cap = total + 65536;
+            HIPCHK(hipMalloc((void **)&e->pcm_stage, e->pcm_stage_cap * 2));
+        }
+        size_t o = 0;
+        ProfScope ps(e, "h2d_pcm", (double)total * 2);
+        for (int b = 0; b < B; b++) {
+            if (n_samples[b] > 0) HIPCHK(hipMemcpyAsync(e->pcm_stage + o, pcm[b], (size_t)n_samples[b] * 2, hipMemcpyHostToDevice, e->st));
+            base[b] = e->pcm_stage + o;
+            o += (size_t)n_samples[b];
+        }
+    } else {
+        for (int b = 0; b < B; b++) base[b] = pcm[b];
+    }
+    if (e->debug) for (int b = 0; b < B; b++) { e->tap_mel_frames[streams[b]->slot] = 0; e->tap_mel_row[streams[b]->slot] = b; }
+    for (int b = 0; b < B; b++) streams[b]->samples_in += n_samples[b];
+    // A push longer than one launch sequence can take (MAXNEW encoder frames per stream, w_rows rows in all) is
+    // cut into pieces of whole chunks; each piece is a multi-chunk step when the streams are aligned.
+    const int T = streams[0]->T;
+    int gcap = std::min(MAXNEW / T, e->w_rows / (B * T));
+    if (gcap < 1) gcap = 1;
+    const int64_t piece = (int64_t)gcap * 8 * T * HOP;
+    bool multi = false;
+    for (int b = 0; b < B; b++) multi = multi || n_samples[b] > piece;
+    if (!multi) return push_piece(e, streams, B, base.data(), n_samples, tokens_out, tokens_cap, n_tokens, flags);
+    std::vector<int64_t> off(B, 0);
+    std::vector<int32_t> acc(B, 0), np(B), cap_left(B), got(B);
+    std::vector<const int16_t *> ptr(B);
+    std::vector<int32_t *> outp(B);
+    for (;;) {
+        bool any = false;
+        for (int b = 0; b < B; b++) {
+            const int64_t rem = n_samples[b] - off[b];
+            np[b] = (int32_t)std::min<int64_t>(rem, piece);
+            any = any || np[b] > 0;
+            ptr[b] = base[b] + off[b];
+            const int32_t cap = tokens_out && tokens_out[b] && tokens_cap ? tokens_cap[b] : 0;
+            const int32_t used = std::min(acc[b], cap);
+            outp[b] = cap > 0 ? tokens_out[b] + used : nullptr;
+            cap_left[b] = cap - used;
+        }
+        if (!any) break;
+        if (push_piece(e, streams, B, ptr.data(), np.data(), outp.data(), cap_left.data(), got.data(), flags)) return -1;
+        for (int b = 0; b < B; b++) { off[b] += np[b]; acc[b] += got[b]; }
+    }
+    if (n_tokens) for (int b = 0; b < B; b++) n_tokens[b] = acc[b];
+    return 0;
 }
 
 extern "C" int nasr_engine_step_mel(nasr_engine *e, nasr_stream *const *streams, int B, const float *const *mel,

@@ -19,7 +19,8 @@ constexpr int HOP    = 160;
 constexpr int WIN    = 400;
 constexpr int LCTX   = 70;    // att_left_context
 constexpr int TMAX   = 14;    // 1 + max right context (13)
-constexpr int KVC    = 84;    // K/V ring capacity = LCTX + TMAX rows
+constexpr int MAXNEW = 256;   // encoder frames one stream may complete in ONE launch sequence (multi-chunk steps)
+constexpr int KVC    = LCTX + MAXNEW;   // K/V ring capacity: the 70-row window + the rows a launch appends
 constexpr int SUBC   = 256;   // subsampling channels
 constexpr int SUBF   = 17;    // subsampled freq bins
 constexpr int SUBFLAT = SUBC * SUBF;  // 4352
@@ -30,8 +31,8 @@ constexpr int JNT    = 640;
 constexpr int PRE_CACHE = 9;
 constexpr int DROP_EXTRA = 2;
 constexpr int MAX_SYMBOLS = 10;
-constexpr int MEL_RING = 256;         // mel ring frames per stream (power of two)
-constexpr int MAX_PUSH = 17920;       // samples per internal sub-push (= R=13 shift)
+constexpr int MEL_RING = 4096;        // mel ring frames per stream (power of two, > 9 + 8 * MAXNEW + one chunk)
+constexpr int MAX_PUSH = 1280 * MAXNEW;   // samples per internal sub-push (MAXNEW encoder frames)
 constexpr int ABUF_CAP = MAX_PUSH + NFFT + 64;
 constexpr int MAX_KS   = 32;          // max depthwise kernel size supported
 constexpr int TOK_CAP  = 4096;        // per-stream device token ring between collects
