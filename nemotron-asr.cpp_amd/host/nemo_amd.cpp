@@ -26,6 +26,39 @@ std::string tokens_to_text(const std::vector<int> &tokens, const std::vector<std
     return out;
 }
 
+std::string tokens_to_text(const std::vector<timed_token> &tokens, const std::vector<std::string> &vocab, bool timestamp_words) {
+    std::string out;
+    for (const timed_token &t : tokens) {
+        if (t.token_id < 0 || t.token_id >= (int)vocab.size()) continue;
+        const std::string &piece = vocab[(size_t)t.token_id];
+        if (piece.compare(0, 3, "\xe2\x96\x81") == 0) {
+            out += ' ';
+            if (timestamp_words) {
+                char stamp[32];
+                snprintf(stamp, sizeof(stamp), "{%.2f}", t.to_seconds());
+                out += stamp;
+            }
+            out.append(piece, 3, std::string::npos);
+        } else {
+            out += piece;
+        }
+    }
+    return out;
+}
+
+std::vector<timed_token> nemo_stream_get_timed_tokens(nemo_stream_context *sctx) {
+    std::vector<timed_token> out;
+    if (!sctx) return out;
+    const size_t n = sctx->tokens.size();
+    std::vector<int32_t> frames(n ? n : 1);
+    const size_t first = n > 4096 ? n - 4096 : 0;       // older frames have left the device ring
+    const int got = nasr_stream_get_token_frames(sctx->stream, (int64_t)first, (int32_t)(n - first), frames.data());
+    if (got < 0) { fprintf(stderr, "%s: %s\n", __func__, nasr_last_error()); return out; }
+    for (size_t i = 0; i < first; i++) out.emplace_back(sctx->tokens[i], -1);
+    for (int i = 0; i < got; i++) out.emplace_back(sctx->tokens[first + (size_t)i], frames[(size_t)i]);
+    return out;
+}
+
 nemo_context *nemo_init_with_device(const char *model_path, int device, int dtype, int max_streams) {
     if (!model_path) return nullptr;
     GgufFile g;

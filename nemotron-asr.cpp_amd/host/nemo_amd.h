@@ -79,3 +79,15 @@ bool nemo_stream_process_batch(nemo_stream_context *const *sctx, int B, const in
 
 // token ids -> text: U+2581 starts a word (reference src/nemo-ggml.cpp:1556-1583); ids outside the vocab are skipped
 std::string tokens_to_text(const std::vector<int> &tokens, const std::vector<std::string> &vocab);
+
+// reference src/nemo-ggml.h:383-395: a token with the encoder frame it was emitted on (80 ms per frame)
+struct timed_token {
+    int token_id;
+    int64_t frame_idx;
+    timed_token(int id = 0, int64_t frame = 0) : token_id(id), frame_idx(frame) {}
+    float to_seconds(int frame_samples = 1280, int sample_rate = 16000) const { return (float)frame_idx * frame_samples / sample_rate; }
+};
+// every token of the stream since init/reset with its frame (the engine keeps the frames of the last 4096 tokens)
+std::vector<timed_token> nemo_stream_get_timed_tokens(nemo_stream_context *sctx);
+// reference src/nemo-ggml.cpp:1556-1583: "{12.34}" in front of every word when timestamp_words is set
+std::string tokens_to_text(const std::vector<timed_token> &tokens, const std::vector<std::string> &vocab, bool timestamp_words);

@@ -14,8 +14,11 @@
 
 static void usage(const char *prog) {
     fprintf(stderr,
-            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens]\n"
-            "  audio: raw s16le, 16 kHz, mono.  right_context in {0, 1, 6, 13} (80 ms .. 1.12 s lookahead)\n", prog);
+            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps]\n"
+            "  audio: raw s16le, 16 kHz, mono.  right_context in {0, 1, 6, 13} (80 ms .. 1.12 s lookahead)\n"
+            "  --read-chunks N: read N chunks of audio per call (default 1 = the reference's read size); a file is\n"
+            "                   transcribed fastest with N = 256: same transcript, the chunks of a read share one launch sequence\n"
+            "  --timestamps:    print the final transcript again with {seconds} in front of every word\n", prog);
 }
 
 int main(int argc, char **argv) {
@@ -23,7 +26,8 @@ int main(int argc, char **argv) {
     const char *model_path = argv[1], *audio_path = argv[2];
     int chunk_ms = 80, right_context = 0, device = 0, dtype = 1, positional = 0;
     const char *lang = nullptr;
-    bool print_tokens = false;
+    bool print_tokens = false, timestamps = false;
+    int read_chunks = 1;
     const bool from_stdin = strcmp(audio_path, "-") == 0 || strcmp(audio_path, "--stdin") == 0;
     for (int i = 3; i < argc; i++) {
         const std::string a = argv[i];
@@ -31,10 +35,13 @@ int main(int argc, char **argv) {
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--f32") dtype = 0;
         else if (a == "--print-tokens") print_tokens = true;
+        else if (a == "--timestamps") timestamps = true;
+        else if (a == "--read-chunks" && i + 1 < argc) read_chunks = atoi(argv[++i]);
         else if (!a.empty() && a[0] == '-') { fprintf(stderr, "Unknown flag: %s\n", a.c_str()); return 1; }
         else if (positional == 0) { chunk_ms = atoi(argv[i]); positional++; }
         else if (positional == 1) { right_context = atoi(argv[i]); positional++; }
     }
+    if (read_chunks < 1 || read_chunks > 4096) { fprintf(stderr, "--read-chunks must be in 1..4096 (got %d)\n", read_chunks); return 1; }
     if (chunk_ms < 10) { fprintf(stderr, "chunk_ms must be >= 10 (got %d)\n", chunk_ms); return 1; }
     fprintf(stderr, "Configuration:\n  Model:          %s\n  Audio:          %s\n  Chunk size:     %d ms\n  Right context:  %d\n\n",
             model_path, from_stdin ? "stdin" : audio_path, chunk_ms, right_context);
@@ -50,7 +57,7 @@ int main(int argc, char **argv) {
     FILE *in = from_stdin ? stdin : fopen(audio_path, "rb");
     if (!in) { fprintf(stderr, "Failed to open audio file: %s\n", audio_path); nemo_stream_free(sctx); nemo_free(ctx); return 1; }
     // like the reference, the read size is the model's chunk (chunk_ms is validated and printed only)
-    std::vector<int16_t> buf((size_t)cfg.get_chunk_samples());
+    std::vector<int16_t> buf((size_t)cfg.get_chunk_samples() + (size_t)(read_chunks - 1) * 1280u * (size_t)(1 + right_context));
     size_t total = 0;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -69,6 +76,7 @@ int main(int argc, char **argv) {
     const double audio_s = (double)total / 16000.0;
     fprintf(stderr, "\nAudio duration:   %.2f s\nProcessing time:  %.3f s\nReal-time factor: %.4f (%.1fx real time)\nChunks: %d\n",
             audio_s, wall, audio_s > 0 ? wall / audio_s : 0.0, wall > 0 ? audio_s / wall : 0.0, sctx->total_chunks_processed);
+    if (timestamps) printf("%s\n", tokens_to_text(nemo_stream_get_timed_tokens(sctx), ctx->vocab, true).c_str());
     if (print_tokens) {
         printf("TOKENS:");
         for (int t : nemo_stream_get_tokens(sctx)) printf(" %d", t);

@@ -113,6 +113,17 @@ def test_cli_end_to_end(tmp_path):
         text = "".join((" " + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t] for t in toks)
         assert lines[0] == text
         assert "Real-time factor" in r.stderr
+    # file mode: 64 chunks per read share one launch sequence; same tokens; word timestamps = frame * 80 ms
+    r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--print-tokens", "--read-chunks", "64", "--timestamps"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    ost = ob.OracleStream(ob.OracleModel(deqW, n_layers), 0)
+    ref = ost.process(pcm) + ost.finalize()
+    assert [int(x) for x in lines[-1].split()[1:]] == ref
+    stamped = "".join((" {%.2f}" % (np.float32(f) * 1280 / 16000) + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t]
+                      for t, f in zip(ref, ost.token_frames()))
+    assert lines[-2] == stamped
     r = subprocess.run([str(cli), str(model), str(audio), "80", "5"], capture_output=True, text=True)
     assert r.returncode == 1 and "right_context" in r.stderr
 
