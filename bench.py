@@ -69,8 +69,10 @@ def parse():
                     help="audio pushed per step, in chunks: > 1 = buffered / file transcription (several chunks of a stream "
                          "go through the layers as one launch sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=3.2, help="audio seconds of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0,
+                    help="audio seconds of the CPU-baseline sample (~10-20 s of CPU work on 16 host threads)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-buffered", action="store_true", help="skip the buffered-audio (file transcription) figure")
     return ap.parse_args()
 
 
@@ -156,19 +158,59 @@ def main():
         eng.profile(False)
         dom = max((k for k in kernels if "gemm" in k["name"]), key=lambda k: k["total_ms"], default=None)
         if dom and dom["total_ms"] > 0:
-            avg_ms = dom["total_ms"] / dom["launches"]
+            # Events bracket every launch of the (eager) profile pass, so each bracket also holds ~2 us of launch
+            # latency that the timed region (graph replay) does not pay.  The kernel's duration inside the timed
+            # region = its share of the bracketed time x the timed step; this is what rocprofv3 reports for the
+            # same command (profiles/).  The raw bracket average is kept beside it.
+            ev_total = sum(k["total_ms"] for k in kernels)
+            share = dom["total_ms"] / ev_total
+            per_step = dom["launches"] / prof_steps
+            avg_ms = share * (1e3 * elapsed / args.steps) / per_step
+            avg_ev_us = 1e3 * dom["total_ms"] / dom["launches"]
             if dom["name"] == "k_gemm_tiled":
                 ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
                 roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS,
                                 unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
-                                avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps)
+                                avg_launch_us=round(avg_ms * 1e3, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
+                                launches_per_step=per_step, share_of_step=round(share, 4))
             else:
                 traffic = pmc_traffic(dom["name"], B * args.chunks_per_step, R, args.dtype, args.layers)
                 ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
                 roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                                 unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                                avg_launch_us=round(avg_ms * 1e3, 3), launches_per_step=dom["launches"] / prof_steps,
+                                avg_launch_us=round(avg_ms * 1e3, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
+                                launches_per_step=per_step, share_of_step=round(share, 4),
                                 alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]))
+
+    # ---- the same stream fed buffered audio (file transcription): 256 chunks per push share one launch sequence ----
+    buffered = None
+    if rank == 0 and world == 1 and (B, args.chunks_per_step) == (1, 1) and not args.no_buffered:
+        G, n_push = 256, 5
+        nb = synth.shift_samples(R) * G
+        pb = synth.make_pcm(1000, (n_push + 1) * nb / synth.SAMPLE_RATE + 0.01)[:(n_push + 1) * nb]
+        db = eng.upload(pb)
+        sb = streams[0]                         # the timed region is over: reuse its slot
+        sb.reset()
+        hb = (C.c_void_p * 1)(sb.h)
+        tb = np.zeros(16 * T * G, np.int32)
+        tpb = (C.c_void_p * 1)(tb.ctypes.data)
+        cb = (C.c_int32 * 1)(tb.size)
+        nbb = (C.c_int32 * 1)(nb)
+        ntb = (C.c_int32 * 1)()
+        tt = []
+        for k in range(n_push + 1):
+            ptr = (C.c_void_p * 1)(db + 2 * k * nb)
+            eng.synchronize()
+            tq = time.perf_counter()
+            if L.nasr_engine_step(eng.h, hb, 1, ptr, nbb, tpb, cb, ntb, capi.FLAG_PCM_DEVICE) < 0:
+                raise RuntimeError(L.nasr_last_error().decode())
+            eng.synchronize()
+            tt.append(time.perf_counter() - tq)
+        tsum = sum(tt[1:])                      # the first push builds the graph
+        buffered = dict(chunks_per_push=G, pushes=n_push, ms_per_push=round(1e3 * tsum / n_push, 3),
+                        value=round(n_push * nb / synth.SAMPLE_RATE / tsum, 1), unit="audio-s/s",
+                        note="same engine, same stream semantics (80 ms lookahead, chunk-by-chunk caches), the 256 chunks of "
+                             "a push go through every layer as one launch sequence; not the headline value")
 
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample ------------
     cpu = None
@@ -177,7 +219,7 @@ def main():
         om = ob.OracleModel(W, args.layers)
         ost = ob.OracleStream(om, R)
         n_cpu_steps = max(2, int(args.cpu_seconds * synth.SAMPLE_RATE / n_step))
-        p = pcm_host[0]
+        p = synth.make_pcm(sharding.stream_ids(rank, world, B)[0], args.cpu_seconds + 3 * n_step / synth.SAMPLE_RATE + 1.0)
         ost.process(p[:2 * n_step])            # warm-up: fills the first chunk
         c0 = ost.total_chunks
         tc = time.perf_counter()
@@ -215,6 +257,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "buffered_audio": buffered,
             "kernels": [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in kernels],
             "setup_s": {"weights": round(t_weights, 1)},
         }
