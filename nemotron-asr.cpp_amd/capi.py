@@ -125,6 +125,9 @@ class Stream:
     def reset(self):
         _chk(lib().nasr_stream_reset(self.h))
 
+    def set_prompt(self, prompt_index: int):
+        _chk(lib().nasr_stream_set_prompt(self.h, prompt_index))
+
     def destroy(self):
         if self.h:
             lib().nasr_stream_destroy(self.h)

@@ -11,18 +11,17 @@ namespace nasr {
 
 // ---- pre-emphasis + append to the stream's audio buffer (src/preprocessor.cpp:345-356) ----
 __global__ __launch_bounds__(256) void k_preemph(MelParams p) {
-    const PcmDesc d = p.desc[blockIdx.x];
+    const PcmDesc d = p.desc[blockIdx.y];
     if (d.n <= 0) return;
     float *buf = p.abuf + ((size_t)d.slot * 2 + d.par) * ABUF_CAP;
-    const float last = p.last_sample[d.slot];
     const float scale = 1.0f / 32768.0f;
-    for (int i = threadIdx.x; i < d.n; i += 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
         float curr = (float)d.pcm[i] * scale;
-        float prev = i > 0 ? (float)d.pcm[i - 1] * scale : last;
+        float prev = i > 0 ? (float)d.pcm[i - 1] * scale : p.last_sample[d.slot];   // i == 0: thread 0 of block 0
         buf[d.cnt + i] = __fsub_rn(curr, __fmul_rn(0.97f, prev));
     }
-    __syncthreads();
-    if (threadIdx.x == 0) p.last_sample[d.slot] = (float)d.pcm[d.n - 1] * scale;
+    __syncthreads();      // block 0: its thread 0 has read last_sample above
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.last_sample[d.slot] = (float)d.pcm[d.n - 1] * scale;
 }
 
 // ---- one workgroup per (frame, stream): window, 512-point FFT in LDS, power, mel, log ------
@@ -79,8 +78,9 @@ __global__ __launch_bounds__(256) void k_abuf_shift(MelParams p) {
 }
 
 void launch_mel(const MelParams &p, int max_n, hipStream_t st) {
-    (void)max_n;
-    hipLaunchKernelGGL(k_preemph, dim3(p.B), dim3(256), 0, st, p);
+    int nblk = (max_n + 2047) / 2048;       // ~8 samples per thread
+    nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+    hipLaunchKernelGGL(k_preemph, dim3(nblk, p.B), dim3(256), 0, st, p);
     if (p.max_frames > 0) {
         hipLaunchKernelGGL(k_melframes, dim3(p.max_frames, p.B), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_abuf_shift, dim3(p.B), dim3(256), 0, st, p);

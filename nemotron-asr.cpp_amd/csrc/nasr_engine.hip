@@ -821,12 +821,14 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         f.g.W = L.pw1; f.g.M = M; f.g.N = 2 * D; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_GLU; f.g.out_f32 = e->glu; f.g.ldo = D;
         launch(f, "k_fused_ln_gemm", wbytes(2 * D, D), 2.0 * M * 2 * D * D);
         cur ^= 1;
-        // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2 (split-K 4); same rule as K4
+        // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2; same rule as K4
+        static const int pw2_splits_env = getenv("NASR_PW2_SPLITS") ? atoi(getenv("NASR_PW2_SPLITS")) : 4;
+        const int pw2_splits = M <= fuse_max_m ? pw2_splits_env : 4;
         if (M <= fuse_max_m) {
             memset(&f, 0, sizeof(f));
             f.pro = PRO_DWCONV; f.cv.glu = e->glu; f.cv.cc_pool = e->cc_pool[l]; f.cv.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
             f.cv.dw = L.dw; f.cv.ln_w = L.cln_w; f.cv.ln_b = L.cln_b; f.cv.rows = rows; f.cv.B = B; f.cv.T = TS; f.cv.ks = ks;
-            f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
+            f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = pw2_splits; f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
             launch(f, "k_fused_dwconv_gemm", wbytes(D, D), 2.0 * M * D * D);
         } else {
             ConvParams cp;
@@ -842,7 +844,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         }
         // K7: x += conv ; LN_ff2 -> W1 -> SiLU
         memset(&f, 0, sizeof(f));
-        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = 4; f.scale = 1.0f;
+        f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = pw2_splits; f.scale = 1.0f;
         f.ln_w = L.ln_ff2_w; f.ln_b = L.ln_ff2_b;
         f.g.W = L.ff2_w1; f.g.M = M; f.g.N = FF; f.g.K = D; f.g.splits = 1; f.g.epi = EPI_SILU_ACT; f.g.out_act = e->hbuf; f.g.ldo_act = FF;
         launch(f, "k_fused_ln_gemm", wbytes(FF, D), 2.0 * M * FF * D);
@@ -1206,7 +1208,7 @@ extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
 // Eligible when every stream of the call receives one sub-push that completes exactly one chunk
 // (the normal streaming cadence: 1280*(1+R) samples per push).  The launch sequence is then fixed
 // for a given (B, T): descriptors live at fixed addresses and are refreshed by memcpy nodes.
-static int max_frames_per_push(int TS) { return 8 * TS + 2; }   // TS = frames of encoder output the push completes
+static int max_frames_per_push(int TS) { return 8 * TS + 16; }  // TS = frames of encoder output the push completes (+ what a first push leaves over)
 
 static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraphExec_t *out) {
     hipStream_t st = e->st;
@@ -1222,7 +1224,7 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraph
         memset(&mp, 0, sizeof(mp));
         mp.desc = e->g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
         mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
-        launch_mel(mp, 0, st);
+        launch_mel(mp, mp.max_frames * HOP + NFFT, st);
         if (enqueue_encoder(e, e->g_rows, G > 1 ? e->g_vrows : e->g_rows, nullptr, B, T, R, G)) return -1;
         DecParams dp;
         make_dec_params(e, e->g_rows, B, T * G, dp);

@@ -79,6 +79,7 @@ def lib():
         L.orc_stream_finalize.argtypes = [C.c_void_p, _ip, C.c_int]
         L.orc_stream_set_taps.argtypes = [C.c_void_p, _fp, _fp]
         L.orc_stream_token_frames.argtypes = [C.c_void_p, _ip, C.c_int]
+        L.orc_stream_set_prompt.argtypes = [C.c_void_p, C.c_int]
         L.orc_stream_get_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp]
         L.orc_stream_get_decoder_state.argtypes = [C.c_void_p, _fp, _fp, _ip]
         L.orc_round_bf16.restype = C.c_float
@@ -218,6 +219,9 @@ class OracleStream:
     @property
     def decode_iterations(self):
         return lib().orc_stream_decode_iterations(self.h)
+
+    def set_prompt(self, prompt_index: int):
+        lib().orc_stream_set_prompt(self.h, prompt_index)
 
     def token_frames(self) -> list:
         """absolute encoder-frame index (x 80 ms) of every token since create/reset"""

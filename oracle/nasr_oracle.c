@@ -587,6 +587,8 @@ void orc_stream_free(orc_stream *s) {
     free(s);
 }
 
+/* nemo_stream_set_language (src/nemo-stream.cpp:735-749): takes effect from the next chunk */
+void orc_stream_set_prompt(orc_stream *s, int prompt_index) { s->prompt_index = prompt_index; }
 int orc_stream_chunk_mel_frames(const orc_stream *s) { return s->chunk_mel; }
 int orc_stream_chunk_len(const orc_stream *s) { return s->T; }
 int orc_stream_cache_valid_len(const orc_stream *s) { return s->cache_valid_len; }

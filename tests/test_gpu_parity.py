@@ -340,6 +340,40 @@ def test_decode_many_rows_tokens_f32(W, om32):
     eng.close()
 
 
+def test_multilingual_prompt_fusion_f32():
+    """a-11 (src/nemo-ggml.cpp:1087-1105): ReLU([enc; onehot(lang)] W1 + b1) W2 + b2 between the last layer and the
+    joint.  Two streams with different prompts in one launch, a language switch mid-stream, an out-of-range index
+    (falls back to prompt 0, src/nemo-stream.cpp:1052-1053) -- tokens and encoder output equal the oracle's."""
+    P, R = 8, 1
+    W = synth.make_weights(n_layers=N_LAYERS, num_prompts=P)
+    om = ob.OracleModel(W, N_LAYERS, num_prompts=P)
+    eng = capi.Engine(W, n_layers=N_LAYERS, dtype=capi.DTYPE_F32, max_streams=3, num_prompts=P)
+    eng.set_debug(True)
+    prompts = [3, 6, -1]
+    sts = [eng.stream(R, p) for p in prompts]
+    osts = [ob.OracleStream(om, R, p) for p in prompts]
+    pcms = [synth.make_pcm(70 + b, 4.0) for b in range(3)]
+    taps = [o.enable_taps() for o in osts]
+    got, ref = [[] for _ in sts], [[] for _ in sts]
+    n = synth.shift_samples(R)
+    for k, o in enumerate(range(0, pcms[0].size, n)):
+        if k == 10:                                    # nemo_stream_set_language mid-stream
+            sts[0].set_prompt(5)
+            osts[0].set_prompt(5)
+        out = eng.step(sts, [p[o:o + n] for p in pcms])
+        for b in range(3):
+            got[b] += out[b]
+            ref[b] += osts[b].process(pcms[b][o:o + n])
+    for b in range(3):
+        assert got[b] == ref[b], b
+        assert sts[b].stats().chunks == osts[b].total_chunks
+    assert sum(len(r) for r in ref) > 5
+    assert ref[0] != ref[1] or ref[1] != ref[2]       # the prompt matters
+    with pytest.raises(capi.NasrError):
+        sts[0].set_prompt(P)
+    eng.close()
+
+
 def test_batch_equals_single_stream(eng32):
     """B streams in one launch == each stream on its own (independent units)."""
     pcms = [synth.make_pcm(s, 2.0) for s in range(3)]
