@@ -112,32 +112,75 @@ void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring
     hipLaunchKernelGGL(k_mel_zero, dim3(max_frames, B), dim3(NMEL), 0, st, desc, mel_ring);
 }
 
-// ---- conv0: 3x3 stride-2, 1 -> 256 channels, pad (2 before, 1 after) both axes, + ReLU ----
-// (src/nemo-ggml.cpp:969-973, :905-913).  out [B][H1][W1][256], channel fastest.
-__global__ __launch_bounds__(256) void k_sub_conv0(const RowDesc *rows, int chunk_mel, const float *mel_ring,
-                                                   const float *w0t /*[9][256]*/, const float *b0, float *out,
-                                                   int H1, int W1) {
-    const int c = threadIdx.x;
-    const int f = blockIdx.x % W1, t = blockIdx.x / W1, b = blockIdx.y;
+// ---- conv0 (3x3 stride-2, 1 -> 256 channels, + ReLU) fused into the first depthwise 3x3 stride-2 conv ----
+// (src/nemo-ggml.cpp:969-978, pads (2 before, 1 after) on both axes :905-913, :936-943).  conv0's output
+// [H1][65][256] f32 is 9x larger than its input and was the largest intermediate of the step (260 MB at 64
+// streams x R = 13); its 9 MACs per element are cheaper to redo than to store and re-read.  Every conv0 value is
+// formed exactly as the unfused kernel formed it (same order, no FMA contraction in this file), so the result is
+// bit-identical.  One workgroup per (output position, chunk), one thread per channel; the mel patch addresses are
+// workgroup-uniform (scalar loads).  out [B][H2][W2][256], channel fastest.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void k_sub_conv0_dw(const RowDesc *rows, int chunk_mel, const float *mel_ring,
+                                                      const float *w0t /*[9][256]*/, const float *b0,
+                                                      const float *w2t /*[9][256]*/, const float *b2, void *out,
+                                                      int H1, int W1, int H2, int W2) {
+    // One workgroup per (output row t2, chunk): the 7 mel rows 4*t2-6 .. 4*t2 it depends on are staged in LDS,
+    // zero padded (an out-of-range tap adds w*0 where the unfused kernel skipped it: same sum), 6 columns of left
+    // pad so that output column f2 reads the 7x7 patch at columns 4*f2 .. 4*f2+6.
+    __shared__ __attribute__((aligned(16))) float sm[7][144];
+    const int c = threadIdx.x, t2 = blockIdx.x, b = blockIdx.y;
     const RowDesc rd = rows[b];
-    float acc = 0.0f;
-#pragma unroll
-    for (int kh = 0; kh < 3; kh++) {
-        const int ih = 2 * t + kh - 2;
-        if (ih < 0 || ih >= chunk_mel) continue;
-        const float *mrow = mel_ring + ((size_t)rd.slot * MEL_RING + ((rd.mel_start + ih) & (MEL_RING - 1))) * NMEL;
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-            const int iw = 2 * f + kw - 2;
-            if (iw < 0 || iw >= NMEL) continue;
-            acc += w0t[(kh * 3 + kw) * SUBC + c] * mrow[iw];
-        }
+    const float *mel = mel_ring + (size_t)rd.slot * MEL_RING * NMEL;
+    for (int i = threadIdx.x; i < 7 * 144; i += 256) {
+        const int r = i / 144, iw = i - r * 144 - 6, ih = 4 * t2 - 6 + r;
+        sm[r][i - r * 144] = (ih >= 0 && ih < chunk_mel && iw >= 0 && iw < NMEL)
+                                 ? mel[(size_t)((rd.mel_start + ih) & (MEL_RING - 1)) * NMEL + iw] : 0.0f;
     }
-    out[(((size_t)b * H1 + t) * W1 + f) * SUBC + c] = fmaxf(acc + b0[c], 0.0f);
+    float w0[9], w2[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { w0[k] = w0t[k * SUBC + c]; w2[k] = w2t[k * SUBC + c]; }
+    const float bias0 = b0[c], bias2 = b2[c];
+    __syncthreads();
+    // blockIdx.z splits the output columns when there are too few (row, chunk) pairs to fill the chip
+    const int f2_lo = (int)((long)W2 * blockIdx.z / gridDim.z), f2_hi = (int)((long)W2 * (blockIdx.z + 1) / gridDim.z);
+    for (int f2 = f2_lo; f2 < f2_hi; f2++) {
+        float p[7][8];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const float4 lo = *(const float4 *)&sm[r][4 * f2], hi = *(const float4 *)&sm[r][4 * f2 + 4];
+            p[r][0] = lo.x; p[r][1] = lo.y; p[r][2] = lo.z; p[r][3] = lo.w;
+            p[r][4] = hi.x; p[r][5] = hi.y; p[r][6] = hi.z; p[r][7] = hi.w;
+        }
+        float acc2 = 0.0f;
+#pragma unroll
+        for (int kh2 = 0; kh2 < 3; kh2++) {
+            const int t = 2 * t2 + kh2 - 2;               // conv0 output row feeding this tap
+            if (t < 0 || t >= H1) continue;
+#pragma unroll
+            for (int kw2 = 0; kw2 < 3; kw2++) {
+                const int f = 2 * f2 + kw2 - 2;           // conv0 output column
+                if (f < 0 || f >= W1) continue;
+                float acc = 0.0f;
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++) acc += w0[kh * 3 + kw] * p[2 * kh2 + kh][2 * kw2 + kw];
+                acc2 += w2[kh2 * 3 + kw2] * fmaxf(acc + bias0, 0.0f);
+            }
+        }
+        acc2 += bias2;
+        const size_t o = (((size_t)b * H2 + t2) * W2 + f2) * SUBC + c;
+        if (OUT_BF16) ((bf16_t *)out)[o] = f32_to_bf16(acc2);
+        else ((float *)out)[o] = acc2;
+    }
 }
-void launch_sub_conv0(const RowDesc *rows, int B, int chunk_mel, const float *mel_ring, const float *w0t,
-                      const float *b0, float *out, int H1, int W1, hipStream_t st) {
-    hipLaunchKernelGGL(k_sub_conv0, dim3(H1 * W1, B), dim3(SUBC), 0, st, rows, chunk_mel, mel_ring, w0t, b0, out, H1, W1);
+void launch_sub_conv0_dw(const RowDesc *rows, int B, int chunk_mel, const float *mel_ring, const float *w0t, const float *b0,
+                         const float *w2t, const float *b2, void *out, int out_bf16, int H1, int W1, hipStream_t st) {
+    const int H2 = H1 / 2 + 1, W2 = W1 / 2 + 1;   // W1 = 65 -> W2 = 33: columns 4*f2 + 7 <= 139 < 144
+    const int fz = H2 * B <= 64 ? 11 : (H2 * B <= 512 ? 3 : 1);
+    const dim3 grid(H2, B, fz);
+    if (out_bf16) hipLaunchKernelGGL(k_sub_conv0_dw<true>, grid, dim3(SUBC), 0, st, rows, chunk_mel, mel_ring, w0t, b0, w2t, b2, out, H1, W1, H2, W2);
+    else hipLaunchKernelGGL(k_sub_conv0_dw<false>, grid, dim3(SUBC), 0, st, rows, chunk_mel, mel_ring, w0t, b0, w2t, b2, out, H1, W1, H2, W2);
 }
 
 // ---- depthwise 3x3 stride-2 (+bias, no activation), :978, :994, :929-950 ---------------------

@@ -564,11 +564,9 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     { char *p; rc |= dalloc(e, &p, M * FF * e->esz); e->hbuf = p; }
     { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->ctx = p; }
     { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->cbuf = p; }
-    // subsampling ping-pong buffers.  Per stream the worst case is NOT R = 13 (H1 = 61 rows) but a
-    // multi-chunk step at R = 0: 14 chunks x H1 = 9 rows = 126 rows of 65 x 256 after conv0, 14 x 5 = 70 rows of
-    // 33 x 256 after the first depthwise conv (G * T <= 14, H1 = 4T + 5, H2 = 2T + 3).
-    const size_t sub_elems = M * 9 * 65 * SUBC;
-    rc |= dalloc(e, &e->sub_a, sub_elems);
+    // subsampling ping-pong buffers, [chunks][H2][33][256] (conv0 is fused into the first depthwise conv and never
+    // stored).  Rows per encoder frame are largest for multi-chunk steps at R = 0: H2 = 2T + 3 = 5 per frame.
+    rc |= dalloc(e, &e->sub_a, M * 5 * 33 * SUBC);
     { char *p; rc |= dalloc(e, &p, (M * 5 * 33 * SUBC) * 4); e->sub_b = p; }
     rc |= dalloc(e, &e->predg, S * JNT);
     rc |= dalloc(e, &e->key, M);
@@ -881,12 +879,8 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     // ---- a-2 subsampling ------------------------------------------------------------------
     const int H1 = chunk_mel / 2 + 1, W1 = 65, H2 = H1 / 2 + 1, W2 = 33, H3 = H2 / 2 + 1, W3 = 17;
     {
-        ProfScope ps(e, "k_sub_conv0", (double)Bs * H1 * W1 * SUBC * 4, 2.0 * Bs * H1 * W1 * SUBC * 9);
-        launch_sub_conv0(vrows, Bs, chunk_mel, e->mel_ring, e->w0t, e->b0, e->sub_a, H1, W1, st);
-    }
-    {
-        ProfScope ps(e, "k_sub_dw", (double)B * H1 * W1 * SUBC * 4, 2.0 * B * H2 * W2 * SUBC * 9);
-        launch_sub_dw(e->sub_a, Bs, H1, W1, e->w2t, e->b2, e->sub_b, act, st);
+        ProfScope ps(e, "k_sub_conv0_dw", (double)Bs * (chunk_mel * NMEL * 4 + H2 * W2 * SUBC * (act ? 2 : 4)), 2.0 * Bs * H2 * W2 * SUBC * 90);
+        launch_sub_conv0_dw(vrows, Bs, chunk_mel, e->mel_ring, e->w0t, e->b0, e->w2t, e->b2, e->sub_b, act, H1, W1, st);
     }
     GemmParams g;
     memset(&g, 0, sizeof(g));

@@ -132,8 +132,8 @@ void launch_mel(const MelParams &p, int max_n, hipStream_t st);
 void launch_mel_put(const float *staged, const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
 void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
 
-void launch_sub_conv0(const RowDesc *rows, int B, int chunk_mel, const float *mel_ring, const float *w0t,
-                      const float *b0, float *out, int H1, int W1, hipStream_t st);
+void launch_sub_conv0_dw(const RowDesc *rows, int B, int chunk_mel, const float *mel_ring, const float *w0t, const float *b0,
+                         const float *w2t, const float *b2, void *out, int out_bf16, int H1, int W1, hipStream_t st);
 void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, const float *bias, void *out,
                    int out_bf16, hipStream_t st);
 
