@@ -6,7 +6,8 @@
 // differs: the reference processes ONE data event of ONE stream at a time (src/nemo-server.cpp:230-239);
 // here the worker drains everything that is queued, concatenates each session's pending audio, groups the
 // sessions by right_context and issues ONE nemo_stream_process_batch per group -- the batch former that the
-// MI355X engine needs (B streams per launch sequence).  One worker thread owns the engine.
+// MI355X engine needs (B streams per launch sequence).  One worker thread owns each engine; with --devices there is
+// one engine + FIFO + worker ("lane") per GPU and stream s is served by lane s mod count, no cross-GPU traffic.
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -69,21 +70,29 @@ struct Event {
     std::vector<int16_t> pcm;
 };
 
-std::mutex g_mtx;
-std::condition_variable g_cv, g_space_cv;
-std::deque<Event> g_queue;
-size_t g_queued_bytes = 0;
+// One lane per GPU: its own engine (weights replicated), FIFO and worker thread.  Session id s lives on lane
+// s mod n_lanes for its whole life (streams are independent, no cross-GPU traffic).
+struct Lane {
+    nemo_context *model = nullptr;
+    std::mutex mtx;
+    std::condition_variable cv, space_cv;
+    std::deque<Event> queue;
+    size_t queued_bytes = 0;
+    std::thread worker;
+};
+std::vector<std::unique_ptr<Lane>> g_lanes;
 std::atomic<bool> g_stop{false};
 std::atomic<uint32_t> g_next_id{1};
 int g_default_rc = 0;
 
 void enqueue(Event &&ev) {
-    std::unique_lock<std::mutex> lk(g_mtx);
+    Lane &ln = *g_lanes[ev.id % g_lanes.size()];
+    std::unique_lock<std::mutex> lk(ln.mtx);
     const size_t bytes = ev.pcm.size() * sizeof(int16_t);
-    g_space_cv.wait(lk, [&] { return g_stop || g_queued_bytes + bytes <= kMaxQueuedBytes || g_queued_bytes == 0; });
-    g_queued_bytes += bytes;
-    g_queue.push_back(std::move(ev));
-    g_cv.notify_one();
+    ln.space_cv.wait(lk, [&] { return g_stop || ln.queued_bytes + bytes <= kMaxQueuedBytes || ln.queued_bytes == 0; });
+    ln.queued_bytes += bytes;
+    ln.queue.push_back(std::move(ev));
+    ln.cv.notify_one();
 }
 
 // minimal JSON field extraction for {"lang":"xx","right_context":N}
@@ -116,7 +125,8 @@ struct Session {
     std::vector<int16_t> pending;
 };
 
-void worker_loop(nemo_context *model) {
+void worker_loop(Lane *lane) {
+    nemo_context *model = lane->model;
     std::map<uint32_t, Session> sessions;
     uint64_t n_batches = 0, n_batched_streams = 0;
     auto flush = [&]() {
@@ -147,12 +157,12 @@ void worker_loop(nemo_context *model) {
     for (;;) {
         std::deque<Event> batch;
         {
-            std::unique_lock<std::mutex> lk(g_mtx);
-            g_cv.wait(lk, [] { return g_stop || !g_queue.empty(); });
-            if (g_stop && g_queue.empty()) break;
-            batch.swap(g_queue);                 // take EVERYTHING that is queued: this is the batch former
-            g_queued_bytes = 0;
-            g_space_cv.notify_all();
+            std::unique_lock<std::mutex> lk(lane->mtx);
+            lane->cv.wait(lk, [&] { return g_stop || !lane->queue.empty(); });
+            if (g_stop && lane->queue.empty()) break;
+            batch.swap(lane->queue);             // take EVERYTHING that is queued: this is the batch former
+            lane->queued_bytes = 0;
+            lane->space_cv.notify_all();
         }
         for (Event &ev : batch) {
             auto it = sessions.find(ev.id);
@@ -264,29 +274,45 @@ void reader_loop(int fd) {
 }
 
 int g_listen_fd = -1;
-void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_fd, SHUT_RDWR); g_cv.notify_all(); }
+void wake_lanes() { for (auto &ln : g_lanes) { ln->cv.notify_all(); ln->space_cv.notify_all(); } }
+void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_fd, SHUT_RDWR); wake_lanes(); }
 
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N] [--f32] [--max-streams N]\n", argv[0]);
+        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N]\n"
+                        "  --devices: one engine + worker per listed GPU; stream s is served by entry s mod count\n", argv[0]);
         return 1;
     }
     std::string tcp = "127.0.0.1:8765", unix_path;
-    int device = 0, dtype = 1, max_streams = 64;
+    std::vector<int> devices{0};
+    int dtype = 1, max_streams = 64;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--tcp" && i + 1 < argc) tcp = argv[++i];
         else if (a == "--unix" && i + 1 < argc) unix_path = argv[++i];
         else if (a == "--right-context" && i + 1 < argc) g_default_rc = atoi(argv[++i]);
-        else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+        else if (a == "--device" && i + 1 < argc) devices.assign(1, atoi(argv[++i]));
+        else if (a == "--devices" && i + 1 < argc) {
+            devices.clear();
+            for (const char *p = argv[++i]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+            if (devices.empty()) { fprintf(stderr, "--devices needs a comma-separated list\n"); return 1; }
+        }
         else if (a == "--max-streams" && i + 1 < argc) max_streams = atoi(argv[++i]);
         else if (a == "--f32") dtype = 0;
         else { fprintf(stderr, "Unknown flag: %s\n", a.c_str()); return 1; }
     }
-    nemo_context *model = nemo_init_with_device(argv[1], device, dtype, max_streams);
-    if (!model) { fprintf(stderr, "Failed to load ASR model\n"); return 1; }
+    for (int dev : devices) {
+        std::unique_ptr<Lane> ln(new Lane());
+        ln->model = nemo_init_with_device(argv[1], dev, dtype, max_streams);
+        if (!ln->model) { fprintf(stderr, "Failed to load ASR model on device %d\n", dev); return 1; }
+        g_lanes.push_back(std::move(ln));
+    }
     int fd;
     if (!unix_path.empty()) {
         fd = ::socket(AF_UNIX, SOCK_STREAM, 0);
@@ -312,8 +338,9 @@ int main(int argc, char **argv) {
     g_listen_fd = fd;
     signal(SIGINT, on_signal);
     signal(SIGTERM, on_signal);
-    fprintf(stderr, "listening on %s (default right_context %d, max %d streams)\n", unix_path.empty() ? tcp.c_str() : unix_path.c_str(), g_default_rc, max_streams);
-    std::thread worker(worker_loop, model);
+    fprintf(stderr, "listening on %s (default right_context %d, %zu GPU lane(s), max %d streams each)\n",
+            unix_path.empty() ? tcp.c_str() : unix_path.c_str(), g_default_rc, g_lanes.size(), max_streams);
+    for (auto &ln : g_lanes) ln->worker = std::thread(worker_loop, ln.get());
     while (!g_stop) {
         const int cfd = ::accept(fd, nullptr, nullptr);
         if (cfd < 0) { if (g_stop) break; continue; }
@@ -322,9 +349,8 @@ int main(int argc, char **argv) {
         std::thread(reader_loop, cfd).detach();
     }
     g_stop = true;
-    g_cv.notify_all();
-    worker.join();
-    nemo_free(model);
+    wake_lanes();
+    for (auto &ln : g_lanes) { ln->worker.join(); nemo_free(ln->model); }
     if (!unix_path.empty()) ::unlink(unix_path.c_str());
     return 0;
 }

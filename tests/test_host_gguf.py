@@ -160,7 +160,9 @@ def test_server_batches_streams(tmp_path):
     srv = BIN / "nemo-server-amd"
     assert srv.exists(), "run __graft_entry__.build()"
     path = str(tmp_path / "asr.sock")
-    proc = subprocess.Popen([str(srv), str(model), "--unix", path, "--f32", "--max-streams", "8"], stderr=subprocess.PIPE, text=True)
+    # two lanes (engine + FIFO + worker each) on the one GPU of the test box: stream s is served by lane s mod 2
+    proc = subprocess.Popen([str(srv), str(model), "--unix", path, "--f32", "--max-streams", "8", "--devices", "0,0"],
+                            stderr=subprocess.PIPE, text=True)
     try:
         for _ in range(600):
             if Path(path).exists() or proc.poll() is not None:
