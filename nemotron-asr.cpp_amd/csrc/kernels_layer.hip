@@ -27,14 +27,17 @@ __device__ __forceinline__ float block_sum(float v, float *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// LayerNorm of the 4 elements each thread holds (1024 = 256 x 4), biased variance, eps 1e-5
-__device__ __forceinline__ float4 ln4(float4 v, const float *w, const float *b, int c4, float *sh) {
+// LayerNorm of the 4 elements each thread holds (1024 = 256 x 4), biased variance, eps 1e-5; the affine
+// parameters are passed in so that the caller can load them before the reductions
+__device__ __forceinline__ float4 ln4(float4 v, float4 ww, float4 bb, float *sh) {
     float mean = block_sum((v.x + v.y) + (v.z + v.w), sh) * (1.0f / D);
     float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
     float var = block_sum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh) * (1.0f / D);
     float inv = 1.0f / sqrtf(var + 1e-5f);
-    const float4 ww = *(const float4 *)(w + c4), bb = *(const float4 *)(b + c4);
     return make_float4(dx * inv * ww.x + bb.x, dy * inv * ww.y + bb.y, dz * inv * ww.z + bb.z, dw * inv * ww.w + bb.w);
+}
+__device__ __forceinline__ float4 ln4(float4 v, const float *w, const float *b, int c4, float *sh) {
+    return ln4(v, *(const float4 *)(w + c4), *(const float4 *)(b + c4), sh);
 }
 
 __device__ __forceinline__ void store_act4(void *base, size_t off, float4 v, int bf16) {
@@ -52,20 +55,28 @@ __device__ __forceinline__ void store_act4(void *base, size_t off, float4 v, int
 __global__ __launch_bounds__(256) void k_post(PostParams p) {
     __shared__ float sh[4];
     const int m = blockIdx.x, c4 = threadIdx.x * 4;
+    // every load of the kernel is independent of the arithmetic: issue them all first
     float4 v = *(const float4 *)(p.x + (size_t)m * D + c4);
+    float4 t[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        if (s < p.splits) t[s] = *(const float4 *)(p.part + ((size_t)s * p.M + m) * D + c4);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w1 = z4, b1 = z4, w2 = z4, b2 = z4;
+    if (p.ln_out) { w1 = *(const float4 *)(p.ln1_w + c4); b1 = *(const float4 *)(p.ln1_b + c4); }
+    if (p.ln2_w) { w2 = *(const float4 *)(p.ln2_w + c4); b2 = *(const float4 *)(p.ln2_b + c4); }
     if (p.splits > 0) {
-        float4 o = *(const float4 *)(p.part + (size_t)m * D + c4);
-        for (int s = 1; s < p.splits; s++) {
-            const float4 t = *(const float4 *)(p.part + ((size_t)s * p.M + m) * D + c4);
-            o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-        }
+        float4 o = t[0];
+#pragma unroll
+        for (int s = 1; s < 8; s++)
+            if (s < p.splits) { o.x += t[s].x; o.y += t[s].y; o.z += t[s].z; o.w += t[s].w; }
         v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
     }
-    if (p.ln_out) v = ln4(v, p.ln1_w, p.ln1_b, c4, sh);
+    if (p.ln_out) v = ln4(v, w1, b1, sh);
     if (p.splits > 0 || p.ln_out) *(float4 *)(p.x + (size_t)m * D + c4) = v;
     if (p.copy_out) *(float4 *)(p.copy_out + (size_t)m * D + c4) = v;
     if (p.ln2_w) {
-        float4 a = ln4(v, p.ln2_w, p.ln2_b, c4, sh);
+        float4 a = ln4(v, w2, b2, sh);
         store_act4(p.a_out, (size_t)m * D + c4, a, p.act_bf16);
     }
 }
@@ -301,16 +312,31 @@ __global__ __launch_bounds__(256) void k_dwconv(ConvParams p) {
     float *cc_out = p.cc_pool + (size_t)rd.slot * p.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
     const float *g = p.glu + (size_t)b * T * D;
     // z = [conv cache (ks-1 rows) ; GLU(new T rows)], out[t] = sum_k z[t+k] * w[k]  (:368-388)
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < p.ks; k++) {
-        const int r = i + k;
-        const float4 z = r < ks1 ? *(const float4 *)(cc_in + (size_t)r * D + c4)
-                                 : *(const float4 *)(g + (size_t)(r - ks1) * D + c4);
-        const float4 w = *(const float4 *)(p.dw + (size_t)k * D + c4);
-        if (k == 0) acc = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
-        else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
+    const float4 lw = *(const float4 *)(p.ln_w + c4), lb = *(const float4 *)(p.ln_b + c4);
+    float4 acc;
+    if (p.ks == 9) {           // the model's kernel size: taps unrolled, all 18 loads in flight together
+        float4 z[9], w[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int r = i + k;
+            z[k] = r < 8 ? *(const float4 *)(cc_in + (size_t)r * D + c4) : *(const float4 *)(g + (size_t)(r - 8) * D + c4);
+            w[k] = *(const float4 *)(p.dw + (size_t)k * D + c4);
+        }
+        acc = make_float4(z[0].x * w[0].x, z[0].y * w[0].y, z[0].z * w[0].z, z[0].w * w[0].w);
+#pragma unroll
+        for (int k = 1; k < 9; k++) { acc.x += z[k].x * w[k].x; acc.y += z[k].y * w[k].y; acc.z += z[k].z * w[k].z; acc.w += z[k].w * w[k].w; }
+    } else {
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < p.ks; k++) {
+            const int r = i + k;
+            const float4 z = r < ks1 ? *(const float4 *)(cc_in + (size_t)r * D + c4)
+                                     : *(const float4 *)(g + (size_t)(r - ks1) * D + c4);
+            const float4 w = *(const float4 *)(p.dw + (size_t)k * D + c4);
+            if (k == 0) acc = make_float4(z.x * w.x, z.y * w.y, z.z * w.z, z.w * w.w);
+            else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
+        }
     }
-    float4 n = ln4(acc, p.ln_w, p.ln_b, c4, sh);                                   // :671-673
+    float4 n = ln4(acc, lw, lb, sh);                                               // :671-673
     n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));          // SiLU :674
     n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
     store_act4(p.c_out, ((size_t)b * T + i) * D + c4, n, p.act_bf16);

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,20 @@ static int fail(const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *nasr_last_error(void) { return g_err; }
+
+// Several engines may live in one process, one host thread each (the socket server: one lane per GPU).  HIP stream
+// capture, even in thread-local mode, is broken by what other threads do meanwhile ("operation failed due to a
+// previous error during capture" when another thread copies or allocates).  Every entry point that talks to HIP
+// therefore holds this lock shared; building a step graph (rare: once per (B, T, G)) takes it exclusively.
+static std::shared_mutex g_api_mu;
+struct ApiGuard {
+    ApiGuard() { g_api_mu.lock_shared(); }
+    ~ApiGuard() { g_api_mu.unlock_shared(); }
+};
+struct CaptureExclusive {       // held by a thread that is inside an ApiGuard
+    CaptureExclusive() { g_api_mu.unlock_shared(); g_api_mu.lock(); }
+    ~CaptureExclusive() { g_api_mu.unlock(); g_api_mu.lock_shared(); }
+};
 extern "C" int nasr_abi_version(void) { return NASR_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------
@@ -509,8 +524,10 @@ static int ensure_posproj(nasr_engine *e, int T) {
 }
 
 // ---------------------------------------------------------------------------------------
+static void engine_destroy_impl(nasr_engine *e);
 extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
                                   const nasr_weight_desc *weights, int n_weights, int max_streams) {
+    ApiGuard api_guard;
     if (!out || !hp || !weights) return fail("nasr_engine_create: null argument");
     *out = nullptr;
     if (dtype != NASR_DTYPE_F32 && dtype != NASR_DTYPE_BF16) return fail("unsupported dtype %d", dtype);
@@ -533,7 +550,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
     init_gemm_kernel_attributes();
     init_fused_kernel_attributes();
-    if (load_weights(e, weights, n_weights)) { nasr_engine_destroy(e); return -1; }
+    if (load_weights(e, weights, n_weights)) { engine_destroy_impl(e); return -1; }
 
     const size_t S = (size_t)max_streams, Lr = (size_t)hp->n_layers, ks1 = (size_t)hp->kernel_size - 1;
     e->w_rows = std::max(max_streams * TMAX, MAXNEW);
@@ -575,32 +592,36 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     rc |= dalloc(e, &e->rowmap, M);
     rc |= dalloc(e, &e->tok_frame, S * TOK_CAP);
     rc |= dalloc(e, &e->collect_dev, S * (1 + COLLECT_STRIDE));
-    if (rc) { nasr_engine_destroy(e); return -1; }
+    if (rc) { engine_destroy_impl(e); return -1; }
     e->pin_cap = 8u << 20;
     e->pin_off = 256;
-    if (hipHostMalloc((void **)&e->pin, e->pin_cap, hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&e->pin, e->pin_cap, hipHostMallocDefault) != hipSuccess) { engine_destroy_impl(e); return fail("hipHostMalloc failed"); }
     e->ddesc_cap = 8u << 20;
-    if (hipMalloc((void **)&e->ddesc, e->ddesc_cap) != hipSuccess) { nasr_engine_destroy(e); return fail("hipMalloc desc failed"); }
+    if (hipMalloc((void **)&e->ddesc, e->ddesc_cap) != hipSuccess) { engine_destroy_impl(e); return fail("hipMalloc desc failed"); }
     {
         const size_t off_rows = 0, off_pcm = off_rows + S * sizeof(RowDesc), off_meta = off_pcm + S * sizeof(PcmDesc);
         const size_t off_col = off_meta + 2 * S * sizeof(int), off_act = off_col + S * (1 + COLLECT_STRIDE) * sizeof(int);
         const size_t off_vr = off_act + 64;
-        if (hipHostMalloc((void **)&e->gh, off_vr + M * sizeof(RowDesc), hipHostMallocDefault) != hipSuccess) { nasr_engine_destroy(e); return fail("hipHostMalloc failed"); }
+        if (hipHostMalloc((void **)&e->gh, off_vr + M * sizeof(RowDesc), hipHostMallocDefault) != hipSuccess) { engine_destroy_impl(e); return fail("hipHostMalloc failed"); }
         e->gh_vrows = (RowDesc *)(e->gh + off_vr);
-        if (dalloc(e, &e->g_vrows, M)) { nasr_engine_destroy(e); return -1; }
+        if (dalloc(e, &e->g_vrows, M)) { engine_destroy_impl(e); return -1; }
         e->gh_rows = (RowDesc *)(e->gh + off_rows); e->gh_pcm = (PcmDesc *)(e->gh + off_pcm); e->gh_meta = (int *)(e->gh + off_meta);
         e->gh_collect = (int *)(e->gh + off_col); e->gh_active = (int *)(e->gh + off_act);
-        if (dalloc(e, &e->g_rows, S) || dalloc(e, &e->g_pcm, S) || dalloc(e, &e->g_meta, 2 * S)) { nasr_engine_destroy(e); return -1; }
+        if (dalloc(e, &e->g_rows, S) || dalloc(e, &e->g_pcm, S) || dalloc(e, &e->g_meta, 2 * S)) { engine_destroy_impl(e); return -1; }
     }
     e->slots.assign(S, nullptr);
     e->tap_mel_frames.assign(S, 0);
     e->tap_mel_row.assign(S, 0);
-    if (hipStreamSynchronize(e->st) != hipSuccess) { nasr_engine_destroy(e); return fail("engine init sync failed"); }
+    if (hipStreamSynchronize(e->st) != hipSuccess) { engine_destroy_impl(e); return fail("engine init sync failed"); }
     *out = e;
     return 0;
 }
 
 extern "C" void nasr_engine_destroy(nasr_engine *e) {
+    ApiGuard api_guard;
+    engine_destroy_impl(e);
+}
+static void engine_destroy_impl(nasr_engine *e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->st) hipStreamSynchronize(e->st);
@@ -680,6 +701,7 @@ static int stream_zero_state(nasr_stream *s) {
 }
 
 extern "C" int nasr_stream_create(nasr_engine *e, int right_context, int prompt_index, nasr_stream **out) {
+    ApiGuard api_guard;
     if (!e || !out) return fail("nasr_stream_create: null argument");
     *out = nullptr;
     if (right_context != 0 && right_context != 1 && right_context != 6 && right_context != 13)
@@ -701,6 +723,7 @@ extern "C" int nasr_stream_create(nasr_engine *e, int right_context, int prompt_
 }
 
 extern "C" int nasr_stream_reset(nasr_stream *s) {
+    ApiGuard api_guard;
     if (!s) return fail("null stream");
     HIPCHK(hipSetDevice(s->e->device));
     // NOTE: the reference's reset leaves stale conv-cache/K/V contents in place
@@ -709,6 +732,7 @@ extern "C" int nasr_stream_reset(nasr_stream *s) {
 }
 
 extern "C" int nasr_stream_destroy(nasr_stream *s) {
+    ApiGuard api_guard;
     if (!s) return 0;
     nasr_engine *e = s->e;
     hipSetDevice(e->device);
@@ -1191,6 +1215,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
 }
 
 extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
+    ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
     if (enable && ensure_debug_buffers(e)) return -1;
@@ -1270,7 +1295,10 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
     if (it == e->graphs.end()) {
         HIPCHK(hipStreamSynchronize(e->st));
         hipGraphExec_t ex = nullptr;
-        if (build_step_graph(e, B, T, R, G, &ex)) return -1;
+        {
+            CaptureExclusive alone;
+            if (build_step_graph(e, B, T, R, G, &ex)) return -1;
+        }
         it = e->graphs.emplace(key, ex).first;
     }
     for (int b = 0; b < B; b++) {
@@ -1400,6 +1428,7 @@ static int push_piece(nasr_engine *e, nasr_stream *const *streams, int B, const 
 extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm,
                                 const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap,
                                 int32_t *n_tokens, uint32_t flags) {
+    ApiGuard api_guard;
     if (validate_batch(e, streams, B)) return -1;
     if (!pcm || !n_samples) return fail("null pcm / n_samples");
     HIPCHK(hipSetDevice(e->device));
@@ -1466,6 +1495,7 @@ extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int
 extern "C" int nasr_engine_step_mel(nasr_engine *e, nasr_stream *const *streams, int B, const float *const *mel,
                                     const int32_t *n_frames, int32_t *const *tokens_out, const int32_t *tokens_cap,
                                     int32_t *n_tokens, uint32_t flags) {
+    ApiGuard api_guard;
     if (validate_batch(e, streams, B)) return -1;
     if (!mel || !n_frames) return fail("null mel / n_frames");
     HIPCHK(hipSetDevice(e->device));
@@ -1516,6 +1546,7 @@ extern "C" int nasr_engine_step_mel(nasr_engine *e, nasr_stream *const *streams,
 
 extern "C" int nasr_engine_finalize(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
                                     const int32_t *tokens_cap, int32_t *n_tokens) {
+    ApiGuard api_guard;
     if (validate_batch(e, streams, B)) return -1;
     HIPCHK(hipSetDevice(e->device));
     // src/nemo-stream.cpp:1234-1258: frames > 9 -> n_valid = (frames-9)/8 outputs of one zero-padded step
@@ -1553,12 +1584,14 @@ extern "C" int nasr_engine_finalize(nasr_engine *e, nasr_stream *const *streams,
 
 extern "C" int nasr_engine_collect(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
                                    const int32_t *tokens_cap, int32_t *n_tokens) {
+    ApiGuard api_guard;
     if (validate_batch(e, streams, B)) return -1;
     HIPCHK(hipSetDevice(e->device));
     return collect_tokens(e, streams, B, tokens_out, tokens_cap, n_tokens);
 }
 
 extern "C" int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first, int32_t count, int32_t *frames_out) {
+    ApiGuard api_guard;
     if (!s || (count > 0 && !frames_out)) return fail("null argument");
     if (first < 0 || count < 0) return fail("negative token range");
     nasr_engine *e = s->e;
@@ -1576,6 +1609,7 @@ extern "C" int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first,
 }
 
 extern "C" int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out) {
+    ApiGuard api_guard;
     if (!s || !out) return fail("null argument");
     nasr_engine *e = s->e;
     HIPCHK(hipSetDevice(e->device));
@@ -1593,6 +1627,7 @@ extern "C" int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *ou
 }
 
 extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, float *out, int64_t cap) {
+    ApiGuard api_guard;
     if (!s || !out) return fail("null argument");
     nasr_engine *e = s->e;
     HIPCHK(hipSetDevice(e->device));
@@ -1665,6 +1700,7 @@ extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, flo
 }
 
 extern "C" int nasr_engine_profile(nasr_engine *e, int enable) {
+    ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
     prof_flush(e);
@@ -1674,6 +1710,7 @@ extern "C" int nasr_engine_profile(nasr_engine *e, int enable) {
 }
 
 extern "C" int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, int cap) {
+    ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
     prof_flush(e);
@@ -1689,24 +1726,28 @@ extern "C" int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, i
 extern "C" void *nasr_engine_hip_stream(nasr_engine *e) { return e ? (void *)e->st : nullptr; }
 
 extern "C" int nasr_device_alloc(nasr_engine *e, void **out, int64_t bytes) {
+    ApiGuard api_guard;
     if (!e || !out || bytes <= 0) return fail("bad argument");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMalloc(out, (size_t)bytes));
     return 0;
 }
 extern "C" int nasr_device_free(nasr_engine *e, void *p) {
+    ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipFree(p));
     return 0;
 }
 extern "C" int nasr_device_upload(nasr_engine *e, void *dst, const void *src, int64_t bytes) {
+    ApiGuard api_guard;
     if (!e || !dst || !src) return fail("bad argument");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
     return 0;
 }
 extern "C" int nasr_engine_synchronize(nasr_engine *e) {
+    ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->st));

@@ -221,6 +221,10 @@ def test_server_batches_streams(tmp_path):
         assert op == 0x8F and b"language" in payload
         for c in conns:
             c.close()
+    except BaseException:
+        proc.terminate()
+        print("server stderr:\n" + proc.stderr.read())
+        raise
     finally:
         proc.terminate()
         try:
