@@ -11,8 +11,13 @@
  * Conventions
  *   - every function returns 0 on success, <0 on error; nasr_last_error() gives the text
  *     (reference convention: nullptr/false/"" + fprintf(stderr); we never abort or throw)
- *   - not thread-safe: one host thread per engine (reference: one worker thread owns all
- *     backend state, src/nemo-server.cpp:6-10); one engine per GPU
+ *   - an engine and its streams belong to ONE host thread (reference: one worker thread owns all
+ *     backend state, src/nemo-server.cpp:6-10); one engine per GPU.  Several engines may live in
+ *     one process, each on its own thread (the calls are serialised only while a step graph is
+ *     being captured); nasr_last_error() is per thread
+ *   - a push may carry any number of samples: when it completes several chunks of a stream they
+ *     run as one launch sequence (up to 256 encoder frames per stream), with the results of
+ *     chunk-by-chunk calls
  *   - PCM is s16le 16 kHz mono (src/transcribe_stream.cpp:13); mel is [frames][128] f32
  *     row-major (src/preprocessor.cpp:370-381); encoder out is [T][1024] f32
  *     (src/nemo-stream.cpp:1073-1075); tokens are int32 ids in [0, vocab-1)
