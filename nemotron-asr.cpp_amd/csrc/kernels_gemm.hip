@@ -27,12 +27,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // ------------------------------------------------------------------------------------
-// skinny: M <= 16*MT.  grid = (N/16, splits), block = 256 (4 waves split K).
+// skinny: weight-streaming, 16 output columns x (16*MT rows) per workgroup.  grid = (N/16, splits, slabs of
+// 16*MT rows), block = 256 (4 waves split K).  Used up to a few hundred rows: there the 128x128 tiles of the
+// large-M kernel would leave most CUs idle (M = 128 -> 32 tiles), while here every slab re-reads its 32 KiB of
+// weights from L2 and all CUs stream.
 // ------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
     __shared__ float red[4][MT][64][4];
-    const int nt = blockIdx.x, split = blockIdx.y;
+    const int nt = blockIdx.x, split = blockIdx.y, m_base = blockIdx.z * 16 * MT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = lane >> 4, r = lane & 15;
     const int KT = p.K >> 5;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
     const char *arow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        int m = mt * 16 + r;
+        int m = m_base + mt * 16 + r;
         arow[mt] = a_row_ptr(p, m < p.M ? m : p.M - 1, 2) + q * 16;
     }
     f32x4 acc[MT];
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             v[j] = ((red[0][wave][lane][j] + red[1][wave][lane][j]) + red[2][wave][lane][j]) + red[3][wave][lane][j];
-        epi_quad<true>(p, split, wave * 16 + r, nt * 16 + q * 4, v[0], v[1], v[2], v[3]);
+        epi_quad<true>(p, split, m_base + wave * 16 + r, nt * 16 + q * 4, v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -301,11 +304,16 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_tiled2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
 }
 
+int gemm_skinny_max_m() {
+    static const int v = getenv("NASR_SKINNY_MAXM") ? atoi(getenv("NASR_SKINNY_MAXM")) : 128;   // measured: 128 rows 3.94 vs 4.36 ms per step, 256 rows 4.40 vs 3.88
+    return v;
+}
+
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     if (p.splits < 1) p.splits = 1;
-    if (p.M <= 64) {
-        dim3 grid(p.N / 16, p.splits);
+    if (p.M <= gemm_skinny_max_m()) {
+        dim3 grid(p.N / 16, p.splits, (p.M + 63) / 64);
         if (p.M <= 16) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, st, p);
         else if (p.M <= 32) hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_gemm_skinny<4>, grid, dim3(256), 0, st, p);

@@ -178,8 +178,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
         else ((float *)p.ctx_out)[o] = acc;
     }
 }
-// ---- attention on the matrix cores (bf16, 4 <= T <= 16): one workgroup per (head, stream) ----------
-// scores^T tiles  S[j][i] = K[j].(q_i+u)   (A = 16 cached keys straight from the ring, B = queries)
+// ---- attention on the matrix cores (bf16, T <= 16): one workgroup per (head, stream, group of query rows) ----
+// A workgroup takes QB consecutive rows of a stream: one chunk (QB = T) for T >= 4, sixteen rows = 16/T chunks for
+// T <= 2 (multi-chunk steps at 80/160 ms lookahead).  Its keys are the SPAN of ring rows those rows can see:
+// 70 + (chunks in the group) * T <= 86 rows; row (chunk g, frame i) attends the window of 70 + T keys that starts
+// (g - g0) * T rows into the span, everything else gets weight 0.
+// scores^T tiles  S[j][i] = K[j].(q_i+u)   (A = 16 span keys straight from the ring, B = queries)
 // pos-score tiles P[r][i] = Pp[r].(q_i+v)  for every relative row r, rel-shift = an LDS gather
 // context^T       O[d][i] = sum_j V^T[d][j] w[i][j]   (V tile transposed into LDS once per workgroup)
 // q+u / q+v and the softmax weights are rounded to bf16 for the MFMA (two extra rounding points vs the
@@ -191,11 +195,15 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char qu_s[16 * 256], qv_s[16 * 256], w_s[16 * 256];
     __shared__ __attribute__((aligned(16))) char vt_s[128 * 256];
     __shared__ float sk[16 * 96], sp[16 * 112];
-    const int h = blockIdx.x, b = blockIdx.y, g = blockIdx.z, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
+    const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
     const int TS = p.TS > 0 ? p.TS : p.T;
+    const int QB = T <= 2 ? 16 : T;                          // query rows per workgroup
+    const int r0 = blockIdx.z * QB, nrows = TS - r0 < QB ? TS - r0 : QB;
+    const int g0 = r0 / T;                                   // first chunk of the group
+    const int span = LCTX + ((nrows + T - 1) / T) * T;       // ring rows the group can see (<= 86 < 96)
     const RowDesc rd = p.rows[b];
-    const size_t row0 = (size_t)b * TS + (size_t)g * T;      // chunk g of a multi-chunk step (see k_attention)
-    int head0 = rd.kv_head + g * T;
+    const size_t row0 = (size_t)b * TS + (size_t)r0;
+    int head0 = rd.kv_head + g0 * T;
     while (head0 >= KVC) head0 -= KVC;
     const bf16_t *kbase = (const bf16_t *)p.kv_pool + (size_t)rd.slot * p.kv_slot_stride + h * DH;
     const bf16_t *vbase = kbase + (size_t)KVC * D;
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     // ---- phase 0: queries (+u, +v) -> bf16 LDS; V tile -> transposed LDS (zero padded to 96 keys) ----
     for (int e = threadIdx.x; e < 16 * DH; e += 256) {
         const int i = e >> 7, d = e & 127;
-        const float qq = i < T ? p.q[(row0 + i) * D + h * DH + d] : 0.0f;
+        const float qq = i < nrows ? p.q[(row0 + i) * D + h * DH + d] : 0.0f;
         const int off = i * 256 + ((((d >> 3) ^ i) & 15) << 4) + (d & 7) * 2;
         *(bf16_t *)(qu_s + off) = f32_to_bf16(qq + p.bias_u[h * DH + d]);
         *(bf16_t *)(qv_s + off) = f32_to_bf16(qq + p.bias_v[h * DH + d]);
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     for (int e = threadIdx.x; e < 96 * 16; e += 256) {
         const int c = e & 15, j = e >> 4;               // 8 consecutive d of key j
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (j < KV) {
+        if (j < span) {
             int ring = head0 + j;
             if (ring >= KVC) ring -= KVC;
             v = *(const uint4 *)(vbase + (size_t)ring * D + c * 8);
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         const bf16_t *arow;
         if (isk) {
             int j = t * 16 + r;
-            if (j >= KV) j = KV - 1;
+            if (j >= span) j = span - 1;
             int ring = head0 + j;
             if (ring >= KVC) ring -= KVC;
             arow = kbase + (size_t)ring * D;
@@ -256,23 +264,26 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         *(float4 *)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
-    // ---- phase 2: rel-shift gather + mask + softmax -> bf16 weights (zero padded to 128 keys) ---------
+    // ---- phase 2: rel-shift gather + mask + softmax -> bf16 weights over the span (zero outside the row's window) ----
     const float scale = 0.08838834764831845f;
-    const int mask_upto = LCTX - (rd.valid_len + g * T < LCTX ? rd.valid_len + g * T : LCTX);
     for (int i = wave; i < 16; i += 4) {
+        const int il = r0 + i, g = il / T, ic = il - g * T;      // (chunk, frame in chunk) of this row
+        const int wo = (g - g0) * T;                             // its window starts wo rows into the span
+        const int valid = rd.valid_len + g * T < LCTX ? rd.valid_len + g * T : LCTX;
+        const int mask_upto = LCTX - valid;
+        const int j0 = lane - wo, j1 = lane + 64 - wo;           // window index of span positions lane, lane + 64
+        const bool in0 = i < nrows && j0 >= 0 && j0 < KV, in1 = i < nrows && j1 >= 0 && j1 < KV;
         float v0 = -INFINITY, v1 = -INFINITY;
-        if (i < T) {
-            if (lane < KV) { v0 = (sk[i * 96 + lane] + sp[i * 112 + lane + T - 1 - i]) * scale; if (lane < mask_upto) v0 += -1e9f; }
-            if (lane + 64 < KV) { v1 = (sk[i * 96 + lane + 64] + sp[i * 112 + lane + 64 + T - 1 - i]) * scale; if (lane + 64 < mask_upto) v1 += -1e9f; }
-        }
+        if (in0) { v0 = (sk[i * 96 + lane] + sp[i * 112 + j0 + T - 1 - ic]) * scale; if (j0 < mask_upto) v0 += -1e9f; }
+        if (in1) { v1 = (sk[i * 96 + lane + 64] + sp[i * 112 + j1 + T - 1 - ic]) * scale; if (j1 < mask_upto) v1 += -1e9f; }
         const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = (i < T && lane < KV) ? __expf(v0 - mx) : 0.0f;
-        const float e1 = (i < T && lane + 64 < KV) ? __expf(v1 - mx) : 0.0f;
+        const float e0 = in0 ? __expf(v0 - mx) : 0.0f;
+        const float e1 = in1 ? __expf(v1 - mx) : 0.0f;
         const float sum = wave_sum(e0 + e1);
-        const float inv = i < T ? 1.0f / sum : 0.0f;
-        const int j0 = lane, j1 = lane + 64;
-        *(bf16_t *)(w_s + i * 256 + ((((j0 >> 3) ^ i) & 15) << 4) + (j0 & 7) * 2) = f32_to_bf16(e0 * inv);
-        *(bf16_t *)(w_s + i * 256 + ((((j1 >> 3) ^ i) & 15) << 4) + (j1 & 7) * 2) = f32_to_bf16(e1 * inv);
+        const float inv = i < nrows ? 1.0f / sum : 0.0f;
+        const int p0 = lane, p1 = lane + 64;
+        *(bf16_t *)(w_s + i * 256 + ((((p0 >> 3) ^ i) & 15) << 4) + (p0 & 7) * 2) = f32_to_bf16(e0 * inv);
+        *(bf16_t *)(w_s + i * 256 + ((((p1 >> 3) ^ i) & 15) << 4) + (p1 & 7) * 2) = f32_to_bf16(e1 * inv);
     }
     __syncthreads();
     // ---- phase 3: O^T[d][i] = V^T . w^T, 8 d-tiles x 3 k-steps ---------------------------------------
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
             const uint4 bv = *(const uint4 *)(w_s + r * 256 + (((((ks << 2) | q) ^ r) & 15) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
         }
-        if (r < T) {   // D[d][i]: lane holds query i = r, d = dt*16 + 4q + reg
+        if (r < nrows) {   // D[d][i]: lane holds query i = r, d = dt*16 + 4q + reg
             uint2 o;
             o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
             o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
@@ -295,10 +306,14 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
 }
 
 void launch_attention(const AttnParams &p, hipStream_t st) {
-    const int G = p.TS > 0 ? p.TS / p.T : 1;
-    const dim3 grid(NH, p.B, G);
-    if (p.act_bf16 && p.T >= 4 && p.T <= 16) hipLaunchKernelGGL(k_attention_mfma, grid, dim3(256), 0, st, p);
-    else if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, grid, dim3(256), 0, st, p);
+    const int TS = p.TS > 0 ? p.TS : p.T;
+    if (p.act_bf16 && p.T <= 16) {
+        const int QB = p.T <= 2 ? 16 : p.T;
+        hipLaunchKernelGGL(k_attention_mfma, dim3(NH, p.B, (TS + QB - 1) / QB), dim3(256), 0, st, p);
+        return;
+    }
+    const dim3 grid(NH, p.B, TS / p.T);
+    if (p.act_bf16) hipLaunchKernelGGL(k_attention<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_attention<false>, grid, dim3(256), 0, st, p);
 }
 

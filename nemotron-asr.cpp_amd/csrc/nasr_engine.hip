@@ -758,7 +758,7 @@ static double gemm_bytes(const nasr_engine *e, int M, int N, int K, int wesz) {
 static int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
     (void)tag;
     const bool use_bf16 = e->bf16 && !f32_weights;
-    const char *name = !use_bf16 ? "k_gemm_f32" : (g.M <= 64 ? "k_gemm_skinny" : "k_gemm_tiled");
+    const char *name = !use_bf16 ? "k_gemm_f32" : (g.M <= gemm_skinny_max_m() ? "k_gemm_skinny" : "k_gemm_tiled");
     ProfScope ps(e, name, gemm_bytes(e, g.M, g.N, g.K, use_bf16 ? 2 : 4), 2.0 * g.M * g.N * g.K);
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);
@@ -768,8 +768,9 @@ static int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char 
 // residual GEMM: part = A.W^T (split-K), followed by k_post
 static int pick_splits(const nasr_engine *e, int M, int N, int K) {
     if (!e->bf16) return 1;
-    int tasks = (M <= 64) ? N / 16 : (N / 128) * ((M + 127) / 128);
-    if (M > 64) return tasks < 128 ? 4 : (tasks < 256 ? 2 : 1);   // partial traffic grows with M
+    const bool skinny = M <= gemm_skinny_max_m();
+    int tasks = skinny ? (N / 16) * ((M + 63) / 64) : (N / 128) * ((M + 127) / 128);
+    if (!skinny) return tasks < 128 ? 4 : (tasks < 256 ? 2 : 1);   // partial traffic grows with M
     int s = 1;
     while (s < 8 && tasks * s < 256 && (K / 32) / (s * 2) >= 4) s *= 2;
     return s;

@@ -113,6 +113,7 @@ struct GemmParams {
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
 void init_gemm_kernel_attributes();    // one-time hipFuncSetAttribute calls (never inside a stream capture)
 void init_fused_kernel_attributes();
+int gemm_skinny_max_m();     // largest M served by the weight-streaming kernel
 void launch_gemm_bf16(const GemmParams &p, hipStream_t st);
 void launch_gemm_f32(const GemmParams &p, hipStream_t st);
 void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st);
