@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--right-context", type=int, default=0, choices=[0, 1, 6, 13])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--weights", default="f32", choices=["f32", "f16", "q8_0", "q4_0"],
+                    help="GGUF tensor type of the encoder matrices handed to the engine (reference flavours, "
+                         "scripts/convert_to_gguf.py:246-263); they are dequantised at upload (bf16 MFMA operands)")
     ap.add_argument("--chunks-per-step", type=int, default=1,
                     help="audio pushed per step, in chunks: > 1 = buffered / file transcription (several chunks of a stream "
                          "go through the layers as one launch sequence)")
@@ -101,7 +104,11 @@ def main():
     W = synth.make_weights(n_layers=args.layers)
     t_weights = time.time() - t0
     dtype = capi.DTYPE_BF16 if args.dtype == "bf16" else capi.DTYPE_F32
-    eng = capi.Engine(W, n_layers=args.layers, dtype=dtype, max_streams=B, device=local_rank)
+    engW = W
+    if args.weights != "f32":
+        engW, W = synth.quantize_weights(W, args.weights)     # engine gets the packed blocks, the CPU baseline their values
+    eng = capi.Engine(engW, n_layers=args.layers, dtype=dtype, max_streams=B, device=local_rank)
+    del engW
     streams = [eng.stream(R) for _ in range(B)]
     # PCM for every step, resident in HBM before timing starts.  Extra steps for the profile pass.
     prof_steps = 0 if args.no_profile_pass else min(args.steps, 50)
@@ -247,7 +254,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}, batch={B} stream(s)/GPU, "
+                "workload": f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}"
+                            + (f" from {args.weights.upper()} tensors" if args.weights != "f32" else "") + f", batch={B} stream(s)/GPU, "
                             f"{80 * T} ms lookahead (R={R}), {world}xMI355X"
                             + (f", {args.chunks_per_step} chunks pushed per step" if args.chunks_per_step > 1 else "")
                             + (" [BASELINE.json configs[1]]" if (B, R, args.dtype, args.layers, args.chunks_per_step) == (1, 0, "bf16", 24, 1) else ""),
