@@ -340,6 +340,70 @@ def test_decode_many_rows_tokens_f32(W, om32):
     eng.close()
 
 
+def test_full_size_24_layers():
+    """BASELINE.json's model size (24 layers, 1.2 GB of bf16 matrices).  (i) f32 engine vs f32 oracle on 2.4 s of PCM at
+    R = 0 and R = 13: same tokens, frames, chunk counts, encoder output within the reference ladder scaled to 24
+    layers.  (ii) size-independent properties of the bf16 engine at full size: a stream inside a batch of 8 == the
+    same stream alone; one 30-chunk push == 30 one-chunk pushes (leading tokens, cache state, last encoder row)."""
+    L = 24
+    W24 = synth.make_weights(n_layers=L)
+    om = ob.OracleModel(W24, L)
+    eng = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_F32, max_streams=1)
+    eng.set_debug(True)
+    pcm = synth.make_pcm(5, 2.4)
+    n_tok = 0
+    for R in (0, 13):
+        st, ost = eng.stream(R), ob.OracleStream(om, R)
+        taps = ost.enable_taps()
+        n = synth.shift_samples(R)
+        tg, to, worst = [], [], 0.0
+        for o in range(0, pcm.size, n):
+            tg += eng.step([st], [pcm[o:o + n]])[0]
+            c0 = ost.total_chunks
+            to += ost.process(pcm[o:o + n])
+            if ost.total_chunks > c0:
+                got = st.tap(capi.TAP_LAYER_OUT, L - 1).reshape(-1, 1024)
+                worst = max(worst, float(np.abs(got - taps[1][L - 1][:got.shape[0]]).max()))
+        tg += eng.finalize([st])[0]
+        to += ost.finalize()
+        assert tg == to and st.token_frames() == ost.token_frames() and st.stats().chunks == ost.total_chunks
+        assert worst < 5e-3, worst
+        n_tok += len(to)
+        st.destroy()
+    eng.close()
+    del om
+    engb = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=8)
+    pcms = [synth.make_pcm(300 + b, 2.4) for b in range(8)]
+    sts = [engb.stream(0) for _ in range(8)]
+    bat = [[] for _ in range(8)]
+    for o in range(0, pcms[0].size, 1280):
+        for b, t in enumerate(engb.step(sts, [p[o:o + 1280] for p in pcms])):
+            bat[b] += t
+    enc_b = sts[5].tap(capi.TAP_ENCODER_OUT).reshape(-1, 1024)[-1].copy()
+    cache_b = sts[5].tap(capi.TAP_K_CACHE, L - 1)
+    for s in sts:
+        s.destroy()
+    solo, st = [], engb.stream(0)
+    for o in range(0, pcms[5].size, 1280):
+        solo += engb.step([st], [pcms[5][o:o + 1280]])[0]
+    enc_s = st.tap(capi.TAP_ENCODER_OUT).reshape(-1, 1024)[-1].copy()
+    # batch of 8 runs the unfused layer, the single stream the fused one: same math, different bf16 re-rounding over
+    # 24 layers; K rows are not LayerNorm-scaled (|k| up to ~4, bf16 ulp 0.03 there)
+    assert np.abs(enc_s - enc_b).max() < 3e-2 and np.abs(st.tap(capi.TAP_K_CACHE, L - 1) - cache_b).max() < 1e-1
+    assert solo[:4] == bat[5][:4]
+    st.reset()
+    many = st and engb.step([st], [pcms[5][:1280 * 30]])[0]
+    enc_m = st.tap(capi.TAP_ENCODER_OUT).reshape(-1, 1024)[-1].copy()
+    st.reset()
+    one = []
+    for o in range(0, 1280 * 30, 1280):
+        one += engb.step([st], [pcms[5][o:o + 1280]])[0]
+    enc_o = st.tap(capi.TAP_ENCODER_OUT).reshape(-1, 1024)[-1].copy()
+    assert np.abs(enc_m - enc_o).max() < 3e-2 and many[:4] == one[:4]
+    assert st.stats().cache_valid_len == 30 or st.stats().cache_valid_len == 29
+    engb.close()
+
+
 def test_multilingual_prompt_fusion_f32():
     """a-11 (src/nemo-ggml.cpp:1087-1105): ReLU([enc; onehot(lang)] W1 + b1) W2 + b2 between the last layer and the
     joint.  Two streams with different prompts in one launch, a language switch mid-stream, an out-of-range index
