@@ -15,6 +15,7 @@
 // The GEMM body / weight layout / epilogues are those of k_gemm_skinny (kernels_gemm.hip).
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
+#include "nasr_wave.h"
 
 namespace nasr {
 
@@ -22,16 +23,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-__device__ __forceinline__ float wsum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wmax_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ float wsum_f(float v) { return wave_sum(v); }
+__device__ __forceinline__ float wmax_f(float v) { return wave_max(v); }
 
 // LDS A panel: [16 rows][KP] bf16, 16-byte chunks XOR-swizzled with the row so that the MFMA
 // B-fragment read (16 rows x same chunk) is bank-conflict free.
@@ -68,19 +61,19 @@ __device__ __forceinline__ void wave_ln(float4 v[4], const float *w, const float
     }
 }
 
-// sum over the 256-thread block; sh = 4 floats of LDS scratch
+// sum over the 256-thread block; sh = 4 floats of LDS scratch that the previous bsum did not use (two halves
+// alternate: one barrier per sum, see block_sum in kernels_layer.hip)
 __device__ __forceinline__ float bsum(float v, float *sh) {
     v = wsum_f(v);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-// LayerNorm of one 1024-row spread over the block (4 channels per thread), weights already loaded
+// LayerNorm of one 1024-row spread over the block (4 channels per thread), weights already loaded; sh = 8 floats
 __device__ __forceinline__ float4 block_ln(float4 v, float4 ww, float4 bb, float *sh) {
     const float mean = bsum((v.x + v.y) + (v.z + v.w), sh) * (1.0f / D);
     const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-    const float var = bsum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh) * (1.0f / D);
+    const float var = bsum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh + 4) * (1.0f / D);
     const float inv = 1.0f / sqrtf(var + 1e-5f);
     return make_float4(dx * inv * ww.x + bb.x, dy * inv * ww.y + bb.y, dz * inv * ww.z + bb.z, dw * inv * ww.w + bb.w);
 }
@@ -104,6 +97,17 @@ __device__ __forceinline__ float dot32(const float *qs, const void *row) {   // 
     return s;
 }
 
+#ifdef NASR_STAMPS
+// diagnostic build (never shipped): wave 0 of the first and of the last workgroup stamp the 100 MHz real-time counter
+#define STAMP(i)                                                                                                         \
+    do {                                                                                                                 \
+        if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))          \
+            p.stamps[(blockIdx.x == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memrealtime();                                \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <int PRO>
 __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     char *panel = smem + 4096;                     // [16][KP] bf16
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
     const int M = g.M;
+    STAMP(0);
 
     // The weight stream does not depend on the prologue: issue this wave's tiles (<= 8 KiB) first so
     // the HBM latency runs under the prologue.
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
         wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
     }
+    STAMP(1);
 
     if (PRO == PRO_LN && M <= 2) {
         // block-per-row: every global load of the prologue is issued up front (one memory round trip)
@@ -159,9 +165,11 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
                         if (sI < p.part_splits) { o.x += t[m][sI].x; o.y += t[m][sI].y; o.z += t[m][sI].z; o.w += t[m][sI].w; }
                     v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
                 }
+                STAMP(2);
                 if (p.lno_w) v = block_ln(v, ow, ob, red);                 // previous layer's norm_out (:687)
                 if (writer && p.x_out) *(float4 *)(p.x_out + (size_t)m * D + c4) = v;
                 v = block_ln(v, lw, lb, red);
+                STAMP(3);
                 store4_panel(panel, m, c4, KP, v.x, v.y, v.z, v.w);
             }
         }
@@ -216,35 +224,44 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         }
         __syncthreads();
     } else if (PRO == PRO_ATTN) {
-        // one head (= split) of the cached rel-pos attention for all M rows (src/nemo-stream.cpp:463-573)
+        // one head (= split) of the cached rel-pos attention for all M <= 2 rows (src/nemo-stream.cpp:463-573).
+        // For the first 128 (row, key) pairs and for row 0 -- all there is at M = 1 -- everything the arithmetic needs
+        // is requested up front, in two memory round trips instead of five: (a) row descriptors, queries,
+        // relative-position rows; (b) once the descriptors are in, the K and V ring rows.  A second row (M = 2) is
+        // handled by a second pass that loads as it goes (keeps the kernel under the register limit).
         const AttnParams &a = p.at;
         const int h = split, T = a.T, KV = LCTX + T, TS = a.TS > 0 ? a.TS : a.T;
-        float *qu = (float *)(panel + 16 * KP * 2);                  // [16][128]
-        float *qv = qu + 16 * DH;                                    // [16][128]
-        float *sc = qv + 16 * DH;                                    // [16][KVC]
-        for (int e = threadIdx.x; e < M * DH; e += 256) {
-            const int m = e >> 7, d = e & 127;
-            const float qq = a.q[(size_t)m * D + h * DH + d];
-            qu[e] = qq + a.bias_u[h * DH + d];
-            qv[e] = qq + a.bias_v[h * DH + d];
-        }
-        __syncthreads();
+        float *qu = (float *)(panel + 16 * KP * 2);                  // [2][128]
+        float *qv = qu + 16 * DH;                                    // [2][128]
+        float *sc = qv + 16 * DH;                                    // [2][KVC]
+        const int sub = threadIdx.x & 1;                             // 2 lanes per (row, key) pair, 64 dims each
+        const int npair = M * KV;                                    // <= 144: at most two passes of 128 pairs
         const float scale = 0.08838834764831845f;
-        const int sub = threadIdx.x & 1;                     // 2 lanes per (row, key) pair, 64 dims each
-        for (int pr = threadIdx.x >> 1; pr < ((M * KV + 127) & ~127); pr += 128) {   // uniform trip count
-            const bool ok = pr < M * KV;
-            const int m = ok ? pr / KV : 0, j = ok ? pr - m * KV : 0;
-            // row m = (stream b, chunk g of this launch, frame i); its key window starts g*T rows later
-            const int b = m / TS, il = m - b * TS, gch = il / T, i = il - gch * T;
-            const RowDesc rd = a.rows[b];
+        float qq = 0.f, bu = 0.f, bv = 0.f;
+        if ((int)threadIdx.x < M * DH) {
+            const int m = threadIdx.x >> 7, d = threadIdx.x & 127;
+            qq = a.q[(size_t)m * D + h * DH + d]; bu = a.bias_u[h * DH + d]; bv = a.bias_v[h * DH + d];
+        }
+        RowDesc rds[2];
+        rds[0] = a.rows[0];
+        rds[1] = a.rows[(M - 1) / TS];                               // stream of row 1 (= stream 0 unless B = 2)
+        auto pair_rows = [&](int pr, int &m, int &j, const bf16_t *&prow) {
+            const bool ok = pr < npair;
+            m = ok ? pr / KV : 0;
+            j = ok ? pr - m * KV : 0;
+            const int il = m - (m / TS) * TS, gch = il / T, i = il - gch * T;
+            prow = (const bf16_t *)a.posproj + (size_t)(j + T - 1 - i) * D + h * DH + sub * 64;
+            return ok;
+        };
+        auto key_row = [&](int m, int j) {
+            const int b = m / TS, gch = (m - b * TS) / T;
+            const RowDesc rd = b == 0 ? rds[0] : rds[1];
             int ring = rd.kv_head + gch * T + j;
             if (ring >= KVC) ring -= KVC;
             if (ring >= KVC) ring -= KVC;
-            const bf16_t *krow = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)ring * D + h * DH + sub * 64;
-            const bf16_t *prow = (const bf16_t *)a.posproj + (size_t)(j + T - 1 - i) * D + h * DH + sub * 64;
-            uint4 kk[8], pp[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) { kk[c] = ((const uint4 *)krow)[c]; pp[c] = ((const uint4 *)prow)[c]; }
+            return (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)ring * D + h * DH + sub * 64;
+        };
+        auto score = [&](const uint4 *kk, const uint4 *pp, int m, int j, bool ok) {
             const float *qa = qu + m * DH + sub * 64, *qb = qv + m * DH + sub * 64;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -259,13 +276,53 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
                 }
             }
             float v = s1 + s2;
-            v += __shfl_xor(v, 1);
+            v += dpp_mov<0xB1>(v);                                   // the other half of the pair (lane ^ 1)
             if (ok && sub == 0) {
+                const int b = m / TS, gch = (m - b * TS) / T;
+                const RowDesc rd = b == 0 ? rds[0] : rds[1];
                 v *= scale;
                 const int valid = rd.valid_len + gch * T < LCTX ? rd.valid_len + gch * T : LCTX;
                 if (j < LCTX - valid) v += -1e9f;
                 sc[m * KVC + j] = v;
             }
+        };
+        auto value_rows = [&](int m, uint2 *vv) {
+            const int b = m / TS, gch = (m - b * TS) / T;
+            const RowDesc rd = b == 0 ? rds[0] : rds[1];
+            const int head0 = rd.kv_head + gch * T;
+            const bf16_t *vbase = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)KVC * D + h * DH + (threadIdx.x & 31) * 4;
+#pragma unroll
+            for (int u = 0; u < 11; u++) {                           // KV <= 84 -> at most 11 keys per group
+                const int jj = (threadIdx.x >> 5) + 8 * u;
+                int ring = head0 + (jj < KV ? jj : 0);
+                if (ring >= KVC) ring -= KVC;
+                if (ring >= KVC) ring -= KVC;
+                vv[u] = *(const uint2 *)(vbase + (size_t)ring * D);
+            }
+        };
+        // (a) + (b) for pass 0 / row 0
+        int m0, j0;
+        const bf16_t *prow0;
+        const bool ok0 = pair_rows(threadIdx.x >> 1, m0, j0, prow0);
+        uint4 kk[8], pp[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) pp[c] = ((const uint4 *)prow0)[c];
+        const bf16_t *krow0 = key_row(m0, j0);
+#pragma unroll
+        for (int c = 0; c < 8; c++) kk[c] = ((const uint4 *)krow0)[c];
+        uint2 vv[11];
+        value_rows(0, vv);
+        if ((int)threadIdx.x < M * DH) { qu[threadIdx.x] = qq + bu; qv[threadIdx.x] = qq + bv; }
+        __syncthreads();
+        score(kk, pp, m0, j0, ok0);
+        if (npair > 128) {                                           // M = 2: the remaining pairs
+            int m1, j1;
+            const bf16_t *prow1;
+            const bool ok1 = pair_rows(128 + (threadIdx.x >> 1), m1, j1, prow1);
+            const bf16_t *krow1 = key_row(m1, j1);
+#pragma unroll
+            for (int c = 0; c < 8; c++) { pp[c] = ((const uint4 *)prow1)[c]; kk[c] = ((const uint4 *)krow1)[c]; }
+            score(kk, pp, m1, j1, ok1);
         }
         __syncthreads();
         for (int m = wave; m < M; m += 4) {
@@ -279,42 +336,29 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             if (lane + 64 < KV) sc[m * KVC + lane + 64] = e1 * inv;
         }
         __syncthreads();
-        // P.V: thread = (key group kg of 8, 4 consecutive d); partial sums reduced through LDS
+        // P.V: thread = (key group kgp of 8, 4 consecutive d); partial sums of the 8 groups reduced through LDS
         {
-            float *pv = qu;                                   // reuse: [8 groups][16 rows... handled per row][128]
+            float *pv = qu;                                          // reuse: [2 rows][8 groups][128]
             const int dq = threadIdx.x & 31, kgp = threadIdx.x >> 5;
             for (int m = 0; m < M; m++) {
-                const int b = m / TS, gch = (m - b * TS) / T;
-                const RowDesc rd = a.rows[b];
-                const int head0 = rd.kv_head + gch * T;
-                const bf16_t *vbase = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)KVC * D + h * DH + dq * 4;
+                if (m > 0) value_rows(m, vv);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                uint2 vv[11];
-#pragma unroll
-                for (int u = 0; u < 11; u++) {                // KV <= 84 -> at most 11 keys per group
-                    const int j = kgp + 8 * u;
-                    int ring = head0 + (j < KV ? j : 0);
-                    if (ring >= KVC) ring -= KVC;
-                    if (ring >= KVC) ring -= KVC;
-                    vv[u] = *(const uint2 *)(vbase + (size_t)ring * D);
-                }
 #pragma unroll
                 for (int u = 0; u < 11; u++) {
-                    const int j = kgp + 8 * u;
-                    const float w = j < KV ? sc[m * KVC + j] : 0.0f;
+                    const int jj = kgp + 8 * u;
+                    const float w = jj < KV ? sc[m * KVC + jj] : 0.0f;
                     acc.x += w * __uint_as_float(vv[u].x << 16); acc.y += w * __uint_as_float(vv[u].x & 0xffff0000u);
                     acc.z += w * __uint_as_float(vv[u].y << 16); acc.w += w * __uint_as_float(vv[u].y & 0xffff0000u);
                 }
-                __syncthreads();                              // previous row's reduction done with pv
-                *(float4 *)(pv + kgp * DH + dq * 4) = acc;
-                __syncthreads();
-                if (threadIdx.x < DH) {
-                    const int d = threadIdx.x;
-                    float o = 0.f;
+                *(float4 *)(pv + (m * 8 + kgp) * DH + dq * 4) = acc;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < M * DH) {
+                const int m = threadIdx.x >> 7, d = threadIdx.x & 127;
+                float o = 0.f;
 #pragma unroll
-                    for (int gI = 0; gI < 8; gI++) o += pv[gI * DH + d];
-                    *(bf16_t *)(panel + m * KP * 2 + ((((d >> 3) ^ (m & 15)) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
-                }
+                for (int gI = 0; gI < 8; gI++) o += pv[(m * 8 + gI) * DH + d];
+                *(bf16_t *)(panel + m * KP * 2 + ((((d >> 3) ^ (m & 15)) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
             }
         }
         __syncthreads();
@@ -431,6 +475,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         __syncthreads();
     }
 
+    STAMP(4);
     // ---- GEMM over this workgroup's k-tiles (weights already in registers) -------------------------
     const char *arow = nullptr;
     if (PRO == PRO_PLAIN) arow = (const char *)g.A + ((size_t)(r < M ? r : M - 1) * g.lda) * 2 + q * 16;
@@ -445,9 +490,11 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[u]), __builtin_bit_cast(bf16x8, av), acc, 0, 0, 0);
         }
     }
+    STAMP(5);
 #pragma unroll
     for (int j = 0; j < 4; j++) red[(wave * 64 + lane) * 4 + j] = acc[j];
     __syncthreads();
+    STAMP(6);
     if (wave == 0) {
         float v[4];
 #pragma unroll
@@ -455,6 +502,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             v[j] = ((red[lane * 4 + j] + red[(64 + lane) * 4 + j]) + red[(128 + lane) * 4 + j]) + red[(192 + lane) * 4 + j];
         epi_quad<true>(g, split, r, nt * 16 + q * 4, v[0], v[1], v[2], v[3]);
     }
+    STAMP(7);
 }
 
 void init_fused_kernel_attributes() {   // LN / dwconv row staging can exceed the 64 KiB default dynamic-LDS limit at M = 16

@@ -5,34 +5,26 @@
 //               softmax and P.V in one kernel, K/V read straight from the ring (:463-573)
 //   k_dwconv    cached causal depthwise conv + LayerNorm + SiLU + conv-cache update (:336-412, :671-674)
 #include "nasr_internal.h"
+#include "nasr_wave.h"
 
 namespace nasr {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-// sum over a 256-thread block; every thread gets the result. `sh` = 4 floats of LDS.
+// sum over a 256-thread block; every thread gets the result.  `sh` = 4 floats of LDS that the PREVIOUS block_sum of
+// this workgroup did not use (callers alternate between two 4-float halves, so one barrier per sum is enough: a wave
+// can only be one barrier ahead, and by then every wave has read the half that is being rewritten).
 __device__ __forceinline__ float block_sum(float v, float *sh) {
     v = wave_sum(v);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // LayerNorm of the 4 elements each thread holds (1024 = 256 x 4), biased variance, eps 1e-5; the affine
-// parameters are passed in so that the caller can load them before the reductions
+// parameters are passed in so that the caller can load them before the reductions; sh = 8 floats of LDS
 __device__ __forceinline__ float4 ln4(float4 v, float4 ww, float4 bb, float *sh) {
     float mean = block_sum((v.x + v.y) + (v.z + v.w), sh) * (1.0f / D);
     float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-    float var = block_sum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh) * (1.0f / D);
+    float var = block_sum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh + 4) * (1.0f / D);
     float inv = 1.0f / sqrtf(var + 1e-5f);
     return make_float4(dx * inv * ww.x + bb.x, dy * inv * ww.y + bb.y, dz * inv * ww.z + bb.z, dw * inv * ww.w + bb.w);
 }
@@ -53,7 +45,7 @@ __device__ __forceinline__ void store_act4(void *base, size_t off, float4 v, int
 
 // ---- post: one workgroup per row ------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_post(PostParams p) {
-    __shared__ float sh[4];
+    __shared__ float sh[8];
     const int m = blockIdx.x, c4 = threadIdx.x * 4;
     // every load of the kernel is independent of the arithmetic: issue them all first
     float4 v = *(const float4 *)(p.x + (size_t)m * D + c4);
@@ -319,7 +311,7 @@ void launch_attention(const AttnParams &p, hipStream_t st) {
 
 // ---- depthwise conv + LN + SiLU: one workgroup per (frame, stream) ------------------------------
 __global__ __launch_bounds__(256) void k_dwconv(ConvParams p) {
-    __shared__ float sh[4];
+    __shared__ float sh[8];
     const int i = blockIdx.x, b = blockIdx.y, T = p.T, ks1 = p.ks - 1;
     const int c4 = threadIdx.x * 4;
     const RowDesc rd = p.rows[b];

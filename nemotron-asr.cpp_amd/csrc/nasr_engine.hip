@@ -41,6 +41,9 @@ extern "C" const char *nasr_last_error(void) { return g_err; }
 // capture, even in thread-local mode, is broken by what other threads do meanwhile ("operation failed due to a
 // previous error during capture" when another thread copies or allocates).  Every entry point that talks to HIP
 // therefore holds this lock shared; building a step graph (rare: once per (B, T, G)) takes it exclusively.
+#ifdef NASR_STAMPS
+static unsigned long long *g_stamp_buf = nullptr;
+#endif
 static std::shared_mutex g_api_mu;
 struct ApiGuard {
     ApiGuard() { g_api_mu.lock_shared(); }
@@ -550,6 +553,9 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
     init_gemm_kernel_attributes();
     init_fused_kernel_attributes();
+#ifdef NASR_STAMPS
+    if (!g_stamp_buf) { hipMalloc((void **)&g_stamp_buf, 256 * 32 * 8); hipMemset(g_stamp_buf, 0, 256 * 32 * 8); }
+#endif
     if (load_weights(e, weights, n_weights)) { engine_destroy_impl(e); return -1; }
 
     const size_t S = (size_t)max_streams, Lr = (size_t)hp->n_layers, ks1 = (size_t)hp->kernel_size - 1;
@@ -622,6 +628,22 @@ extern "C" void nasr_engine_destroy(nasr_engine *e) {
     engine_destroy_impl(e);
 }
 static void engine_destroy_impl(nasr_engine *e) {
+#ifdef NASR_STAMPS
+    if (e && g_stamp_buf) {
+        hipSetDevice(e->device);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(256 * 32);
+        hipMemcpy(h.data(), g_stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
+        const unsigned long long t0 = h[0];
+        for (int s = 0; s < 24 && t0; s++) {          // first three layers: ticks of 10 ns relative to slot 0 / block 0 / stamp 0
+            fprintf(stderr, "slot %2d blk0:", s);
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %6lld", h[s * 32 + i] ? (long long)(h[s * 32 + i] - t0) : -1LL);
+            fprintf(stderr, "  | last:");
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %6lld", h[s * 32 + 16 + i] ? (long long)(h[s * 32 + 16 + i] - t0) : -1LL);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (!e) return;
     hipSetDevice(e->device);
     if (e->st) hipStreamSynchronize(e->st);
@@ -784,8 +806,15 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
     float *X[2] = {e->x, e->x2};
     int cur = 0;
     int prev_splits = 0;          // split-K partials pending from the previous layer's FFN2
+#ifdef NASR_STAMPS
+    unsigned long long *stamp_buf = g_stamp_buf;           // diagnostic build: 8 launches x 24 layers x 32 stamps
+    int stamp_slot = 0;
+#endif
     auto launch = [&](FusedParams &f, const char *name, double bytes, double flops) {
         ProfScope ps(e, name, bytes, flops);
+#ifdef NASR_STAMPS
+        f.stamps = stamp_buf + (size_t)(stamp_slot++) * 32;
+#endif
         launch_fused_skinny(f, st);
     };
     auto wbytes = [&](int N, int K) { return (double)N * K * 2 + (double)M * (K + N) * 4; };

@@ -204,6 +204,9 @@ struct FusedParams {
     const float *ln_w, *ln_b;
     AttnParams at;                // PRO_ATTN (blockIdx.y = head; K range = that head's 128 columns)
     ConvParams cv;                // PRO_DWCONV
+#ifdef NASR_STAMPS
+    unsigned long long *stamps;   // diagnostic build: [launch slot][2 blocks][16] s_memrealtime values (10 ns ticks)
+#endif
 };
 void launch_fused_skinny(const FusedParams &p, hipStream_t st);
 

@@ -1,0 +1,36 @@
+// nasr_wave.h -- wave64 all-reduce on the DPP path.
+//
+// __shfl_xor compiles to ds_bpermute_b32 (a trip through the LDS crossbar, ~100 cycles each, six dependent ones
+// per reduction): in-kernel stamps of the batch-1 layer showed one LayerNorm (two block sums) costing ~0.9 us of a
+// 4 us kernel.  Here the 16 lanes of a DPP row are combined by four VALU adds with lane-permuting operands
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane ends with its row's total) and the four rows by
+// v_readlane.  The summation order differs from the xor butterfly (a fixed order either way).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nasr {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+
+}  // namespace nasr
