@@ -124,18 +124,22 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     const int M = g.M;
     STAMP(0);
 
-    // The weight stream does not depend on the prologue: issue this wave's tiles (<= 8 KiB) first so
-    // the HBM latency runs under the prologue.
+    // The weight stream does not depend on the prologue: this wave's tiles (<= 8 KiB) are requested at the top of
+    // the kernel so that their 2.2-2.4 us run under the prologue -- but AFTER the prologue's own first loads: the
+    // memory pipeline serves a wave's requests in order, and the prologue inputs are the critical path.
     constexpr int U = 8;
     const int nts = t1 - t0;
     const int w0 = t0 + nts * wave / 4, w1 = t0 + nts * (wave + 1) / 4;   // host guarantees w1 - w0 <= U
     const u32x4 *wp = (const u32x4 *)g.W + (size_t)nt * KT * 64 + lane;
     u32x4 wv[U];
+    auto issue_weights = [&]() {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
-        wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
-    }
+        for (int u = 0; u < U; u++) {
+            const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
+            wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
+        }
+    };
+    if (!((PRO == PRO_LN && M <= 2) || PRO == PRO_ATTN || PRO == PRO_PLAIN || (PRO == PRO_DWCONV && M <= 2))) issue_weights();
     STAMP(1);
 
     if (PRO == PRO_LN && M <= 2) {
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
                     t[m][sI] = sI < p.part_splits ? *(const float4 *)(p.part + ((size_t)sI * M + m) * D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        issue_weights();
 #pragma unroll
         for (int m = 0; m < 2; m++) {
             if (m < M) {
@@ -307,6 +312,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         uint4 kk[8], pp[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) pp[c] = ((const uint4 *)prow0)[c];
+        issue_weights();
         const bf16_t *krow0 = key_row(m0, j0);
 #pragma unroll
         for (int c = 0; c < 8; c++) kk[c] = ((const uint4 *)krow0)[c];
@@ -370,20 +376,26 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             // block-per-row, 4 channels per thread; taps unrolled so all loads are in flight together
             const int c4 = threadIdx.x * 4;
             const float4 lw = *(const float4 *)(c.ln_w + c4), lb = *(const float4 *)(c.ln_b + c4);
+            const RowDesc rd_first = c.rows[0];             // the cache rows below depend on it: request it first,
+            float4 w[9];                                    // then what does not (taps weights, the GEMM weight stream)
+            if (c.ks == 9) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) w[k] = *(const float4 *)(c.dw + (size_t)k * D + c4);
+            }
+            issue_weights();
             for (int m = 0; m < M; m++) {
                 const int b = m / T, i = m - b * T;
-                const RowDesc rd = c.rows[b];
+                const RowDesc rd = b == 0 ? rd_first : c.rows[b];
                 const float *cc_in = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)rd.cc_par * ks1 * D;
                 float *cc_out = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
                 const float *gl = c.glu + (size_t)b * T * D;
                 float4 acc;
                 if (c.ks == 9) {
-                    float4 z[9], w[9];
+                    float4 z[9];
 #pragma unroll
                     for (int k = 0; k < 9; k++) {
                         const int rr = i + k;
                         z[k] = rr < 8 ? *(const float4 *)(cc_in + (size_t)rr * D + c4) : *(const float4 *)(gl + (size_t)(rr - 8) * D + c4);
-                        w[k] = *(const float4 *)(c.dw + (size_t)k * D + c4);
                     }
                     acc = make_float4(z[0].x * w[0].x, z[0].y * w[0].y, z[0].z * w[0].z, z[0].w * w[0].w);
 #pragma unroll
@@ -477,15 +489,20 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
 
     STAMP(4);
     // ---- GEMM over this workgroup's k-tiles (weights already in registers) -------------------------
-    const char *arow = nullptr;
-    if (PRO == PRO_PLAIN) arow = (const char *)g.A + ((size_t)(r < M ? r : M - 1) * g.lda) * 2 + q * 16;
+    uint4 avp[U];
+    if (PRO == PRO_PLAIN) {       // activations (written by the previous kernel) first, then the weight stream
+        const char *arow = (const char *)g.A + ((size_t)(r < M ? r : M - 1) * g.lda) * 2 + q * 16;
+#pragma unroll
+        for (int u = 0; u < U; u++) avp[u] = *(const uint4 *)(arow + (size_t)(w0 + u < w1 ? w0 + u : w1 - 1) * 64);
+        issue_weights();
+    }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int kt = w0 + u;
         if (kt < w1) {
             uint4 av;
-            if (PRO == PRO_PLAIN) av = *(const uint4 *)(arow + (size_t)kt * 64);
+            if (PRO == PRO_PLAIN) av = avp[u];
             else av = *(const uint4 *)(panel + r * KP * 2 + (((((kt - t0) << 2) | q) ^ r) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[u]), __builtin_bit_cast(bf16x8, av), acc, 0, 0, 0);
         }
