@@ -511,7 +511,11 @@ void launch_decode_iter(const DecParams &p, int iter, hipStream_t st) {
     else hipLaunchKernelGGL(k_dec_joint_tiled, dim3((VOCAB + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_dec_commit, dim3(1), dim3(256), 0, st, p);
 }
-// iterations enqueued before the host looks at n_active: (symbols of the busiest stream) + 1 are needed
-int decode_blind_iterations(int frames) { return frames / 2 + 3 < 16 ? frames / 2 + 3 : 16; }
+// iterations enqueued before the host looks at n_active: (symbols of the busiest stream) + 1 are needed; a shortfall
+// costs one host round trip and a further round of iterations
+int decode_blind_iterations(int frames) {
+    if (frames <= 1) return 2;                  // one emission + the closing blank; a spare iteration would cost 1 % of the step
+    return frames / 2 + 4 < 16 ? frames / 2 + 4 : 16;   // an idle iteration (~10 us) is far cheaper than a host round trip
+}
 
 }  // namespace nasr

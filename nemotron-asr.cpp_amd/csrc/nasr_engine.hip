@@ -121,11 +121,10 @@ struct nasr_engine {
     // hipGraph replay of the steady-state step: fixed descriptor buffers + one exec per (B, T)
     std::map<int64_t, hipGraphExec_t> graphs;
     int w_rows = 0;                  // workspace rows = max(max_streams x TMAX, MAXNEW)
-    RowDesc *g_rows = nullptr, *g_vrows = nullptr; PcmDesc *g_pcm = nullptr; int *g_meta = nullptr;       // device
-    RowDesc *gh_vrows = nullptr;
+    char *g_desc = nullptr;          // device mirror of the packed descriptor block (layout: graph_desc_layout)
     bool opt_multichunk = true;
     char *gh = nullptr;                                                               // pinned host block
-    RowDesc *gh_rows = nullptr; PcmDesc *gh_pcm = nullptr; int *gh_meta = nullptr, *gh_collect = nullptr, *gh_active = nullptr;
+    int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active
     int64_t graph_replays = 0, eager_steps = 0, decode_fallbacks = 0, decode_fallback_rounds = 0;
     void *a, *hbuf, *ctx, *cbuf, *sub_b;
     float *predg;                    // [slot][640] cached joint.pred output of the LSTM candidate
@@ -597,7 +596,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     rc |= dalloc(e, &e->dlist, S);
     rc |= dalloc(e, &e->rowmap, M);
     rc |= dalloc(e, &e->tok_frame, S * TOK_CAP);
-    rc |= dalloc(e, &e->collect_dev, S * (1 + COLLECT_STRIDE));
+    rc |= dalloc(e, &e->collect_dev, S * (1 + COLLECT_STRIDE) + 4);
     if (rc) { engine_destroy_impl(e); return -1; }
     e->pin_cap = 8u << 20;
     e->pin_off = 256;
@@ -605,15 +604,11 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     e->ddesc_cap = 8u << 20;
     if (hipMalloc((void **)&e->ddesc, e->ddesc_cap) != hipSuccess) { engine_destroy_impl(e); return fail("hipMalloc desc failed"); }
     {
-        const size_t off_rows = 0, off_pcm = off_rows + S * sizeof(RowDesc), off_meta = off_pcm + S * sizeof(PcmDesc);
-        const size_t off_col = off_meta + 2 * S * sizeof(int), off_act = off_col + S * (1 + COLLECT_STRIDE) * sizeof(int);
-        const size_t off_vr = off_act + 64;
-        if (hipHostMalloc((void **)&e->gh, off_vr + M * sizeof(RowDesc), hipHostMallocDefault) != hipSuccess) { engine_destroy_impl(e); return fail("hipHostMalloc failed"); }
-        e->gh_vrows = (RowDesc *)(e->gh + off_vr);
-        if (dalloc(e, &e->g_vrows, M)) { engine_destroy_impl(e); return -1; }
-        e->gh_rows = (RowDesc *)(e->gh + off_rows); e->gh_pcm = (PcmDesc *)(e->gh + off_pcm); e->gh_meta = (int *)(e->gh + off_meta);
-        e->gh_collect = (int *)(e->gh + off_col); e->gh_active = (int *)(e->gh + off_act);
-        if (dalloc(e, &e->g_rows, S) || dalloc(e, &e->g_pcm, S) || dalloc(e, &e->g_meta, 2 * S)) { engine_destroy_impl(e); return -1; }
+        const size_t desc_bytes = S * (sizeof(RowDesc) + sizeof(PcmDesc) + 2 * sizeof(int)) + M * sizeof(RowDesc) + 64;
+        const size_t col_bytes = (S * (1 + COLLECT_STRIDE) + 4) * sizeof(int);
+        if (hipHostMalloc((void **)&e->gh, desc_bytes + col_bytes, hipHostMallocDefault) != hipSuccess) { engine_destroy_impl(e); return fail("hipHostMalloc failed"); }
+        e->gh_collect = (int *)(e->gh + desc_bytes);
+        if (dalloc(e, &e->g_desc, desc_bytes)) { engine_destroy_impl(e); return -1; }
     }
     e->slots.assign(S, nullptr);
     e->tap_mel_frames.assign(S, 0);
@@ -1177,8 +1172,10 @@ static int validate_batch(nasr_engine *e, nasr_stream *const *streams, int B) {
 }
 
 // gather new tokens of the B streams
-__global__ void k_collect(const int *slots, const int *tok_read, int B, const DecCtrl *ctrl, const int *tok_ring, int *out, int stride) {
+__global__ void k_collect(const int *slots, const int *tok_read, int B, const DecCtrl *ctrl, const int *tok_ring, int *out, int stride,
+                          const int *n_active) {
     const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && n_active) out[(size_t)B * (1 + stride)] = *n_active;   // rides along in the same D2H copy
     const int slot = slots[b];
     const int n_tok = ctrl[slot].n_tok, rd = tok_read[b];
     const int n_new = n_tok - rd;
@@ -1196,7 +1193,7 @@ static int collect_tokens(nasr_engine *e, nasr_stream *const *streams, int B, in
     for (int b = 0; b < B; b++) { meta[b] = streams[b]->slot; meta[B + b] = streams[b]->tok_read; }
     const int *dmeta;
     if (stage_desc(e, meta, &dmeta)) return -1;
-    hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st, dmeta, dmeta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE);
+    hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st, dmeta, dmeta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE, (const int *)nullptr);
     std::vector<int> host((size_t)B * (1 + COLLECT_STRIDE));
     HIPCHK(hipMemcpyAsync(host.data(), e->collect_dev, host.size() * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
@@ -1259,30 +1256,42 @@ extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
 // for a given (B, T): descriptors live at fixed addresses and are refreshed by memcpy nodes.
 static int max_frames_per_push(int TS) { return 8 * TS + 16; }  // TS = frames of encoder output the push completes (+ what a first push leaves over)
 
+// Descriptors of a graph step, packed so that ONE memcpy node refreshes them: [RowDesc B][PcmDesc B][meta 2B][RowDesc B*G]
+struct GraphDescLayout { size_t rows, pcm, meta, vrows, total; };
+static GraphDescLayout graph_desc_layout(int B, int G) {
+    GraphDescLayout l;
+    l.rows = 0;
+    l.pcm = l.rows + (size_t)B * sizeof(RowDesc);
+    l.meta = l.pcm + (size_t)B * sizeof(PcmDesc);
+    l.vrows = (l.meta + (size_t)2 * B * sizeof(int) + 15) & ~(size_t)15;
+    l.total = l.vrows + (G > 1 ? (size_t)B * G * sizeof(RowDesc) : 0);
+    return l;
+}
+
 static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraphExec_t *out) {
     hipStream_t st = e->st;
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = 0;
     auto body = [&]() -> int {
-        HIPCHK(hipMemcpyAsync(e->g_pcm, e->gh_pcm, (size_t)B * sizeof(PcmDesc), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(e->g_rows, e->gh_rows, (size_t)B * sizeof(RowDesc), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(e->g_meta, e->gh_meta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, st));
-        if (G > 1) HIPCHK(hipMemcpyAsync(e->g_vrows, e->gh_vrows, (size_t)B * G * sizeof(RowDesc), hipMemcpyHostToDevice, st));
+        const GraphDescLayout L = graph_desc_layout(B, G);
+        const RowDesc *g_rows = (const RowDesc *)(e->g_desc + L.rows), *g_vrows = (const RowDesc *)(e->g_desc + L.vrows);
+        const PcmDesc *g_pcm = (const PcmDesc *)(e->g_desc + L.pcm);
+        const int *g_meta = (const int *)(e->g_desc + L.meta);
+        HIPCHK(hipMemcpyAsync(e->g_desc, e->gh, L.total, hipMemcpyHostToDevice, st));
         MelParams mp;
         memset(&mp, 0, sizeof(mp));
-        mp.desc = e->g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+        mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
         mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
         launch_mel(mp, mp.max_frames * HOP + NFFT, st);
-        if (enqueue_encoder(e, e->g_rows, G > 1 ? e->g_vrows : e->g_rows, nullptr, B, T, R, G)) return -1;
+        if (enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G)) return -1;
         DecParams dp;
-        make_dec_params(e, e->g_rows, B, T * G, dp);
+        make_dec_params(e, g_rows, B, T * G, dp);
         launch_decode_begin(dp, st);
         int it = 0;
         enqueue_decode_iters(e, dp, B, decode_blind_iterations(T * G), it);
-        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, st, e->g_meta, e->g_meta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE);
-        HIPCHK(hipMemcpyAsync(e->gh_collect, e->collect_dev, (size_t)B * (1 + COLLECT_STRIDE) * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, st, g_meta, g_meta + B, B, e->ctrl, e->tok_ring, e->collect_dev, COLLECT_STRIDE, e->n_active);
+        HIPCHK(hipMemcpyAsync(e->gh_collect, e->collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
         return 0;
     };
     rc = body();
@@ -1331,45 +1340,50 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         }
         it = e->graphs.emplace(key, ex).first;
     }
+    const GraphDescLayout L = graph_desc_layout(B, G);
+    RowDesc *gh_rows = (RowDesc *)(e->gh + L.rows), *gh_vrows = (RowDesc *)(e->gh + L.vrows);
+    PcmDesc *gh_pcm = (PcmDesc *)(e->gh + L.pcm);
+    int *gh_meta = (int *)(e->gh + L.meta);
+    int *gh_active = e->gh_collect + (size_t)B * (1 + COLLECT_STRIDE);      // k_collect appends n_active to its records
     for (int b = 0; b < B; b++) {
         nasr_stream *s = streams[b];
-        PcmDesc &d = e->gh_pcm[b];
+        PcmDesc &d = gh_pcm[b];
         memset(&d, 0, sizeof(d));
         d.pcm = pcm_dev[b]; d.slot = s->slot; d.n = n_samples[b]; d.cnt = s->abuf_cnt; d.par = s->abuf_par;
         const int avail = d.cnt + d.n;
         d.n_frames = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
         d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
         d.consumed = d.n_frames * HOP;
-        fill_row_desc(e->gh_rows[b], s, T * G);
+        fill_row_desc(gh_rows[b], s, T * G);
         for (int g = 0; g < G; g++) {
-            RowDesc &v = e->gh_vrows[b * G + g];
-            v = e->gh_rows[b];
+            RowDesc &v = gh_vrows[b * G + g];
+            v = gh_rows[b];
             v.mel_start = (s->mel_start + g * shift) & (MEL_RING - 1);
         }
-        e->gh_meta[b] = s->slot;
-        e->gh_meta[B + b] = s->tok_read;
+        gh_meta[b] = s->slot;
+        gh_meta[B + b] = s->tok_read;
     }
     HIPCHK(hipGraphLaunch(it->second, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
     e->graph_replays++;
     for (int b = 0; b < B; b++) {
         nasr_stream *s = streams[b];
-        const PcmDesc &d = e->gh_pcm[b];
+        const PcmDesc &d = gh_pcm[b];
         s->abuf_cnt = d.cnt + d.n - d.consumed;
         if (d.n_frames > 0) s->abuf_par ^= 1;
         s->mel_count += d.n_frames;
     }
-    if (*e->gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
+    if (*gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
         DecParams dp;
-        make_dec_params(e, e->g_rows, B, T * G, dp);
-        int itn = decode_blind_iterations(T * G), round = 4;
+        make_dec_params(e, (const RowDesc *)(e->g_desc + L.rows), B, T * G, dp);
+        int itn = decode_blind_iterations(T * G), round = T * G > 1 ? 8 : 4;   // idle iterations ~10 us each, a round trip ~40 us
         e->decode_fallbacks++;
         for (;;) {
             e->decode_fallback_rounds++;
             enqueue_decode_iters(e, dp, B, round, itn);
-            HIPCHK(hipMemcpyAsync(e->gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st));
+            HIPCHK(hipMemcpyAsync(gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st));
             HIPCHK(hipStreamSynchronize(e->st));
-            if (*e->gh_active == 0) break;
+            if (*gh_active == 0) break;
             if (itn > T * G * MAX_SYMBOLS + 64) return fail("decode did not terminate");
             round = std::min(2 * round, 32);
         }
