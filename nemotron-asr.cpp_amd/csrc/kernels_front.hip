@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_melframes(MelParams p) {
     __syncthreads();
     if (threadIdx.x < NMEL) {
         float sum = 0.0f;
-        for (int k = 0; k < NBINS; k++) sum = __fadd_rn(sum, __fmul_rn(p.fbT[k * NMEL + threadIdx.x], pw[k]));
+        const int k_lo = p.fb_band[2 * threadIdx.x], k_hi = p.fb_band[2 * threadIdx.x + 1];   // see the engine: same sum
+        for (int k = k_lo; k < k_hi; k++) sum = __fadd_rn(sum, __fmul_rn(p.fbT[k * NMEL + threadIdx.x], pw[k]));
         float v = logf(__fadd_rn(sum, 5.960464477539063e-8f));                             // :381
         p.mel_ring[((size_t)d.slot * MEL_RING + ((d.mel_wpos + t) & (MEL_RING - 1))) * NMEL + threadIdx.x] = v;
         if (p.tap && t < p.tap_cap) p.tap[((size_t)blockIdx.y * p.tap_cap + t) * NMEL + threadIdx.x] = v;

@@ -103,6 +103,7 @@ struct nasr_engine {
     hipStream_t st = nullptr;
     // front-end constants
     float *window = nullptr, *fbT = nullptr, *cos_t = nullptr, *sin_t = nullptr;
+    int *fb_band = nullptr;
     float *w0t, *b0, *w2t, *b2, *b3, *w5t, *b5, *b6, *sub_out_b;
     void *w3, *w6, *sub_out_w;
     std::vector<LayerW> L;
@@ -284,9 +285,10 @@ struct Loader {
         HIPCHK(hipMemcpy(*dev, h.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
         return 0;
     }
-    int upload_vec(const std::vector<float> &h, float **dev) {
+    template <typename Tp>
+    int upload_vec(const std::vector<Tp> &h, Tp **dev) {
         if (dalloc(e, dev, h.size())) return -1;
-        HIPCHK(hipMemcpy(*dev, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(*dev, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
         return 0;
     }
     // matrix [N][K] f32 host -> engine GEMM layout (packed bf16 tiles, or f32 row-major)
@@ -370,6 +372,17 @@ static int load_weights(nasr_engine *e, const nasr_weight_desc *w, int n_w) {
         for (int m = 0; m < NMEL; m++)
             for (int k = 0; k < NBINS; k++) fbT[(size_t)k * NMEL + m] = h[(size_t)m * NBINS + k];
         if (ld.upload_vec(fbT, &e->fbT)) return -1;
+        // band of every (triangular) filter: the reference sums all 257 bins in order (src/preprocessor.cpp:374-383);
+        // outside the band the terms are +0 * power = +0 and sum + 0 == sum, so summing the band alone is bit-identical
+        std::vector<int> band(2 * NMEL);
+        for (int m = 0; m < NMEL; m++) {
+            int lo = NBINS, hi = 0;
+            for (int k = 0; k < NBINS; k++)
+                if (h[(size_t)m * NBINS + k] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
+            if (lo > hi) lo = hi = 0;
+            band[2 * m] = lo; band[2 * m + 1] = hi;
+        }
+        if (ld.upload_vec(band, &e->fb_band)) return -1;
         std::vector<float> ct(NFFT), sn(NFFT);
         for (int i = 0; i < NFFT; i++) {
             const float theta = (2.0f * (float)M_PI * (float)i) / (float)NFFT;
@@ -1282,7 +1295,7 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraph
         MelParams mp;
         memset(&mp, 0, sizeof(mp));
         mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
-        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
         launch_mel(mp, mp.max_frames * HOP + NFFT, st);
         if (enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G)) return -1;
         DecParams dp;
@@ -1446,7 +1459,7 @@ static int push_piece(nasr_engine *e, nasr_stream *const *streams, int B, const 
         MelParams mp;
         memset(&mp, 0, sizeof(mp));
         mp.desc = dpd; mp.B = (int)pd.size(); mp.max_frames = max_frames; mp.abuf = e->abuf; mp.last_sample = e->last_sample;
-        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
         if (e->debug) { mp.tap = e->tap_mel; mp.tap_cap = e->tap_mel_cap; }
         {
             ProfScope ps(e, "k_mel", 0, 0);

@@ -126,6 +126,7 @@ struct MelParams {
     float *mel_ring;      // [slot][MEL_RING][128]
     const float *window;  // [512] padded Hann
     const float *fbT;     // [257][128] transposed filterbank
+    const int *fb_band;   // [128][2] first / one-past-last bin with a non-zero weight of every filter
     const float *cos_t, *sin_t;  // [512]
     float *tap; int tap_cap;     // optional debug copy of produced frames [B][tap_cap][128]
 };
