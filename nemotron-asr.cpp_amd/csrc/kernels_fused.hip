@@ -108,6 +108,8 @@ __device__ __forceinline__ float dot32(const float *qs, const void *row) {   // 
 #define STAMP(i)
 #endif
 
+#define PIN_SGPR(x) asm volatile("" ::"s"(x))
+
 template <int PRO>
 __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,6 +140,11 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
             const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
             wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
         }
+        // hipcc sinks the scalar loads of kernel-argument fields to their first use: the epilogue's output pointers
+        // and strides were fetched after the last barrier, ~0.3 us of exposed latency per kernel (seen in the ISA and
+        // in the stamps).  Naming them here makes them resident before the vector loads above return.
+        PIN_SGPR(g.epi); PIN_SGPR(g.out_f32); PIN_SGPR(g.ldo); PIN_SGPR(g.out_act); PIN_SGPR(g.ldo_act); PIN_SGPR(g.N);
+        PIN_SGPR(g.q_out); PIN_SGPR(g.kv_pool); PIN_SGPR(g.kv_slot_stride); PIN_SGPR(g.rows); PIN_SGPR(g.T);
     };
     if (!((PRO == PRO_LN && M <= 2) || PRO == PRO_ATTN || PRO == PRO_PLAIN || (PRO == PRO_DWCONV && M <= 2))) issue_weights();
     STAMP(1);
