@@ -135,10 +135,21 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     const u32x4 *wp = (const u32x4 *)g.W + (size_t)nt * KT * 64 + lane;
     u32x4 wv[U];
     auto issue_weights = [&]() {
+        if (PRO == PRO_ATTN) {
+            // blockIdx.x = group of 128 output columns, blockIdx.y = head: wave w owns column tiles 2w, 2w+1 of the group
+            // over the head's four k-tiles (K = 128, no cross-wave reduction).  64 workgroups redo the head's attention
+            // 8 times, not 64: the 512-workgroup form spent ~3 us per launch with every workgroup pulling the same K/V/P rows.
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
-            wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
+            for (int u = 0; u < U; u++) {
+                const int ntile = blockIdx.x * 8 + wave * 2 + (u >> 2), kt = t0 + (u & 3);
+                wv[u] = __builtin_nontemporal_load((const u32x4 *)g.W + ((size_t)ntile * KT + kt) * 64 + lane);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int kt = w0 + u < w1 ? w0 + u : w1 - 1;
+                wv[u] = __builtin_nontemporal_load(wp + (size_t)kt * 64);
+            }
         }
         // hipcc sinks the scalar loads of kernel-argument fields to their first use: the epilogue's output pointers
         // and strides were fetched after the last barrier, ~0.3 us of exposed latency per kernel (seen in the ISA and
@@ -503,6 +514,20 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         for (int u = 0; u < U; u++) avp[u] = *(const uint4 *)(arow + (size_t)(w0 + u < w1 ? w0 + u : w1 - 1) * 64);
         issue_weights();
     }
+    if (PRO == PRO_ATTN) {
+        f32x4 a2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint4 av = *(const uint4 *)(panel + r * KP * 2 + (((((u & 3) << 2) | q) ^ r) << 4));
+            a2[u >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[u]), __builtin_bit_cast(bf16x8, av), a2[u >> 2], 0, 0, 0);
+        }
+        STAMP(5);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            epi_quad<true>(g, split, r, (blockIdx.x * 8 + wave * 2 + j) * 16 + q * 4, a2[j][0], a2[j][1], a2[j][2], a2[j][3]);
+        STAMP(7);
+        return;
+    }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -544,7 +569,7 @@ void launch_fused_skinny(const FusedParams &p, hipStream_t st) {
     switch (p.pro) {
     case PRO_LN: hipLaunchKernelGGL(k_fused_skinny<PRO_LN>, grid, dim3(256), lds, st, p); break;
     case PRO_PLAIN: hipLaunchKernelGGL(k_fused_skinny<PRO_PLAIN>, grid, dim3(256), 4096, st, p); break;
-    case PRO_ATTN: hipLaunchKernelGGL(k_fused_skinny<PRO_ATTN>, grid, dim3(256), lds, st, p); break;
+    case PRO_ATTN: hipLaunchKernelGGL(k_fused_skinny<PRO_ATTN>, dim3(g.N / 128, g.splits), dim3(256), lds, st, p); break;   // (column group, head)
     case PRO_DWCONV: hipLaunchKernelGGL(k_fused_skinny<PRO_DWCONV>, grid, dim3(256), lds, st, p); break;
     }
 }
