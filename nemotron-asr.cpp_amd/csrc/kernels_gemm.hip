@@ -58,6 +58,13 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
     constexpr int U = 8;   // weight tiles in flight per wave (8 KiB)
     int kt = w0;
     for (; kt + U <= w1; kt += U) {
+        // activations first: they were written by the previous kernel and are the critical path; the memory pipeline
+        // serves a wave's requests in order, so they must not queue behind 8 KiB of weights
+        uint4 av[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) av[u][mt] = *(const uint4 *)(arow[mt] + (size_t)(kt + u) * 64);
         u32x4 wv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) wv[u] = __builtin_nontemporal_load(wp + (size_t)(kt + u) * 64);
@@ -65,10 +72,8 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
         for (int u = 0; u < U; u++) {
             const bf16x8 wf = __builtin_bit_cast(bf16x8, wv[u]);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const uint4 av = *(const uint4 *)(arow[mt] + (size_t)(kt + u) * 64);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, av), acc[mt], 0, 0, 0);
-            }
+            for (int mt = 0; mt < MT; mt++)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, av[u][mt]), acc[mt], 0, 0, 0);
         }
     }
     for (; kt < w1; kt++) {
