@@ -10,11 +10,11 @@
 //     for the access pattern, not inherited from the file format.
 //   * the weight tile is the MFMA A operand (rows = n), activations are the B operand
 //     (cols = m), so D[n][m]: lane holds 4 consecutive n for one m -> row-major stores.
-//   * k_gemm_skinny (M <= 64): weight-streaming kernel, HBM-bound.  One 16-column tile
-//     per workgroup, K split over the 4 waves (and over blockIdx.y for split-K);
-//     activations (a few KB, L2 resident) go straight to registers; no LDS in the loop.
-//   * k_gemm_tiled (M > 64): 128 rows x 128 cols per workgroup, activation panel staged
-//     through XOR-swizzled LDS, weights straight from the packed layout.
+//   * k_gemm_skinny (M <= 128): weight-streaming kernel, HBM-bound.  One 16-column tile x one
+//     64-row slab per workgroup, K split over the 4 waves (and over blockIdx.y for split-K);
+//     activations go straight to registers (requested before the weights); no LDS in the loop.
+//   * k_gemm_tiled2 (M > 128): 128 rows x 128 cols per workgroup, both operands by LDS-DMA
+//     into a 4-slot ring, 8 waves.
 // f32 path (parity mode): plain LDS-tiled FMA kernel, k ascending, deterministic.
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
@@ -100,106 +100,15 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------
-// tiled: 128 rows x 128 cols per workgroup (4 waves x 2 n-tiles x 8 m-tiles), K chunks of
-// 64 through a double-buffered XOR-swizzled LDS panel.  grid = (N/128, ceil(M/128), splits)
-// flattened with an XCD-aware remap so that blocks sharing weight columns share an L2.
-// ------------------------------------------------------------------------------------
-constexpr int TM = 128, TKC = 64;
+constexpr int TM = 128;
 
 __device__ __forceinline__ int panel_off(int row, int chunk) {  // byte offset in a [128][64] bf16 panel
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-__global__ __launch_bounds__(256) void k_gemm_tiled(GemmParams p, int n_groups, int m_chunks) {
-    __shared__ __attribute__((aligned(16))) char panel[2][TM * TKC * 2];
-    // XCD-aware bijective remap of the flat block id (8 XCDs, round-robin dispatch)
-    const int nblk = gridDim.x;
-    int id = blockIdx.x;
-    {
-        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
-        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
-    }
-    const int mc = id % m_chunks;
-    const int rest = id / m_chunks;
-    const int ng = rest % n_groups, split = rest / n_groups;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q = lane >> 4, r = lane & 15;
-    const int KT = p.K >> 5;
-    const int kc_total = KT >> 1;                                   // chunks of 64
-    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
-    const int m0 = mc * TM;
-    const int ntile0 = (ng * 4 + wave) * 2;
-    const uint4 *wp0 = (const uint4 *)p.W + (size_t)ntile0 * KT * 64 + lane;
-    const uint4 *wp1 = wp0 + (size_t)KT * 64;
-
-    // panel loader: thread t -> row t/2, chunks (t&1)*4 .. +4
-    const int lrow = threadIdx.x >> 1, lhalf = threadIdx.x & 1;
-    const bool lok = (m0 + lrow) < p.M;
-    const char *lsrc = a_row_ptr(p, lok ? m0 + lrow : 0, 2) + lhalf * 64;
-
-    f32x4 acc[2][8];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    uint4 pre[4];
-    auto gload = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) pre[i] = lok ? *(const uint4 *)(lsrc + (size_t)kc * 128 + i * 16) : make_uint4(0, 0, 0, 0);
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) *(uint4 *)(panel[buf] + panel_off(lrow, lhalf * 4 + i)) = pre[i];
-    };
-    int cur = 0;
-    // software pipeline: chunk kc+1's activation panel (global -> regs) and weight tiles (global -> regs)
-    // are in flight while chunk kc is multiplied out of LDS.
-    uint4 wc[2][2], wn[2][2];
-    auto wload = [&](uint4 (&w)[2][2], int kc) {
-        w[0][0] = wp0[(size_t)(2 * kc) * 64];
-        w[0][1] = wp0[(size_t)(2 * kc + 1) * 64];
-        w[1][0] = wp1[(size_t)(2 * kc) * 64];
-        w[1][1] = wp1[(size_t)(2 * kc + 1) * 64];
-    };
-    if (c0 < c1) { gload(c0); wload(wc, c0); lstore(0); }
-    __syncthreads();
-    for (int kc = c0; kc < c1; kc++) {
-        const bool more = kc + 1 < c1;
-        if (more) { gload(kc + 1); wload(wn, kc + 1); }
-#pragma unroll
-        for (int k2 = 0; k2 < 2; k2++) {
-#pragma unroll
-            for (int mt = 0; mt < 8; mt++) {
-                uint4 bv = *(const uint4 *)(panel[cur] + panel_off(mt * 16 + r, k2 * 4 + q));
-                bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
-                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[0][k2]), bf, acc[0][mt], 0, 0, 0);
-                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[1][k2]), bf, acc[1][mt], 0, 0, 0);
-            }
-        }
-        if (more) {
-            lstore(cur ^ 1);
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int k2 = 0; k2 < 2; k2++) wc[j][k2] = wn[j][k2];
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++)
-            epi_quad<true>(p, split, m0 + mt * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1],
-                           acc[j][mt][2], acc[j][mt][3]);
-}
-
 // ------------------------------------------------------------------------------------
-// tiled, LDS-DMA pipelined (the large-M kernel): same 128 x 128 tile / 4 waves x (2 n-tiles x 8
-// m-tiles) decomposition, but BOTH operands arrive by global_load_lds into a 4-slot LDS ring
+// tiled, LDS-DMA pipelined (the large-M kernel): 128 x 128 tile, 8 waves = 4 n-tile pairs x 2 halves of
+// the rows (32 x 64 per wave); BOTH operands arrive by global_load_lds into a 4-slot LDS ring
 // (slot = 16 KiB activation panel + 16 KiB weight tiles per 64-deep K chunk) with three chunks in
 // flight per workgroup and one raw s_barrier per chunk.  With ~1 workgroup per CU (M = 896 gives
 // 224 tiles) there is no other wave to hide the ~1 us L2/HBM latency behind, so the depth has to
@@ -325,12 +234,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     } else {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
         dim3 grid(n_groups * m_chunks * p.splits);
-        static bool use_dma = getenv("NASR_GEMM_NODMA") == nullptr;
-        if (use_dma) {
-            hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
-        } else {
-            hipLaunchKernelGGL(k_gemm_tiled, grid, dim3(256), 0, st, p, n_groups, m_chunks);
-        }
+        hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
     }
 }
 
