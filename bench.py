@@ -88,6 +88,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    torch = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -141,6 +142,8 @@ def main():
 
     def barrier():
         sharding.barrier(dist, eng.synchronize)
+        if dist is not None:
+            torch.cuda.synchronize()            # torch's own stream (RCCL barrier); the engine's stream is synchronised above
 
     for k in range(args.warmup):
         run_step(k)
