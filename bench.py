@@ -89,7 +89,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("NASR_BENCH_FORCE_DIST"):      # the knob exercises the RCCL plumbing on a 1-GPU box
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
