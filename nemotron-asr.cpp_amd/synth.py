@@ -338,3 +338,87 @@ def quantize_weights(W: dict, kind: str):
         else:
             eng[name], deq[name] = a, a
     return eng, deq
+
+
+# ---- diarization side-car: MarbleNet VAD + TitaNet-L, tensor names and layouts of
+# scripts/convert_diarize_to_gguf.py (depthwise (k, ch), pointwise (out, in)) ---------------------------------------
+VAD_TOPO = [(11, 1, 1, 80, 128, False, True, False), (13, 1, 2, 128, 64, True, True, False), (15, 1, 2, 64, 64, True, True, False),
+            (17, 1, 2, 64, 64, True, True, False), (29, 2, 1, 64, 128, False, True, False), (1, 1, 1, 128, 128, False, False, False)]
+SPK_TOPO = [(3, 1, 1, 80, 1024, False, True, True), (7, 1, 3, 1024, 1024, True, True, True), (11, 1, 3, 1024, 1024, True, True, True),
+            (15, 1, 3, 1024, 1024, True, True, True), (1, 1, 1, 1024, 3072, False, True, True)]
+DIAR_N_MELS = 80
+
+
+def mel_filterbank_n(n_mels: int) -> np.ndarray:
+    """Triangular HTK filterbank [n_mels][257] (same construction as mel_filterbank())."""
+    def hz2mel(f):
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+
+    def mel2hz(m):
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+
+    freqs = np.linspace(0.0, SAMPLE_RATE / 2, N_BINS)
+    pts = mel2hz(np.linspace(hz2mel(0.0), hz2mel(SAMPLE_RATE / 2), n_mels + 2))
+    fb = np.zeros((n_mels, N_BINS), dtype=np.float64)
+    for m in range(n_mels):
+        lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
+        fb[m] = np.maximum(0.0, np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce))) * (2.0 / (hi - lo))
+    return fb.astype(np.float32)
+
+
+def _bn(seed, prefix, C, w):
+    w[prefix + ".weight"] = _tensor(seed, prefix + ".weight", (C,), 0.05, center=1.0)
+    w[prefix + ".bias"] = _tensor(seed, prefix + ".bias", (C,), 0.05)
+    w[prefix + ".running_mean"] = _tensor(seed, prefix + ".running_mean", (C,), 0.05)
+    w[prefix + ".running_var"] = _tensor(seed, prefix + ".running_var", (C,), 0.3, center=1.0)
+
+
+def _jasper(seed, ns, topo, w):
+    for b, (kernel, _dil, repeat, cin, cout, residual, separable, has_se) in enumerate(topo):
+        pre = f"{ns}.encoder.encoder.{b}"
+        for s in range(repeat):
+            ci = cin if s == 0 else cout
+            dw_i, pw_i, bn_i = 5 * s, 5 * s + 1, 5 * s + 2
+            if not separable:
+                pw_i, bn_i = 0, 1
+            else:
+                n = f"{pre}.mconv.{dw_i}.conv.weight"
+                w[n] = _tensor(seed, n, (kernel, ci), float(np.sqrt(3.0 / kernel)))
+            n = f"{pre}.mconv.{pw_i}.conv.weight"
+            w[n] = _tensor(seed, n, (cout, ci), float(np.sqrt(3.0 / ci)))
+            _bn(seed, f"{pre}.mconv.{bn_i}", cout, w)
+        if residual:
+            n = f"{pre}.res.0.0.conv.weight"
+            w[n] = _tensor(seed, n, (cout, cin), float(np.sqrt(3.0 / cin)))
+            _bn(seed, f"{pre}.res.0.1", cout, w)
+        if has_se:
+            se = f"{pre}.mconv.{5 * (repeat - 1) + 3}"
+            w[se + ".fc.0.weight"] = _tensor(seed, se + ".fc.0.weight", (cout // 8, cout), float(np.sqrt(3.0 / cout)))
+            w[se + ".fc.2.weight"] = _tensor(seed, se + ".fc.2.weight", (cout, cout // 8), float(np.sqrt(3.0 / (cout // 8))))
+
+
+def make_diar_weights(seed: int = 0xD1A12, vad: bool = True, spk: bool = True) -> dict:
+    """name -> float32 ndarray for diarize.gguf's two namespaces (random-init MarbleNet 6 blocks / TitaNet-L 5 blocks)."""
+    w = {}
+    for ns, on in (("vad", vad), ("spk", spk)):
+        if not on:
+            continue
+        w[f"{ns}.preprocessor.featurizer.fb"] = mel_filterbank_n(DIAR_N_MELS)
+        w[f"{ns}.preprocessor.featurizer.window"] = hann_window()
+    if vad:
+        _jasper(seed, "vad", VAD_TOPO, w)
+        w["vad.decoder.decoder_layers.0.weight"] = _tensor(seed, "vad.decoder.decoder_layers.0.weight", (2, 128), float(np.sqrt(3.0 / 128)) * 4)
+        w["vad.decoder.decoder_layers.0.bias"] = _tensor(seed, "vad.decoder.decoder_layers.0.bias", (2,), 0.05)
+    if spk:
+        _jasper(seed, "spk", SPK_TOPO, w)
+        C, A = 3072, 128
+        d = "spk.decoder"
+        w[d + "._pooling.attention_layer.0.conv_layer.weight"] = _tensor(seed, d + ".a1w", (A, 3 * C), float(np.sqrt(3.0 / (3 * C))))
+        w[d + "._pooling.attention_layer.0.conv_layer.bias"] = _tensor(seed, d + ".a1b", (A,), 0.05)
+        _bn(seed, d + "._pooling.attention_layer.0.bn", A, w)
+        w[d + "._pooling.attention_layer.2.weight"] = _tensor(seed, d + ".a2w", (C, A), float(np.sqrt(3.0 / A)))
+        w[d + "._pooling.attention_layer.2.bias"] = _tensor(seed, d + ".a2b", (C,), 0.05)
+        _bn(seed, d + ".emb_layers.0.0", 2 * C, w)
+        w[d + ".emb_layers.0.1.weight"] = _tensor(seed, d + ".embw", (192, 2 * C), float(np.sqrt(3.0 / (2 * C))))
+        w[d + ".emb_layers.0.1.bias"] = _tensor(seed, d + ".embb", (192,), 0.05)
+    return w

@@ -28,10 +28,11 @@ def _f(a: np.ndarray):
 
 def build(force: bool = False) -> None:
     """Compile the oracle (and the reference shim when /root/reference exists)."""
-    if force or not ORACLE_SO.exists() or ORACLE_SO.stat().st_mtime < (HERE / "nasr_oracle.c").stat().st_mtime:
+    srcs = [HERE / n for n in ("nasr_oracle.c", "nasr_oracle.h", "diar_oracle.c", "diar_oracle.h")]
+    if force or not ORACLE_SO.exists() or ORACLE_SO.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
         subprocess.check_call(["make", "-C", str(HERE), "libnasr_oracle.so"], stdout=subprocess.DEVNULL)
     ref_root = Path(os.environ.get("NASR_REFERENCE", "/root/reference"))
-    if (ref_root / "src").is_dir() and (force or not REF_SO.exists()):
+    if (ref_root / "src").is_dir() and (force or not REF_SO.exists() or REF_SO.stat().st_mtime < (HERE / "ref_shim.cpp").stat().st_mtime):
         subprocess.check_call(["make", "-C", str(HERE), "ref", f"REF={ref_root}"], stdout=subprocess.DEVNULL)
 
 

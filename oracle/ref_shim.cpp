@@ -164,3 +164,18 @@ int ref_greedy(const float *const *w, const float *enc, int T, int *tokens, int 
 }
 
 }  // extern "C"
+
+// ---- f-4 front end: src/diarize_audio.cpp (ggml-free, compiled unmodified) ---------------------
+#include "diarize_audio.h"
+extern "C" int ref_diar_logmel(const float *audio, int n_samples, int per_feature_normalize, const float *fb,
+                               const float *window, float *out /*[80][t_padded]*/, int cap_frames, int *t_valid) {
+    diarize_audio_cfg cfg;
+    cfg.per_feature_normalize = per_feature_normalize != 0;
+    std::vector<float> mel;
+    size_t tv = 0;
+    const size_t tp = diarize_compute_logmel(audio, (size_t)n_samples, cfg, fb, window, mel, &tv);
+    if ((int)tp > cap_frames) return -1;
+    std::memcpy(out, mel.data(), mel.size() * sizeof(float));
+    if (t_valid) *t_valid = (int)tv;
+    return (int)tp;
+}
