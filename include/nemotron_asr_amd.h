@@ -182,6 +182,25 @@ int nasr_device_free(nasr_engine *e, void *p);
 int nasr_device_upload(nasr_engine *e, void *dst_device, const void *src_host, int64_t bytes);
 int nasr_engine_synchronize(nasr_engine *e);
 
+/* ---- diarization side-car (BASELINE config 5): MarbleNet VAD + TitaNet-L speaker embeddings ----------------------
+ * Replaces the compute of vad_session / spk_session (src/diarize_vad.h:95-135, src/diarize_spk.h:95-120).  weights =
+ * the tensors of diarize.gguf ("vad.*" and/or "spk.*", F32, layouts of scripts/convert_diarize_to_gguf.py:129-158),
+ * same descriptor type as nasr_engine_create.  Not in scope: the onset/offset state machine, sub-segment cursor,
+ * clustering and RTTM output of src/diarize_pipeline.cpp / src/diarize_cluster.cpp (host control flow). */
+typedef struct nasr_diar nasr_diar;
+int  nasr_diar_create(nasr_diar **out, int device_id, const nasr_weight_desc *weights, int n_weights,
+                      int max_windows, int max_segments);
+void nasr_diar_destroy(nasr_diar *d);
+/* vad_session_run_batch (src/diarize_vad.cpp:490-503) for B buffers in one launch sequence: P(speech) of every 0.63 s
+ * window (10 080 samples) of audio[b] at a 10 ms shift (the reference runs each window as its own graph,
+ * src/diarize_pipeline.cpp:204-211).  audio: float samples in [-1, 1] (host, or device with NASR_FLAG_PCM_DEVICE);
+ * n_windows[b] = 1 + (n_samples[b] - 10080) / 160, or 0. */
+int  nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, const int32_t *n_samples, float *const *probs_out,
+                   const int32_t *probs_cap, int32_t *n_windows, uint32_t flags);
+/* spk_session_run_chunk (src/diarize_spk.cpp:601-626) for S sub-segments at once: audio[s] holds 24 000 samples (zero
+ * padded by the caller), lens_samples[s] of them real; emb_out = [S][192]. */
+int  nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, const int32_t *lens_samples, float *emb_out, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

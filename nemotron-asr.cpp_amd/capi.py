@@ -24,6 +24,7 @@ EXPORTS = [
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize",
+    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_vad", "nasr_diar_embed",
 ]
 
 
@@ -68,6 +69,11 @@ def lib():
             getattr(L, f"nasr_stream_{n}").argtypes = [vp]
         L.nasr_stream_set_prompt.argtypes = [vp, C.c_int]
         L.nasr_stream_get_stats.argtypes = [vp, C.POINTER(StreamStats)]
+        L.nasr_diar_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(WeightDesc), C.c_int, C.c_int, C.c_int]
+        L.nasr_diar_destroy.argtypes = [vp]
+        L.nasr_diar_destroy.restype = None
+        L.nasr_diar_vad.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
+        L.nasr_diar_embed.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(C.c_float), C.c_uint32]
         L.nasr_stream_get_token_frames.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
         L.nasr_engine_step.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
         L.nasr_engine_step_mel.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
@@ -153,6 +159,75 @@ class Stream:
         return out[:n].copy()
 
 
+def weight_descs(weights: dict):
+    """name -> ndarray (F32) or (ggml type id, packed bytes, logical shape)  ->  (keep-alive list, WeightDesc array)"""
+    keep, descs = [], (WeightDesc * len(weights))()
+    for i, (name, v) in enumerate(weights.items()):
+        if isinstance(v, tuple):
+            tid, raw, shape = v
+            raw = np.ascontiguousarray(raw)
+        else:
+            tid, raw, shape = TYPE_F32, np.ascontiguousarray(v, np.float32), v.shape
+        keep.append(raw)
+        d = descs[i]
+        d.name = name.encode()
+        d.type = tid
+        d.n_dims = len(shape)
+        for j, s in enumerate(reversed(shape)):     # ggml order: ne[0] fastest
+            d.ne[j] = s
+        for j in range(len(shape), 4):
+            d.ne[j] = 1
+        d.data = raw.ctypes.data
+    return keep, descs
+
+
+class Diar:
+    """Diarization side-car (MarbleNet VAD + TitaNet-L embeddings) through the C ABI."""
+
+    def __init__(self, weights: dict, max_windows=8192, max_segments=64, device=0):
+        L = lib()
+        keep, descs = weight_descs(weights)
+        h = C.c_void_p()
+        _chk(L.nasr_diar_create(C.byref(h), device, descs, len(weights), max_windows, max_segments))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().nasr_diar_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def vad(self, audios: list) -> list:
+        """P(speech) of every 0.63 s window (10 ms shift) of each float32 buffer -> list of float32 arrays"""
+        B = len(audios)
+        bufs = [np.ascontiguousarray(a, np.float32) for a in audios]
+        n = (C.c_int32 * B)(*[b.size for b in bufs])
+        outs = [np.zeros(max(1, 1 + (b.size - 10080) // 160 if b.size >= 10080 else 1), np.float32) for b in bufs]
+        ap = (C.c_void_p * B)(*[b.ctypes.data for b in bufs])
+        op = (C.c_void_p * B)(*[o.ctypes.data for o in outs])
+        caps = (C.c_int32 * B)(*[o.size for o in outs])
+        nw = (C.c_int32 * B)()
+        _chk(lib().nasr_diar_vad(self.h, B, ap, n, op, caps, nw, 0))
+        return [outs[b][:nw[b]] for b in range(B)]
+
+    def embed(self, segments: list, lens: list = None) -> np.ndarray:
+        """192-d embeddings of 1.5 s sub-segments (each zero padded to 24 000 samples) -> [S][192]"""
+        S = len(segments)
+        bufs = []
+        for a in segments:
+            b = np.zeros(24000, np.float32)
+            a = np.asarray(a, np.float32)[:24000]
+            b[:a.size] = a
+            bufs.append(b)
+        ln = (C.c_int32 * S)(*[(lens[i] if lens else min(len(segments[i]), 24000)) for i in range(S)])
+        ap = (C.c_void_p * S)(*[b.ctypes.data for b in bufs])
+        out = np.zeros((S, 192), np.float32)
+        _chk(lib().nasr_diar_embed(self.h, S, ap, ln, out.ctypes.data_as(C.POINTER(C.c_float)), 0))
+        return out
+
+
 class Engine:
     """weights: dict name -> ndarray (float32, or (type_id, raw bytes ndarray, shape) for quantised)."""
 
@@ -161,23 +236,7 @@ class Engine:
         L = lib()
         self.n_layers = n_layers
         hp = default_hparams(n_layers, kernel_size, num_prompts)
-        keep, descs = [], (WeightDesc * len(weights))()
-        for i, (name, v) in enumerate(weights.items()):
-            if isinstance(v, tuple):
-                tid, raw, shape = v
-                raw = np.ascontiguousarray(raw)
-            else:
-                tid, raw, shape = TYPE_F32, np.ascontiguousarray(v, np.float32), v.shape
-            keep.append(raw)
-            d = descs[i]
-            d.name = name.encode()
-            d.type = tid
-            d.n_dims = len(shape)
-            for j, s in enumerate(reversed(shape)):     # ggml order: ne[0] fastest
-                d.ne[j] = s
-            for j in range(len(shape), 4):
-                d.ne[j] = 1
-            d.data = raw.ctypes.data
+        keep, descs = weight_descs(weights)
         h = C.c_void_p()
         _chk(L.nasr_engine_create(C.byref(h), device, dtype, C.byref(hp), descs, len(weights), max_streams))
         self.h = h

@@ -214,4 +214,79 @@ void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, co
     else hipLaunchKernelGGL(k_sub_dw<false>, dim3(Hout * Wout, B), dim3(SUBC), 0, st, in, Hin, Win, wt, bias, out, Hout, Wout);
 }
 
+
+// ---- diarization front end: stateless 80-mel log spectrogram of a whole window (src/diarize_audio.cpp:136-227) ----
+// One workgroup per (frame, window).  Unlike the streaming ASR front end above: pre-emphasis restarts in every
+// window (y[0] = x[0], :83-93), the STFT is centred with zero padding (:119-125), power = re^2 + im^2 without the
+// sqrt round trip (:127-131), frames >= t_valid (the +1 frame of the centred STFT and the pad-to-16 tail) are zeros.
+// Operation order as in the reference (this file is compiled without FMA contraction).
+__global__ __launch_bounds__(256) void k_diar_logmel(DiarMelParams p) {
+    const int t = blockIdx.x, w = blockIdx.y;
+    float *out = p.mel + ((size_t)w * p.T_pad + t) * p.cpitch;
+    if (t >= p.t_valid) {
+        for (int c = threadIdx.x; c < p.cpitch; c += 256) out[c] = 0.0f;
+        return;
+    }
+    __shared__ float re[NFFT], im[NFFT], pw[NBINS + 3];
+    const float *x = p.audio + p.win_off[w];
+    const int start = t * HOP - NFFT / 2;
+    for (int i = threadIdx.x; i < NFFT; i += 256) {
+        const int idx = start + i;
+        float s = 0.0f;
+        if (idx >= 0 && idx < p.n_win) s = idx == 0 ? x[0] : __fsub_rn(x[idx], __fmul_rn(0.97f, x[idx - 1]));
+        const float v = __fmul_rn(s, p.window[i]);
+        const int j = (int)(__brev((unsigned)i) >> 23);
+        re[j] = v;
+        im[j] = 0.0f;
+    }
+    __syncthreads();
+    for (int m = 2; m <= NFFT; m <<= 1) {                              // :56-74
+        const int m2 = m >> 1, step = NFFT / m;
+        const int bf = threadIdx.x;
+        const int k = (bf / m2) * m, j = bf % m2;
+        const float wr = p.cos_t[j * step], wi = -p.sin_t[j * step];
+        const int i1 = k + j, i2 = i1 + m2;
+        const float r1 = re[i1], q1 = im[i1], r2 = re[i2], q2 = im[i2];
+        const float tr = __fsub_rn(__fmul_rn(wr, r2), __fmul_rn(wi, q2));
+        const float ti = __fadd_rn(__fmul_rn(wr, q2), __fmul_rn(wi, r2));
+        re[i2] = __fsub_rn(r1, tr);
+        im[i2] = __fsub_rn(q1, ti);
+        re[i1] = __fadd_rn(r1, tr);
+        im[i1] = __fadd_rn(q1, ti);
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < NBINS; k += 256) pw[k] = __fadd_rn(__fmul_rn(re[k], re[k]), __fmul_rn(im[k], im[k]));
+    __syncthreads();
+    if (threadIdx.x < DIAR_NMEL) {
+        float sum = 0.0f;                                              // band of the triangular filter: same sum (see k_melframes)
+        const int k_lo = p.fb_band[2 * threadIdx.x], k_hi = p.fb_band[2 * threadIdx.x + 1];
+        for (int k = k_lo; k < k_hi; k++) sum = __fadd_rn(sum, __fmul_rn(p.fbT[k * DIAR_NMEL + threadIdx.x], pw[k]));
+        out[threadIdx.x] = logf(__fadd_rn(sum, 5.960464477539063e-8f));
+    } else if ((int)threadIdx.x < p.cpitch) {
+        out[threadIdx.x] = 0.0f;
+    }
+}
+
+// per-feature normalisation over the t_valid frames (:182-199): mean and Bessel-corrected std in double, as the reference
+__global__ __launch_bounds__(128) void k_diar_featnorm(DiarMelParams p) {
+    const int w = blockIdx.x, m = threadIdx.x;
+    if (m >= DIAR_NMEL) return;
+    float *base = p.mel + (size_t)w * p.T_pad * p.cpitch + m;
+    const int n_eff = p.t_valid, denom = n_eff - 1 > 1 ? n_eff - 1 : 1;
+    double sum = 0.0;
+    for (int t = 0; t < n_eff; t++) sum += (double)base[(size_t)t * p.cpitch];
+    const float mean = (float)(sum / n_eff);
+    double var = 0.0;
+    for (int t = 0; t < n_eff; t++) { const float d = __fsub_rn(base[(size_t)t * p.cpitch], mean); var += (double)d * (double)d; }
+    const float std_v = __fadd_rn(sqrtf((float)(var / denom)), 1e-5f);
+    const float inv_std = 1.0f / std_v;
+    for (int t = 0; t < n_eff; t++) base[(size_t)t * p.cpitch] = __fmul_rn(__fsub_rn(base[(size_t)t * p.cpitch], mean), inv_std);
+}
+
+void launch_diar_logmel(const DiarMelParams &p, int W, bool per_feature_normalize, hipStream_t st) {
+    if (W <= 0) return;
+    hipLaunchKernelGGL(k_diar_logmel, dim3(p.T_pad, W), dim3(256), 0, st, p);
+    if (per_feature_normalize) hipLaunchKernelGGL(k_diar_featnorm, dim3(W), dim3(128), 0, st, p);
+}
+
 }  // namespace nasr

@@ -1,0 +1,320 @@
+// nasr_diar.hip -- diarization side-car behind the C ABI.
+//
+// Replaces the compute of the reference's vad_session / spk_session (src/diarize_vad.cpp:436-503,
+// src/diarize_spk.cpp:601-626): one ggml graph per 0.63 s window / per 1.5 s sub-segment there, one launch sequence
+// over ALL windows (of all streams) / all sub-segments here.  Host control flow around it (onset/offset state machine,
+// sub-segment cursor, clustering, RTTM) is out of scope.
+#include "nasr_internal.h"
+#include "nemotron_asr_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace nasr;
+
+void api_lock_shared();
+void api_unlock_shared();
+namespace {
+struct Guard { Guard() { api_lock_shared(); } ~Guard() { api_unlock_shared(); } };
+
+int failf(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return set_error(buf);
+}
+#define DCHK(x)                                                                                                  \
+    do {                                                                                                         \
+        hipError_t e_ = (x);                                                                                     \
+        if (e_ != hipSuccess) return failf("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Topo { int kernel, dil, repeat, cin, cout; bool residual, separable, has_se; };
+const Topo VAD_TOPO[6] = {{11, 1, 1, 80, 128, false, true, false}, {13, 1, 2, 128, 64, true, true, false},
+                          {15, 1, 2, 64, 64, true, true, false},   {17, 1, 2, 64, 64, true, true, false},
+                          {29, 2, 1, 64, 128, false, true, false}, {1, 1, 1, 128, 128, false, false, false}};   // src/diarize_vad.cpp:25-32
+}  // namespace
+
+struct nasr_diar {
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::vector<void *> allocs;
+    std::map<std::string, std::vector<float>> host;     // tensors by name (only during create)
+    bool has_vad = false, has_spk = false;
+    int max_windows = 0, max_segments = 0;
+    // front end constants (both namespaces use the same 80-mel preprocessor layout)
+    float *window = nullptr, *cos_t = nullptr, *sin_t = nullptr;
+    float *vad_fbT = nullptr; int *vad_band = nullptr;
+    VadNet vad{};
+    // scratch
+    float *audio = nullptr; size_t audio_cap = 0;       // staged input samples
+    long long *win_off = nullptr; int *lens = nullptr;   // [max_windows]
+    float *mel = nullptr, *prob = nullptr;               // [max_windows][64][80], [max_windows]
+    char *pin = nullptr; size_t pin_cap = 0;             // pinned staging for descriptors / results
+};
+
+namespace {
+template <typename Tp>
+int dalloc(nasr_diar *d, Tp **out, size_t n) {
+    void *p = nullptr;
+    DCHK(hipMalloc(&p, std::max<size_t>(n * sizeof(Tp), 16)));
+    d->allocs.push_back(p);
+    *out = (Tp *)p;
+    return 0;
+}
+template <typename Tp>
+int upload(nasr_diar *d, const std::vector<Tp> &h, Tp **dev) {
+    if (dalloc(d, dev, h.size())) return -1;
+    DCHK(hipMemcpy(*dev, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    return 0;
+}
+const std::vector<float> *get(nasr_diar *d, const std::string &name, size_t want) {
+    auto it = d->host.find(name);
+    if (it == d->host.end()) { failf("diarize weights: missing tensor '%s'", name.c_str()); return nullptr; }
+    if (want && it->second.size() != want) { failf("diarize weights: tensor '%s' has %zu elements, expected %zu", name.c_str(), it->second.size(), want); return nullptr; }
+    return &it->second;
+}
+// folded batch norm (src/diarize_vad.cpp:56-79): scale = gamma / sqrt(var + eps), bias = beta - mean * scale
+int fold_bn(nasr_diar *d, const std::string &prefix, int C, float eps, std::vector<float> &scale, std::vector<float> &bias) {
+    const auto *g = get(d, prefix + ".weight", C), *b = get(d, prefix + ".bias", C);
+    const auto *m = get(d, prefix + ".running_mean", C), *v = get(d, prefix + ".running_var", C);
+    if (!g || !b || !m || !v) return -1;
+    scale.resize(C); bias.resize(C);
+    for (int i = 0; i < C; i++) {
+        const float s = (*g)[i] / std::sqrt((*v)[i] + eps);
+        scale[i] = s;
+        bias[i] = (*b)[i] - (*m)[i] * s;
+    }
+    return 0;
+}
+int front_end_constants(nasr_diar *d, const std::string &ns, float **fbT, int **band) {
+    const auto *fb = get(d, ns + ".preprocessor.featurizer.fb", (size_t)DIAR_NMEL * NBINS);
+    const auto *win = get(d, ns + ".preprocessor.featurizer.window", WIN);
+    if (!fb || !win) return -1;
+    if (!d->window) {
+        std::vector<float> wp(NFFT, 0.0f), ct(NFFT), sn(NFFT);
+        memcpy(wp.data() + (NFFT - WIN) / 2, win->data(), WIN * sizeof(float));          // src/diarize_audio.cpp:145-147
+        for (int i = 0; i < NFFT; i++) {
+            const float th = (2.0f * (float)M_PI * (float)i) / (float)NFFT;                  // :28-32
+            sn[i] = sinf(th);
+            ct[i] = cosf(th);
+        }
+        if (upload(d, wp, &d->window) || upload(d, ct, &d->cos_t) || upload(d, sn, &d->sin_t)) return -1;
+    }
+    std::vector<float> t((size_t)NBINS * DIAR_NMEL);
+    std::vector<int> bd(2 * DIAR_NMEL);
+    for (int m = 0; m < DIAR_NMEL; m++) {
+        int lo = NBINS, hi = 0;
+        for (int k = 0; k < NBINS; k++) {
+            const float v = (*fb)[(size_t)m * NBINS + k];
+            t[(size_t)k * DIAR_NMEL + m] = v;
+            if (v != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
+        }
+        if (lo > hi) lo = hi = 0;
+        bd[2 * m] = lo; bd[2 * m + 1] = hi;
+    }
+    return upload(d, t, fbT) || upload(d, bd, band) ? -1 : 0;
+}
+
+int load_vad(nasr_diar *d) {
+    if (front_end_constants(d, "vad", &d->vad_fbT, &d->vad_band)) return -1;
+    int si = 0;
+    for (int b = 0; b < 6; b++) {
+        const Topo &t = VAD_TOPO[b];
+        const std::string pre = "vad.encoder.encoder." + std::to_string(b);
+        for (int s = 0; s < t.repeat; s++, si++) {
+            const int cin = s == 0 ? t.cin : t.cout;
+            int dw_i = 5 * s, pw_i = 5 * s + 1, bn_i = 5 * s + 2;
+            if (!t.separable) { pw_i = 0; bn_i = 1; }                                        // :160-162
+            VadSub &vs = d->vad.sub[si];
+            vs.kernel = t.kernel; vs.dil = t.dil; vs.cin = cin; vs.cout = t.cout; vs.dw = nullptr;
+            float *p;
+            if (t.separable) {
+                const auto *dw = get(d, pre + ".mconv." + std::to_string(dw_i) + ".conv.weight", (size_t)t.kernel * cin);
+                if (!dw || upload(d, *dw, &p)) return -1;
+                vs.dw = p;
+            }
+            const auto *pw = get(d, pre + ".mconv." + std::to_string(pw_i) + ".conv.weight", (size_t)t.cout * cin);
+            if (!pw || upload(d, *pw, &p)) return -1;
+            vs.pw = p;
+            std::vector<float> sc, bi;
+            if (fold_bn(d, pre + ".mconv." + std::to_string(bn_i), t.cout, 1e-3f, sc, bi)) return -1;   // Jasper BN eps 1e-3 (:34-36)
+            if (upload(d, sc, &p)) return -1;
+            vs.scale = p;
+            if (upload(d, bi, &p)) return -1;
+            vs.bias = p;
+        }
+        if (t.residual) {
+            VadSub &vr = d->vad.res[b - 1];
+            vr.kernel = 1; vr.dil = 1; vr.cin = t.cin; vr.cout = t.cout; vr.dw = nullptr;
+            float *p;
+            const auto *pw = get(d, pre + ".res.0.0.conv.weight", (size_t)t.cout * t.cin);
+            if (!pw || upload(d, *pw, &p)) return -1;
+            vr.pw = p;
+            std::vector<float> sc, bi;
+            if (fold_bn(d, pre + ".res.0.1", t.cout, 1e-3f, sc, bi)) return -1;
+            if (upload(d, sc, &p)) return -1;
+            vr.scale = p;
+            if (upload(d, bi, &p)) return -1;
+            vr.bias = p;
+        }
+    }
+    float *p;
+    const auto *dw = get(d, "vad.decoder.decoder_layers.0.weight", 2 * 128), *db = get(d, "vad.decoder.decoder_layers.0.bias", 2);
+    if (!dw || !db || upload(d, *dw, &p)) return -1;
+    d->vad.dec_w = p;
+    if (upload(d, *db, &p)) return -1;
+    d->vad.dec_b = p;
+    if (dalloc(d, &d->win_off, (size_t)d->max_windows) || dalloc(d, &d->lens, (size_t)d->max_windows) ||
+        dalloc(d, &d->mel, (size_t)d->max_windows * VAD_T * DIAR_NMEL) || dalloc(d, &d->prob, (size_t)d->max_windows))
+        return -1;
+    return 0;
+}
+
+int stage_audio(nasr_diar *d, const float *const *audio, const int32_t *n, int B, bool on_device, std::vector<long long> &base) {
+    size_t total = 0;
+    base.resize(B);
+    for (int b = 0; b < B; b++) { base[b] = (long long)total; total += (size_t)std::max(n[b], 0); }
+    if (total > d->audio_cap) {
+        DCHK(hipStreamSynchronize(d->st));
+        if (d->audio) hipFree(d->audio);
+        d->audio = nullptr;
+        d->audio_cap = total + 65536;
+        DCHK(hipMalloc((void **)&d->audio, d->audio_cap * sizeof(float)));
+    }
+    for (int b = 0; b < B; b++)
+        if (n[b] > 0)
+            DCHK(hipMemcpyAsync(d->audio + base[b], audio[b], (size_t)n[b] * sizeof(float),
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d->st));
+    return 0;
+}
+}  // namespace
+
+static int nasr_diar_load_spk(nasr_diar *d);
+
+extern "C" void nasr_diar_destroy(nasr_diar *d) {
+    if (!d) return;
+    Guard g;
+    hipSetDevice(d->device);
+    if (d->st) hipStreamSynchronize(d->st);
+    for (void *p : d->allocs) hipFree(p);
+    if (d->audio) hipFree(d->audio);
+    if (d->pin) hipHostFree(d->pin);
+    if (d->st) hipStreamDestroy(d->st);
+    delete d;
+}
+
+extern "C" int nasr_diar_create(nasr_diar **out, int device_id, const nasr_weight_desc *weights, int n_weights,
+                                int max_windows, int max_segments) {
+    Guard g;
+    if (!out || !weights || n_weights <= 0) return failf("null argument");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return failf("no HIP device visible: the diarization engine is MI355X-only, there is no CPU fallback");
+    if (device_id < 0 || device_id >= n_dev) return failf("device %d out of range (%d visible)", device_id, n_dev);
+    DCHK(hipSetDevice(device_id));
+    nasr_diar *d = new nasr_diar();
+    d->device = device_id;
+    d->max_windows = std::max(max_windows, 1);
+    d->max_segments = std::max(max_segments, 1);
+    for (int i = 0; i < n_weights; i++) {
+        const nasr_weight_desc &w = weights[i];
+        if (!w.name || !w.data) { delete d; return failf("weight %d: null name or data", i); }
+        const bool vad = !strncmp(w.name, "vad.", 4), spk = !strncmp(w.name, "spk.", 4);
+        if (!vad && !spk) continue;
+        if (w.type != NASR_TYPE_F32) { delete d; return failf("diarize tensor '%s': only F32 is supported (scripts/convert_diarize_to_gguf.py writes F32)", w.name); }
+        size_t n = 1;
+        for (int k = 0; k < w.n_dims; k++) n *= (size_t)w.ne[k];
+        d->host[w.name].assign((const float *)w.data, (const float *)w.data + n);
+        d->has_vad |= vad;
+        d->has_spk |= spk;
+    }
+    if (!d->has_vad && !d->has_spk) { delete d; return failf("no 'vad.*' or 'spk.*' tensors among the %d weights", n_weights); }
+    if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) { delete d; return failf("hipStreamCreate failed"); }
+    init_diar_kernel_attributes();
+    d->pin_cap = (size_t)(d->max_windows + d->max_segments * SPK_EMB + 4096) * 16;
+    if (hipHostMalloc((void **)&d->pin, d->pin_cap, hipHostMallocDefault) != hipSuccess) { nasr_diar_destroy(d); return failf("hipHostMalloc failed"); }
+    int rc = 0;
+    if (d->has_vad) rc |= load_vad(d);
+    if (!rc && d->has_spk) rc |= nasr_diar_load_spk(d);
+    if (rc) { api_unlock_shared(); nasr_diar_destroy(d); api_lock_shared(); return -1; }
+    d->host.clear();
+    if (hipStreamSynchronize(d->st) != hipSuccess) { api_unlock_shared(); nasr_diar_destroy(d); api_lock_shared(); return failf("diar init sync failed"); }
+    *out = d;
+    return 0;
+}
+
+// vad_session_run_batch (src/diarize_vad.cpp:490-503) for B buffers in one launch sequence: every 0.63 s window of
+// every buffer at a 10 ms shift -> P(speech).  audio[b]: n_samples[b] float samples in [-1, 1].
+extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, const int32_t *n_samples, float *const *probs_out,
+                             const int32_t *probs_cap, int32_t *n_windows, uint32_t flags) {
+    Guard g;
+    if (!d || !audio || !n_samples || B < 1) return failf("null argument or B < 1");
+    if (!d->has_vad) return failf("this diarization engine was created without 'vad.*' tensors");
+    DCHK(hipSetDevice(d->device));
+    std::vector<long long> base;
+    std::vector<int> first(B + 1, 0);
+    for (int b = 0; b < B; b++) {
+        if (n_samples[b] < 0 || (n_samples[b] > 0 && !audio[b])) return failf("stream %d: bad audio / n_samples", b);
+        const int nw = n_samples[b] < VAD_WINDOW ? 0 : 1 + (n_samples[b] - VAD_WINDOW) / HOP;      // :492-493
+        first[b + 1] = first[b] + nw;
+    }
+    const int W = first[B];
+    if (n_windows) for (int b = 0; b < B; b++) n_windows[b] = first[b + 1] - first[b];
+    if (W == 0) return 0;
+    if (stage_audio(d, audio, n_samples, B, (flags & NASR_FLAG_PCM_DEVICE) != 0, base)) return -1;
+    // windows in tiles of max_windows
+    for (int w0 = 0; w0 < W; w0 += d->max_windows) {
+        const int Wt = std::min(d->max_windows, W - w0);
+        long long *h_off = (long long *)d->pin;
+        int *h_len = (int *)(d->pin + (size_t)d->max_windows * sizeof(long long));
+        float *h_prob = (float *)(d->pin + (size_t)d->max_windows * (sizeof(long long) + sizeof(int)));
+        int b = 0;
+        for (int i = 0; i < Wt; i++) {
+            const int w = w0 + i;
+            while (w >= first[b + 1]) b++;
+            h_off[i] = base[b] + (long long)(w - first[b]) * HOP;
+            h_len[i] = VAD_WINDOW / HOP;                                       // full windows: 63 valid frames
+        }
+        DCHK(hipMemcpyAsync(d->win_off, h_off, (size_t)Wt * sizeof(long long), hipMemcpyHostToDevice, d->st));
+        DCHK(hipMemcpyAsync(d->lens, h_len, (size_t)Wt * sizeof(int), hipMemcpyHostToDevice, d->st));
+        DiarMelParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.audio = d->audio; mp.win_off = d->win_off; mp.n_win = VAD_WINDOW; mp.T_pad = VAD_T; mp.t_valid = VAD_TVALID;
+        mp.cpitch = DIAR_NMEL; mp.mel = d->mel; mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band;
+        mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+        launch_diar_logmel(mp, Wt, false, d->st);
+        launch_vad_marblenet(d->vad, d->mel, d->lens, d->prob, Wt, d->st);
+        DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)Wt * sizeof(float), hipMemcpyDeviceToHost, d->st));
+        DCHK(hipStreamSynchronize(d->st));
+        b = 0;
+        for (int i = 0; i < Wt; i++) {
+            const int w = w0 + i;
+            while (w >= first[b + 1]) b++;
+            const int k = w - first[b];
+            if (probs_out && probs_out[b] && probs_cap && k < probs_cap[b]) probs_out[b][k] = h_prob[i];
+        }
+    }
+    return 0;
+}
+
+static int nasr_diar_load_spk(nasr_diar *d) {
+    (void)d;
+    return failf("speaker-embedding tensors ('spk.*') are not supported by this build yet");
+}
+
+extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, const int32_t *lens_samples, float *emb_out, uint32_t flags) {
+    Guard g;
+    (void)S; (void)audio; (void)lens_samples; (void)emb_out; (void)flags;
+    if (!d) return failf("null argument");
+    return failf("speaker embeddings are not supported by this build yet");
+}

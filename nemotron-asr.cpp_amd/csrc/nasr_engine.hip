@@ -29,6 +29,9 @@ static int fail(const char *fmt, ...) {
     va_end(ap);
     return -1;
 }
+namespace nasr {
+int set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return -1; }
+}
 #define HIPCHK(x)                                                                           \
     do {                                                                                    \
         hipError_t e_ = (x);                                                                \
@@ -49,6 +52,8 @@ struct ApiGuard {
     ApiGuard() { g_api_mu.lock_shared(); }
     ~ApiGuard() { g_api_mu.unlock_shared(); }
 };
+void api_lock_shared() { g_api_mu.lock_shared(); }       // for the other translation units (nasr_diar.hip)
+void api_unlock_shared() { g_api_mu.unlock_shared(); }
 struct CaptureExclusive {       // held by a thread that is inside an ApiGuard
     CaptureExclusive() { g_api_mu.unlock_shared(); g_api_mu.lock(); }
     ~CaptureExclusive() { g_api_mu.unlock(); g_api_mu.lock_shared(); }

@@ -225,4 +225,37 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // RNE; NaN kept NaN
     return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+
+// ---- diarization side-car (reference src/diarize_{audio,vad,spk}.cpp) -----------------
+constexpr int DIAR_NMEL = 80;
+constexpr int VAD_WINDOW = 10080, VAD_T = 64, VAD_TVALID = 63;      // src/diarize_vad.h:86-89
+constexpr int SPK_SEGMENT = 24000, SPK_T = 160, SPK_TVALID = 150;   // src/diarize_spk.h:102-104
+constexpr int SPK_EMB = 192, SPK_C = 3072, SPK_ATT = 128;
+
+struct DiarMelParams {            // one workgroup per (frame, window)
+    const float *audio;           // all windows index into this buffer
+    const long long *win_off;     // [W] sample offset of every window
+    int n_win;                    // samples per window (10080 / 24000)
+    int T_pad, t_valid;           // frames written per window (64 / 160), of which valid (63 / 150)
+    int cpitch;                   // channel pitch of the output rows (80, or 96 = zero padded for the K % 32 GEMM)
+    float *mel;                   // [W][T_pad][cpitch]
+    const float *window;          // [512] padded Hann
+    const float *fbT;             // [257][80]
+    const int *fb_band;           // [80][2]
+    const float *cos_t, *sin_t;   // [512]
+};
+void launch_diar_logmel(const DiarMelParams &p, int W, bool per_feature_normalize, hipStream_t st);
+
+struct VadSub { const float *dw, *pw, *scale, *bias; int kernel, dil, cin, cout; };   // dw == nullptr: pointwise only
+struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blocks, 9 sub-convs, 3 residual paths
+    VadSub sub[9];
+    VadSub res[3];                // blocks 1..3
+    const float *dec_w, *dec_b;   // [2][128], [2]
+};
+// one workgroup per window: mel [W][64][80] -> P(speech) [W]; lens_mel [W] valid frames (masked convs)
+void launch_vad_marblenet(const VadNet &net, const float *mel, const int *lens_mel, float *prob, int W, hipStream_t st);
+void init_diar_kernel_attributes();
+int set_error(const char *msg);      // fills nasr_last_error() of the calling thread, returns -1
+
+
 }  // namespace nasr

@@ -1,0 +1,48 @@
+"""SURVEY.md section 8 f-4 on the GPU, through the C ABI: the batched sliding-window VAD and the speaker embeddings
+against the CPU restatement (oracle/diar_oracle.c)."""
+import numpy as np
+import pytest
+
+from nemotron_asr_amd import capi, synth
+from oracle import diar_binding as db
+
+pytestmark = pytest.mark.gpu
+
+
+def _audio(seed, n):
+    return synth.make_pcm(seed, n / 16000.0 + 0.01)[:n].astype(np.float32) / 32768.0
+
+
+@pytest.fixture(scope="module")
+def Wv():
+    return synth.make_diar_weights(spk=False)
+
+
+def test_vad_batched_windows_match_oracle(Wv):
+    """3 buffers of different lengths (one shorter than a window, one exactly one window) in ONE call: every 0.63 s window
+    at a 10 ms shift == the oracle's window-by-window run; also through tiles smaller than the window count."""
+    om = db.DiarModel(Wv)
+    audios = [_audio(1, 10080 + 160 * 37 + 55), _audio(2, 9000), _audio(3, 10080)]
+    ref = [om.vad_batch(a) for a in audios]
+    for max_windows in (4096, 16):
+        eng = capi.Diar(Wv, max_windows=max_windows)
+        got = eng.vad(audios)
+        assert [g.size for g in got] == [38, 0, 1] == [r.size for r in ref]
+        for g, r in zip(got, ref):
+            if r.size:
+                assert np.abs(g - r).max() < 2e-5, np.abs(g - r).max()
+        assert 0.0 < got[0].min() and got[0].max() < 1.0 and np.ptp(got[0]) > 1e-4     # not a constant
+        eng.close()
+
+
+def test_vad_errors(Wv):
+    eng = capi.Diar(Wv)
+    with pytest.raises(capi.NasrError):
+        eng.embed([_audio(1, 24000)])            # no 'spk.*' tensors in this engine
+    with pytest.raises(capi.NasrError):
+        capi.Diar({"encoder.x": np.zeros(4, np.float32)})
+    bad = dict(Wv)
+    del bad["vad.encoder.encoder.3.res.0.1.running_var"]
+    with pytest.raises(capi.NasrError, match="running_var"):
+        capi.Diar(bad)
+    eng.close()
