@@ -188,7 +188,9 @@ int nasr_engine_synchronize(nasr_engine *e);
  * same descriptor type as nasr_engine_create.  Not in scope: the onset/offset state machine, sub-segment cursor,
  * clustering and RTTM output of src/diarize_pipeline.cpp / src/diarize_cluster.cpp (host control flow). */
 typedef struct nasr_diar nasr_diar;
-int  nasr_diar_create(nasr_diar **out, int device_id, const nasr_weight_desc *weights, int n_weights,
+/* dtype: NASR_DTYPE_BF16 = TitaNet's pointwise convolutions on the bf16 MFMA (f32 accumulate), NASR_DTYPE_F32 = all f32;
+ * MarbleNet is always f32.  max_windows / max_segments size the scratch (larger calls are tiled). */
+int  nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
                       int max_windows, int max_segments);
 void nasr_diar_destroy(nasr_diar *d);
 /* vad_session_run_batch (src/diarize_vad.cpp:490-503) for B buffers in one launch sequence: P(speech) of every 0.63 s

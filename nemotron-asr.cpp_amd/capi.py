@@ -69,7 +69,7 @@ def lib():
             getattr(L, f"nasr_stream_{n}").argtypes = [vp]
         L.nasr_stream_set_prompt.argtypes = [vp, C.c_int]
         L.nasr_stream_get_stats.argtypes = [vp, C.POINTER(StreamStats)]
-        L.nasr_diar_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(WeightDesc), C.c_int, C.c_int, C.c_int]
+        L.nasr_diar_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(WeightDesc), C.c_int, C.c_int, C.c_int]
         L.nasr_diar_destroy.argtypes = [vp]
         L.nasr_diar_destroy.restype = None
         L.nasr_diar_vad.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
@@ -184,11 +184,11 @@ def weight_descs(weights: dict):
 class Diar:
     """Diarization side-car (MarbleNet VAD + TitaNet-L embeddings) through the C ABI."""
 
-    def __init__(self, weights: dict, max_windows=8192, max_segments=64, device=0):
+    def __init__(self, weights: dict, dtype=DTYPE_BF16, max_windows=8192, max_segments=64, device=0):
         L = lib()
         keep, descs = weight_descs(weights)
         h = C.c_void_p()
-        _chk(L.nasr_diar_create(C.byref(h), device, descs, len(weights), max_windows, max_segments))
+        _chk(L.nasr_diar_create(C.byref(h), device, dtype, descs, len(weights), max_windows, max_segments))
         self.h = h
 
     def close(self):

@@ -130,4 +130,171 @@ void launch_vad_marblenet(const VadNet &net, const float *mel, const int *lens_m
     hipLaunchKernelGGL(k_vad_marblenet, dim3(W), dim3(256), 3 * VT * VC * 4, st, net, mel, lens_mel, prob);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// TitaNet-L speaker embedding (reference src/diarize_spk.cpp).  1024-3072 channels x 160 frames do not fit a CU's
+// LDS, so the network runs layer by layer over ALL sub-segments of the call: the pointwise convolutions are GEMMs
+// with M = S * 160 rows (kernels_gemm.hip: folded BN scale in the weights, BN bias (+ReLU) in the epilogue), the
+// kernels below are what sits between them.  Rows t >= lens of a segment are masked (MaskedConv1d) on READ.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_a(void *base, size_t idx, float v, int bf16) {
+    if (bf16) ((bf16_t *)base)[idx] = f32_to_bf16(v);
+    else ((float *)base)[idx] = v;
+}
+
+// depthwise 'same' conv, dilation 1 (src/diarize_spk.cpp:256-282); kernel == 1 is the per-channel scaling of :263-267.
+// out row t >= lens = 0 (the mask in front of the pointwise conv), channels C..Cpad-1 = 0 (K padding of the GEMM)
+__global__ __launch_bounds__(256) void k_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad,
+                                                       const int *lens, void *a_out, int out_bf16) {
+    const int t = blockIdx.x, s = blockIdx.y, L = lens[s], pad = (kernel - 1) / 2;
+    const float *xs = x + (size_t)s * SPK_T * x_pitch;
+    for (int c = threadIdx.x; c < Cpad; c += 256) {
+        float acc = 0.0f;
+        if (t < L && c < C) {
+            for (int i = 0; i < kernel; i++) {
+                const int tt = t + i - pad;
+                const float v = (tt >= 0 && tt < L) ? xs[(size_t)tt * x_pitch + c] : 0.0f;
+                const float prod = v * w[(size_t)i * C + c];
+                acc = i == 0 ? prod : acc + prod;
+            }
+        }
+        store_a(a_out, ((size_t)s * SPK_T + t) * Cpad + c, acc, out_bf16);
+    }
+}
+void launch_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad, const int *lens, void *a_out,
+                          int out_bf16, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_depthwise, dim3(SPK_T, S), dim3(256), 0, st, x, x_pitch, w, kernel, C, Cpad, lens, a_out, out_bf16);
+}
+
+// masked copy into the GEMM operand type (input of the residual 1x1 conv :369-372 and of the attention conv)
+__global__ __launch_bounds__(256) void k_spk_mask_cvt(const float *x, int C, const int *lens, void *a_out, int out_bf16) {
+    const int t = blockIdx.x, s = blockIdx.y, L = lens[s];
+    const size_t row = ((size_t)s * SPK_T + t) * C;
+    for (int c = threadIdx.x; c < C; c += 256) store_a(a_out, row + c, t < L ? x[row + c] : 0.0f, out_bf16);
+}
+void launch_spk_mask_cvt(const float *x, int C, const int *lens, void *a_out, int out_bf16, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_mask_cvt, dim3(SPK_T, S), dim3(256), 0, st, x, C, lens, a_out, out_bf16);
+}
+
+// squeeze-excite gate of one segment (:303-315): z = sigmoid(fc2 . relu(fc1 . masked_mean_T(y)))
+__global__ __launch_bounds__(256) void k_spk_se(const float *y, int C, const int *lens, const float *fc1, const float *fc2, float *z) {
+    extern __shared__ float sm[];                 // mean [C], hidden [C / 8]
+    float *mean = sm, *hid = sm + C;
+    const int s = blockIdx.x, L = lens[s], H = C / 8;
+    const float inv = 1.0f / (float)L;
+    const float *ys = y + (size_t)s * SPK_T * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sum = 0.0f;
+        for (int t = 0; t < L; t++) sum += ys[(size_t)t * C + c];
+        mean[c] = sum * inv;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < H; j += 4) {           // one wave per hidden unit: coalesced row of fc1
+        float acc = 0.0f;
+        for (int c = lane; c < C; c += 64) acc += fc1[(size_t)j * C + c] * mean[c];
+        acc = wave_sum(acc);
+        if (lane == 0) hid[j] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.0f;
+        for (int j = 0; j < H; j++) acc += fc2[(size_t)c * H + j] * hid[j];
+        z[(size_t)s * C + c] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+void launch_spk_se(const float *y, int C, const int *lens, const float *fc1, const float *fc2, float *z, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_se, dim3(S), dim3(256), (size_t)(C + C / 8) * 4, st, y, C, lens, fc1, fc2, z);
+}
+
+// block output: relu(mask(y) * z + residual)  (:365-377)
+__global__ __launch_bounds__(256) void k_spk_combine(const float *y, const float *z, const float *r, int C, const int *lens, float *out) {
+    const int t = blockIdx.x, s = blockIdx.y, L = lens[s];
+    const size_t row = ((size_t)s * SPK_T + t) * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = t < L ? y[row + c] * z[(size_t)s * C + c] : 0.0f;
+        if (r) v += r[row + c];
+        out[row + c] = fmaxf(v, 0.0f);
+    }
+}
+void launch_spk_combine(const float *y, const float *z, const float *r, int C, const int *lens, float *out, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_combine, dim3(SPK_T, S), dim3(256), 0, st, y, z, r, C, lens, out);
+}
+
+// masked mean / std over time of the encoder output (:392-410): std = sqrt(clamp(mean((x - mean)^2), 1e-10))
+__global__ __launch_bounds__(256) void k_spk_stats(const float *x, int C, const int *lens, float *mean, float *stdv) {
+    const int s = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, L = lens[s];
+    if (c >= C) return;
+    const float *xs = x + (size_t)s * SPK_T * C + c;
+    const float inv = 1.0f / (float)L;
+    float sum = 0.0f;
+    for (int t = 0; t < L; t++) sum += xs[(size_t)t * C];
+    const float m = sum * inv;
+    float v = 0.0f;
+    for (int t = 0; t < L; t++) { const float d = xs[(size_t)t * C] - m; v += d * d; }
+    v *= inv;
+    v = fminf(fmaxf(v, 1e-10f), 1e30f);
+    mean[(size_t)s * C + c] = m;
+    stdv[(size_t)s * C + c] = sqrtf(v);
+}
+void launch_spk_stats(const float *x, int C, const int *lens, float *mean, float *stdv, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_stats, dim3((C + 255) / 256, S), dim3(256), 0, st, x, C, lens, mean, stdv);
+}
+
+// the attention conv sees [x_t ; mean ; std] (:412-421): the mean / std thirds are the same for every frame of a
+// segment, so their contribution (+ the conv bias) is one vector per segment: c[s][a] = W1[a][C:2C].mean + W1[a][2C:].std + b1[a]
+__global__ __launch_bounds__(256) void k_spk_att_const(const float *mean, const float *stdv, const float *w1, const float *b1, float *cst, int C, int A) {
+    const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = blockIdx.x * 4 + wave;
+    if (a >= A) return;
+    const float *w = w1 + (size_t)a * 3 * C;
+    float acc = 0.0f;
+    for (int c = lane; c < C; c += 64) acc += w[C + c] * mean[(size_t)s * C + c];
+    for (int c = lane; c < C; c += 64) acc += w[2 * C + c] * stdv[(size_t)s * C + c];
+    acc = wave_sum(acc);
+    if (lane == 0) cst[(size_t)s * A + a] = acc + b1[a];
+}
+void launch_spk_att_const(const float *mean, const float *stdv, const float *w1, const float *b1, float *c, int C, int A, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_att_const, dim3((A + 3) / 4, S), dim3(256), 0, st, mean, stdv, w1, b1, c, C, A);
+}
+
+// a = tanh(BN(relu(W1x . x_t + c[s])))  (:423-430) -> operand of the second attention conv
+__global__ __launch_bounds__(128) void k_spk_att_post(const float *g, const float *cst, const float *sc, const float *bi, void *a_out, int out_bf16, int A) {
+    const int t = blockIdx.x, s = blockIdx.y, a = threadIdx.x;
+    if (a >= A) return;
+    const size_t row = ((size_t)s * SPK_T + t) * A;
+    float v = g[row + a] + cst[(size_t)s * A + a];
+    v = fmaxf(v, 0.0f);
+    v = v * sc[a] + bi[a];
+    store_a(a_out, row + a, tanhf(v), out_bf16);
+}
+void launch_spk_att_post(const float *g, const float *c, const float *bn_scale, const float *bn_bias, void *a_out, int out_bf16,
+                         int A, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_att_post, dim3(SPK_T, S), dim3(128), 0, st, g, c, bn_scale, bn_bias, a_out, out_bf16, A);
+}
+
+// attentive statistics (:432-487): per channel softmax over the valid frames, weighted mean and std; then the folded
+// BN of the embedding layer.  pool = [S][2C] (mu ; sigma)
+__global__ __launch_bounds__(256) void k_spk_asp(const float *x, const float *logits, int C, const int *lens, const float *sc, const float *bi, float *pool) {
+    const int s = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, L = lens[s];
+    if (c >= C) return;
+    const float *xs = x + (size_t)s * SPK_T * C + c, *ls = logits + (size_t)s * SPK_T * C + c;
+    float mx = -INFINITY;
+    for (int t = 0; t < L; t++) mx = fmaxf(mx, ls[(size_t)t * C]);     // frames >= L carry -1e9: exp() == 0 exactly
+    float Z = 0.0f;
+    for (int t = 0; t < L; t++) Z += expf(ls[(size_t)t * C] - mx);
+    float mu = 0.0f;
+    for (int t = 0; t < L; t++) mu += xs[(size_t)t * C] * (expf(ls[(size_t)t * C] - mx) / Z);
+    float sg = 0.0f;
+    for (int t = 0; t < L; t++) { const float d = xs[(size_t)t * C] - mu; sg += d * d * (expf(ls[(size_t)t * C] - mx) / Z); }
+    // masked frames: x_masked = 0 with weight exp(-1e9 - mx) = 0 -> no contribution to mu or sigma
+    sg = sqrtf(fmaxf(sg, 1e-10f));
+    pool[(size_t)s * 2 * C + c] = mu * sc[c] + bi[c];
+    pool[(size_t)s * 2 * C + C + c] = sg * sc[C + c] + bi[C + c];
+}
+void launch_spk_asp(const float *x, const float *logits, int C, const int *lens, const float *bn_scale, const float *bn_bias,
+                    float *pool, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_asp, dim3((C + 255) / 256, S), dim3(256), 0, st, x, logits, C, lens, bn_scale, bn_bias, pool);
+}
+
 }  // namespace nasr

@@ -54,6 +54,17 @@ struct nasr_diar {
     float *window = nullptr, *cos_t = nullptr, *sin_t = nullptr;
     float *vad_fbT = nullptr; int *vad_band = nullptr;
     VadNet vad{};
+    // TitaNet-L
+    bool bf16 = true; int esz = 2;
+    struct SpkSub { float *dw = nullptr; void *pw = nullptr; float *bias = nullptr; int kernel = 1, cin = 0, cin_pad = 0, cout = 0; };
+    struct SpkBlock { int repeat = 1; bool residual = false; SpkSub sub[3], res; float *fc1 = nullptr, *fc2 = nullptr; int cin = 0, cout = 0; };
+    SpkBlock spk[5];
+    float *spk_fbT = nullptr; int *spk_band = nullptr;
+    void *a1x_w = nullptr; float *a1_w = nullptr, *a1_b = nullptr, *a_bn_s = nullptr, *a_bn_b = nullptr, *zero_bias = nullptr;
+    void *a2_w = nullptr; float *a2_b = nullptr, *e_bn_s = nullptr, *e_bn_b = nullptr, *emb_w = nullptr, *emb_b = nullptr;
+    float *s_mel = nullptr, *X0 = nullptr, *X1 = nullptr, *Y = nullptr, *R = nullptr, *se_z = nullptr, *st_mean = nullptr, *st_std = nullptr;
+    float *att_c = nullptr, *att_g = nullptr, *pool = nullptr, *emb = nullptr;
+    void *A = nullptr; int *s_lens = nullptr; long long *s_off = nullptr;
     // scratch
     float *audio = nullptr; size_t audio_cap = 0;       // staged input samples
     long long *win_off = nullptr; int *lens = nullptr;   // [max_windows]
@@ -212,7 +223,7 @@ extern "C" void nasr_diar_destroy(nasr_diar *d) {
     delete d;
 }
 
-extern "C" int nasr_diar_create(nasr_diar **out, int device_id, const nasr_weight_desc *weights, int n_weights,
+extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
                                 int max_windows, int max_segments) {
     Guard g;
     if (!out || !weights || n_weights <= 0) return failf("null argument");
@@ -224,6 +235,9 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, const nasr_weigh
     DCHK(hipSetDevice(device_id));
     nasr_diar *d = new nasr_diar();
     d->device = device_id;
+    if (dtype != NASR_DTYPE_BF16 && dtype != NASR_DTYPE_F32) { delete d; return failf("dtype must be NASR_DTYPE_F32 or NASR_DTYPE_BF16"); }
+    d->bf16 = dtype == NASR_DTYPE_BF16;      // TitaNet's pointwise convolutions; MarbleNet is always f32
+    d->esz = d->bf16 ? 2 : 4;
     d->max_windows = std::max(max_windows, 1);
     d->max_segments = std::max(max_segments, 1);
     for (int i = 0; i < n_weights; i++) {
@@ -307,14 +321,173 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     return 0;
 }
 
-static int nasr_diar_load_spk(nasr_diar *d) {
-    (void)d;
-    return failf("speaker-embedding tensors ('spk.*') are not supported by this build yet");
+// pointwise conv weights [cout][cin] with the folded BN scale multiplied in, K padded to a multiple of 32, in the GEMM's
+// layout (packed bf16 tiles or f32 row-major)
+static int upload_gemm_weight(nasr_diar *d, const std::vector<float> &w, const std::vector<float> *scale, int cout, int cin, int cin_pad, void **out) {
+    std::vector<float> h((size_t)cout * cin_pad, 0.0f);
+    for (int o = 0; o < cout; o++)
+        for (int i = 0; i < cin; i++) h[(size_t)o * cin_pad + i] = w[(size_t)o * cin + i] * (scale ? (*scale)[o] : 1.0f);
+    float *tmp = nullptr;
+    DCHK(hipMalloc((void **)&tmp, h.size() * sizeof(float)));
+    DCHK(hipMemcpy(tmp, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (d->bf16) {
+        bf16_t *pk;
+        if (dalloc(d, &pk, h.size())) { hipFree(tmp); return -1; }
+        launch_pack_weight_bf16(tmp, pk, cout, cin_pad, d->st);
+        DCHK(hipStreamSynchronize(d->st));
+        hipFree(tmp);
+        *out = pk;
+    } else {
+        d->allocs.push_back(tmp);
+        *out = tmp;
+    }
+    return 0;
 }
 
+static int nasr_diar_load_spk(nasr_diar *d) {
+    static const Topo SPK_TOPO[5] = {{3, 1, 1, 80, 1024, false, true, true}, {7, 1, 3, 1024, 1024, true, true, true},
+                                     {11, 1, 3, 1024, 1024, true, true, true}, {15, 1, 3, 1024, 1024, true, true, true},
+                                     {1, 1, 1, 1024, 3072, false, true, true}};       // src/diarize_spk.cpp:28-34
+    if (front_end_constants(d, "spk", &d->spk_fbT, &d->spk_band)) return -1;
+    for (int b = 0; b < 5; b++) {
+        const Topo &t = SPK_TOPO[b];
+        const std::string pre = "spk.encoder.encoder." + std::to_string(b);
+        nasr_diar::SpkBlock &blk = d->spk[b];
+        blk.repeat = t.repeat; blk.residual = t.residual; blk.cin = t.cin; blk.cout = t.cout;
+        for (int s = 0; s < t.repeat; s++) {
+            const int cin = s == 0 ? t.cin : t.cout, cin_pad = (cin + 63) & ~63;     // K of the GEMM: whole 64-deep chunks
+            nasr_diar::SpkSub &ss = blk.sub[s];
+            ss.kernel = t.kernel; ss.cin = cin; ss.cin_pad = cin_pad; ss.cout = t.cout;
+            const auto *dw = get(d, pre + ".mconv." + std::to_string(5 * s) + ".conv.weight", (size_t)t.kernel * cin);
+            const auto *pw = get(d, pre + ".mconv." + std::to_string(5 * s + 1) + ".conv.weight", (size_t)t.cout * cin);
+            std::vector<float> sc, bi;
+            if (!dw || !pw || fold_bn(d, pre + ".mconv." + std::to_string(5 * s + 2), t.cout, 1e-3f, sc, bi)) return -1;   // encoder BN eps 1e-3 (:36-41)
+            if (upload(d, *dw, &ss.dw) || upload_gemm_weight(d, *pw, &sc, t.cout, cin, cin_pad, &ss.pw) || upload(d, bi, &ss.bias)) return -1;
+        }
+        if (t.residual) {
+            nasr_diar::SpkSub &rs = blk.res;
+            rs.kernel = 1; rs.cin = t.cin; rs.cin_pad = t.cin; rs.cout = t.cout;
+            const auto *pw = get(d, pre + ".res.0.0.conv.weight", (size_t)t.cout * t.cin);
+            std::vector<float> sc, bi;
+            if (!pw || fold_bn(d, pre + ".res.0.1", t.cout, 1e-3f, sc, bi)) return -1;
+            if (upload_gemm_weight(d, *pw, &sc, t.cout, t.cin, t.cin, &rs.pw) || upload(d, bi, &rs.bias)) return -1;
+        }
+        const std::string se = pre + ".mconv." + std::to_string(5 * (t.repeat - 1) + 3);                 // :151-158
+        const auto *f1 = get(d, se + ".fc.0.weight", (size_t)(t.cout / 8) * t.cout), *f2 = get(d, se + ".fc.2.weight", (size_t)t.cout * (t.cout / 8));
+        if (!f1 || !f2 || upload(d, *f1, &blk.fc1) || upload(d, *f2, &blk.fc2)) return -1;
+    }
+    const int C = SPK_C, A = SPK_ATT;
+    const std::string dp = "spk.decoder";
+    const auto *a1w = get(d, dp + "._pooling.attention_layer.0.conv_layer.weight", (size_t)A * 3 * C);
+    const auto *a1b = get(d, dp + "._pooling.attention_layer.0.conv_layer.bias", A);
+    const auto *a2w = get(d, dp + "._pooling.attention_layer.2.weight", (size_t)C * A);
+    const auto *a2b = get(d, dp + "._pooling.attention_layer.2.bias", C);
+    const auto *ew = get(d, dp + ".emb_layers.0.1.weight", (size_t)SPK_EMB * 2 * C), *eb = get(d, dp + ".emb_layers.0.1.bias", SPK_EMB);
+    std::vector<float> as, ab, es, ebn;
+    if (!a1w || !a1b || !a2w || !a2b || !ew || !eb) return -1;
+    if (fold_bn(d, dp + "._pooling.attention_layer.0.bn", A, 1e-5f, as, ab) || fold_bn(d, dp + ".emb_layers.0.0", 2 * C, 1e-5f, es, ebn)) return -1;   // decoder BN eps 1e-5
+    std::vector<float> a1x((size_t)A * C);                     // the x third of the attention conv: a GEMM; the rest: k_spk_att_const
+    for (int a = 0; a < A; a++) memcpy(&a1x[(size_t)a * C], &(*a1w)[(size_t)a * 3 * C], (size_t)C * sizeof(float));
+    std::vector<float> zeros((size_t)std::max(C, 1024), 0.0f);
+    if (upload_gemm_weight(d, a1x, nullptr, A, C, C, &d->a1x_w) || upload(d, *a1w, &d->a1_w) || upload(d, *a1b, &d->a1_b) ||
+        upload(d, as, &d->a_bn_s) || upload(d, ab, &d->a_bn_b) || upload(d, zeros, &d->zero_bias) ||
+        upload_gemm_weight(d, *a2w, nullptr, C, A, A, &d->a2_w) || upload(d, *a2b, &d->a2_b) || upload(d, es, &d->e_bn_s) ||
+        upload(d, ebn, &d->e_bn_b) || upload(d, *ew, &d->emb_w) || upload(d, *eb, &d->emb_b))
+        return -1;
+    const size_t S = (size_t)d->max_segments, M = S * SPK_T;
+    char *a = nullptr;
+    if (dalloc(d, &d->s_mel, M * 96) || dalloc(d, &d->X0, M * C) || dalloc(d, &d->X1, M * C) || dalloc(d, &d->Y, M * C) ||
+        dalloc(d, &d->R, M * 1024) || dalloc(d, &a, M * C * (size_t)d->esz) || dalloc(d, &d->se_z, S * C) ||
+        dalloc(d, &d->st_mean, S * C) || dalloc(d, &d->st_std, S * C) || dalloc(d, &d->att_c, S * A) || dalloc(d, &d->att_g, M * A) ||
+        dalloc(d, &d->pool, S * 2 * C) || dalloc(d, &d->emb, S * SPK_EMB) || dalloc(d, &d->s_lens, S) || dalloc(d, &d->s_off, S))
+        return -1;
+    d->A = a;
+    return 0;
+}
+
+static void spk_gemm(nasr_diar *d, const void *A, int lda, const void *W, int M, int N, int K, const float *bias, bool relu, float *out) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = lda; g.splits = 1;
+    g.epi = relu ? EPI_BIAS_RELU_F32 : EPI_BIAS_F32; g.out_f32 = out; g.ldo = N; g.bias = bias;
+    if (d->bf16) launch_gemm_bf16(g, d->st);
+    else launch_gemm_f32(g, d->st);
+}
+
+// spk_session_run_chunk (src/diarize_spk.cpp:601-626) for S sub-segments in one launch sequence
 extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, const int32_t *lens_samples, float *emb_out, uint32_t flags) {
     Guard g;
-    (void)S; (void)audio; (void)lens_samples; (void)emb_out; (void)flags;
-    if (!d) return failf("null argument");
-    return failf("speaker embeddings are not supported by this build yet");
+    if (!d || !audio || !lens_samples || !emb_out || S < 1) return failf("null argument or S < 1");
+    if (!d->has_spk) return failf("this diarization engine was created without 'spk.*' tensors");
+    DCHK(hipSetDevice(d->device));
+    for (int s0 = 0; s0 < S; s0 += d->max_segments) {
+        const int St = std::min(d->max_segments, S - s0), M = St * SPK_T;
+        std::vector<int32_t> n(St, SPK_SEGMENT);
+        std::vector<long long> base;
+        for (int s = 0; s < St; s++) if (!audio[s0 + s]) return failf("segment %d: null audio", s0 + s);
+        if (stage_audio(d, audio + s0, n.data(), St, (flags & NASR_FLAG_PCM_DEVICE) != 0, base)) return -1;
+        long long *h_off = (long long *)d->pin;
+        int *h_len = (int *)(d->pin + (size_t)d->max_segments * sizeof(long long));
+        for (int s = 0; s < St; s++) {
+            h_off[s] = base[s];
+            int lm = lens_samples[s0 + s] / HOP;                        // :613-615, :548
+            h_len[s] = lm > SPK_TVALID ? SPK_TVALID : (lm < 1 ? 1 : lm);
+        }
+        DCHK(hipMemcpyAsync(d->s_off, h_off, (size_t)St * sizeof(long long), hipMemcpyHostToDevice, d->st));
+        DCHK(hipMemcpyAsync(d->s_lens, h_len, (size_t)St * sizeof(int), hipMemcpyHostToDevice, d->st));
+        DiarMelParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.audio = d->audio; mp.win_off = d->s_off; mp.n_win = SPK_SEGMENT; mp.T_pad = SPK_T; mp.t_valid = SPK_TVALID;
+        mp.cpitch = 96; mp.mel = d->s_mel; mp.window = d->window; mp.fbT = d->spk_fbT; mp.fb_band = d->spk_band;
+        mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+        launch_diar_logmel(mp, St, true, d->st);                        // per-feature normalisation on (:578)
+        const float *x = d->s_mel;
+        int x_pitch = 96;
+        float *outs[2] = {d->X0, d->X1};
+        int flip = 0;
+        for (int b = 0; b < 5; b++) {                                   // JasperBlock (:351-383)
+            nasr_diar::SpkBlock &blk = d->spk[b];
+            const float *cur = x;
+            int cur_pitch = x_pitch;
+            for (int r = 0; r < blk.repeat; r++) {
+                nasr_diar::SpkSub &ss = blk.sub[r];
+                launch_spk_depthwise(cur, cur_pitch, ss.dw, ss.kernel, ss.cin, ss.cin_pad, d->s_lens, d->A, d->bf16, St, d->st);
+                spk_gemm(d, d->A, ss.cin_pad, ss.pw, M, ss.cout, ss.cin_pad, ss.bias, r + 1 < blk.repeat, d->Y);   // ReLU between sub-convs
+                cur = d->Y;
+                cur_pitch = ss.cout;
+            }
+            launch_spk_se(d->Y, blk.cout, d->s_lens, blk.fc1, blk.fc2, d->se_z, St, d->st);      // SE before the residual (:365-368)
+            const float *res = nullptr;
+            if (blk.residual) {
+                launch_spk_mask_cvt(x, blk.cin, d->s_lens, d->A, d->bf16, St, d->st);
+                spk_gemm(d, d->A, blk.cin, blk.res.pw, M, blk.cout, blk.cin, blk.res.bias, false, d->R);
+                res = d->R;
+            }
+            float *out = outs[flip];
+            flip ^= 1;
+            launch_spk_combine(d->Y, d->se_z, res, blk.cout, d->s_lens, out, St, d->st);
+            x = out;
+            x_pitch = blk.cout;
+        }
+        // attentive statistics pooling + embedding (:384-500)
+        launch_spk_stats(x, SPK_C, d->s_lens, d->st_mean, d->st_std, St, d->st);
+        launch_spk_att_const(d->st_mean, d->st_std, d->a1_w, d->a1_b, d->att_c, SPK_C, SPK_ATT, St, d->st);
+        launch_spk_mask_cvt(x, SPK_C, d->s_lens, d->A, d->bf16, St, d->st);
+        spk_gemm(d, d->A, SPK_C, d->a1x_w, M, SPK_ATT, SPK_C, d->zero_bias, false, d->att_g);
+        launch_spk_att_post(d->att_g, d->att_c, d->a_bn_s, d->a_bn_b, d->A, d->bf16, SPK_ATT, St, d->st);
+        spk_gemm(d, d->A, SPK_ATT, d->a2_w, M, SPK_C, SPK_ATT, d->a2_b, false, d->Y);                   // attention logits
+        launch_spk_asp(x, d->Y, SPK_C, d->s_lens, d->e_bn_s, d->e_bn_b, d->pool, St, d->st);
+        {
+            GemmParams ge;
+            memset(&ge, 0, sizeof(ge));
+            ge.A = d->pool; ge.W = d->emb_w; ge.M = St; ge.N = SPK_EMB; ge.K = 2 * SPK_C; ge.lda = 2 * SPK_C; ge.splits = 1;
+            ge.epi = EPI_BIAS_F32; ge.out_f32 = d->emb; ge.ldo = SPK_EMB; ge.bias = d->emb_b;
+            launch_gemm_f32(ge, d->st);                                 // [S][6144] x [192][6144]^T, always f32
+        }
+        float *h_emb = (float *)(d->pin + (size_t)d->max_segments * (sizeof(long long) + sizeof(int)));
+        DCHK(hipMemcpyAsync(h_emb, d->emb, (size_t)St * SPK_EMB * sizeof(float), hipMemcpyDeviceToHost, d->st));
+        DCHK(hipStreamSynchronize(d->st));
+        memcpy(emb_out + (size_t)s0 * SPK_EMB, h_emb, (size_t)St * SPK_EMB * sizeof(float));
+    }
+    return 0;
 }

@@ -255,6 +255,19 @@ struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blo
 // one workgroup per window: mel [W][64][80] -> P(speech) [W]; lens_mel [W] valid frames (masked convs)
 void launch_vad_marblenet(const VadNet &net, const float *mel, const int *lens_mel, float *prob, int W, hipStream_t st);
 void init_diar_kernel_attributes();
+
+// TitaNet-L pieces (src/diarize_spk.cpp:320-515); activations [S * 160][C] f32, channels innermost
+void launch_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad, const int *lens, void *a_out,
+                          int out_bf16, int S, hipStream_t st);               // masked 'same' depthwise conv -> GEMM A operand
+void launch_spk_mask_cvt(const float *x, int C, const int *lens, void *a_out, int out_bf16, int S, hipStream_t st);
+void launch_spk_se(const float *y, int C, const int *lens, const float *fc1, const float *fc2, float *z, int S, hipStream_t st);
+void launch_spk_combine(const float *y, const float *z, const float *r, int C, const int *lens, float *out, int S, hipStream_t st);
+void launch_spk_stats(const float *x, int C, const int *lens, float *mean, float *stdv, int S, hipStream_t st);
+void launch_spk_att_const(const float *mean, const float *stdv, const float *w1, const float *b1, float *c, int C, int A, int S, hipStream_t st);
+void launch_spk_att_post(const float *g, const float *c, const float *bn_scale, const float *bn_bias, void *a_out, int out_bf16,
+                         int A, int S, hipStream_t st);
+void launch_spk_asp(const float *x, const float *logits, int C, const int *lens, const float *bn_scale, const float *bn_bias,
+                    float *pool, int S, hipStream_t st);
 int set_error(const char *msg);      // fills nasr_last_error() of the calling thread, returns -1
 
 

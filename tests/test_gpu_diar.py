@@ -35,6 +35,25 @@ def test_vad_batched_windows_match_oracle(Wv):
         eng.close()
 
 
+@pytest.mark.parametrize("dtype,tol", [(capi.DTYPE_F32, 2e-3), (capi.DTYPE_BF16, 6e-2)])
+def test_speaker_embeddings_match_oracle(dtype, tol):
+    """5 sub-segments (full, short, minimal lens) in ONE launch sequence, tiled by max_segments = 2: TitaNet-L embeddings
+    == the oracle's one-by-one run.  f32 engine: 2e-3 of the embedding scale; bf16 pointwise convs: 6e-2, cosine > 0.999."""
+    W = synth.make_diar_weights(vad=False)
+    om = db.DiarModel(W)
+    segs = [_audio(10 + i, 24000) for i in range(5)]
+    lens = [24000, 24000, 12000, 4321, 100]
+    ref = np.stack([om.spk_embed(a, l) for a, l in zip(segs, lens)])
+    eng = capi.Diar(W, dtype=dtype, max_segments=2)
+    got = eng.embed(segs, lens)
+    scale = np.abs(ref).max()
+    assert np.isfinite(got).all() and np.abs(got - ref).max() < tol * scale, (np.abs(got - ref).max(), scale)
+    for g, r in zip(got, ref):
+        assert float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r))) > 0.999
+    assert np.abs(eng.embed(segs[:1], lens[:1])[0] - got[0]).max() < 1e-5 * scale      # batch == alone
+    eng.close()
+
+
 def test_vad_errors(Wv):
     eng = capi.Diar(Wv)
     with pytest.raises(capi.NasrError):
