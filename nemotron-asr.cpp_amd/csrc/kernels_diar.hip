@@ -3,7 +3,7 @@
 // MarbleNet VAD (reference src/diarize_vad.cpp): the reference runs one ggml graph of ~150 nodes per 0.63 s window,
 // 100 windows per second of audio per stream, each on its own.  The whole network is 90 k parameters and a window is
 // 64 frames x <= 128 channels, so here ONE WORKGROUP runs the whole network for one window with the activations in
-// LDS (three [64][128] f32 planes = 96 KiB of the CU's 160 KiB) and the launch covers every window of every stream:
+// LDS (three [64][129] f32 planes = 97 KiB of the CU's 160 KiB) and the launch covers every window of every stream:
 // the sliding window is a batch dimension.  Activations are [T][C], channels innermost, as the reference feeds ggml.
 #include "nasr_internal.h"
 #include "nasr_wave.h"
@@ -12,61 +12,110 @@ namespace nasr {
 
 constexpr int VT = VAD_T;          // 64 frames
 constexpr int VC = 128;            // widest layer
+constexpr int VP = VC + 4;         // LDS row pitch (floats): 528 B keeps rows 16-byte aligned and 16 consecutive rows on distinct banks
 
-// y[t][c] = sum_i x[t + i*dil - pad][c] * w[i][c] with rows outside [0, lens) read as zero (the zero 'same' padding
-// and MaskedConv1d's input mask, src/diarize_vad.cpp:232-251, :283-297); term order as the reference's graph
-__device__ __forceinline__ void vad_depthwise(const float *x, float *y, const VadSub &s, int lens) {
-    const int C = s.cin, pad = s.dil * (s.kernel - 1) / 2;
-    for (int e = threadIdx.x; e < VT * C; e += 256) {
-        const int t = e / C, c = e - t * C;
-        float acc = 0.0f;
-        for (int i = 0; i < s.kernel; i++) {
-            const int tt = t + i * s.dil - pad;
-            const float v = (tt >= 0 && tt < lens) ? x[tt * VC + c] : 0.0f;
-            const float prod = v * s.dw[i * C + c];
-            acc = i == 0 ? prod : acc + prod;
-        }
-        y[t * VC + c] = acc;
+typedef __attribute__((ext_vector_type(4))) float f32x4_d;
+
+// depthwise: y[t][c] = sum_i x[t + i*dil - pad][c] * w[i][c] with rows outside [0, lens) read as zero (the zero 'same'
+// padding and MaskedConv1d's input mask, src/diarize_vad.cpp:232-251, :283-297); term order as the reference's graph.
+// lane = channel (consecutive lanes -> consecutive LDS banks); a thread slides over NF frames of its channel with the
+// NF + (K-1)*DIL inputs and the K taps in registers: each input is read from LDS once.
+template <int K, int DIL, int NF>
+__device__ __forceinline__ void vad_depthwise_k(const float *x, float *y, const float *dw, int C, int lens) {
+    constexpr int PAD = DIL * (K - 1) / 2, NIN = NF + (K - 1) * DIL;
+    const int c = threadIdx.x % C, part = threadIdx.x / C;
+    if (part >= VT / NF) return;
+    float wk[K], in[NIN];
+#pragma unroll
+    for (int i = 0; i < K; i++) wk[i] = dw[i * C + c];
+    const int t_lo = part * NF;
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int tt = t_lo + j - PAD;
+        in[j] = (tt >= 0 && tt < lens) ? x[tt * VP + c] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < NF; u++) {
+        float acc = in[u] * wk[0];
+#pragma unroll
+        for (int i = 1; i < K; i++) acc += in[u + i * DIL] * wk[i];
+        y[(t_lo + u) * VP + c] = acc;
     }
 }
+__device__ __forceinline__ void vad_depthwise(const float *x, float *y, const VadSub &s, int lens) {
+    const int C = s.cin;
+    // the five MarbleNet shapes (src/diarize_vad.cpp:25-32); frames per thread = 64 / (threads per channel)
+    if (s.kernel == 11) vad_depthwise_k<11, 1, 32>(x, y, s.dw, C, lens);            // C = 80: 160 threads x 32 frames
+    else if (s.kernel == 13 && C == 128) vad_depthwise_k<13, 1, 32>(x, y, s.dw, C, lens);
+    else if (s.kernel == 13) vad_depthwise_k<13, 1, 16>(x, y, s.dw, C, lens);       // C = 64: 4 threads per channel
+    else if (s.kernel == 15) vad_depthwise_k<15, 1, 16>(x, y, s.dw, C, lens);
+    else if (s.kernel == 17) vad_depthwise_k<17, 1, 16>(x, y, s.dw, C, lens);
+    else vad_depthwise_k<29, 2, 16>(x, y, s.dw, C, lens);
+}
 
-// y[t][o] = (sum_i w[o][i] * mask(t) x[t][i]) * scale[o] + bias[o]  (+ residual) (relu)   (:226-229, :255-265)
-// thread -> one output channel (its weight row lives in registers) and a contiguous group of frames; the x row is an
-// LDS broadcast.  ADD: accumulate into y (the residual branch lands on top of the main branch).
+// pointwise on the f32-input MFMA (v_mfma_f32_16x16x4_f32, exact fmaf chains): D[o][t] = sum_i W[o][i] * mask(t) x[t][i],
+// then y[t][o] = D * scale[o] + bias[o] (+ what y holds: the residual branch lands on top of the main branch) (relu)
+// (:226-229, :255-265).  Weights are packed at upload in A-fragment order (tile = 16 out channels x 16 k, lane q*16+r
+// holds W[nt*16+r][kg*16+4q..+4)); a wave owns Cout/64 column tiles and walks the four 16-frame tiles.
 template <bool ADD, bool RELU>
 __device__ __forceinline__ void vad_pointwise(const float *x, float *y, const VadSub &s, int lens) {
-    const int Cin = s.cin, Cout = s.cout;
-    const int groups = 256 / Cout, o = threadIdx.x % Cout, g = threadIdx.x / Cout;   // Cout in {64, 128}
-    const int per = VT / groups, t0 = g * per;
-    float wreg[VC];
+    const int KG = s.cin >> 4, NTW = s.cout >> 6;            // k-groups of 16; column tiles per wave (1 or 2)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    for (int j = 0; j < NTW; j++) {
+        const int nt = wave * NTW + j;
+        const float4 *wt = (const float4 *)s.pw + (size_t)nt * KG * 64 + lane;
+        const int o = nt * 16 + q * 4;                       // lane holds out channels o..o+3 of frame mt*16 + r
+        // every global load of this column tile first (weights of all k-groups, BN scale / bias): one round trip
+        float4 wv[8];
 #pragma unroll
-    for (int i = 0; i < VC; i++) wreg[i] = i < Cin ? s.pw[o * Cin + i] : 0.0f;
-    const float sc = s.scale[o], bi = s.bias[o];
-    for (int t = t0; t < t0 + per; t++) {
-        float acc = 0.0f;
-        if (t < lens) {
-            const float *xr = x + t * VC;
+        for (int kg = 0; kg < 8; kg++) wv[kg] = kg < KG ? wt[(size_t)kg * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 sc = *(const float4 *)(s.scale + o), bi = *(const float4 *)(s.bias + o);
+        f32x4_d acc[4];
 #pragma unroll
-            for (int i = 0; i < VC; i++)
-                if (i < Cin) acc += wreg[i] * xr[i];
+        for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x4_d){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) {
+            if (kg < KG) {
+                const float4 w = wv[kg];
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const int t = mt * 16 + r;
+                    float4 xv = *(const float4 *)(x + t * VP + kg * 16 + q * 4);
+                    if (t >= lens) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, xv.x, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, xv.y, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, xv.z, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, xv.w, acc[mt], 0, 0, 0);
+                }
+            }
         }
-        float v = acc * sc + bi;
-        if (ADD) v += y[t * VC + o];
-        if (RELU) v = fmaxf(v, 0.0f);
-        y[t * VC + o] = v;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            float *dst = y + (mt * 16 + r) * VP + o;
+            float4 v = make_float4(acc[mt][0] * sc.x + bi.x, acc[mt][1] * sc.y + bi.y, acc[mt][2] * sc.z + bi.z, acc[mt][3] * sc.w + bi.w);
+            if (ADD) { const float4 old = *(const float4 *)dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+            if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            *(float4 *)dst = v;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_vad_marblenet(VadNet net, const float *mel, const int *lens_mel, float *prob) {
+__global__ __launch_bounds__(256) void k_vad_marblenet(VadNet net, const float *shared, const float *edge, const int *win_row,
+                                                       const int *lens_mel, float *prob) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *A = lds, *B = lds + VT * VC, *Tm = lds + 2 * VT * VC;
+    float *A = lds, *B = lds + VT * VP, *Tm = lds + 2 * VT * VP;
     __shared__ float mean_s[VC];
     const int w = blockIdx.x;
     int lens = lens_mel[w];
     lens = lens < 0 ? 0 : (lens > VAD_TVALID ? VAD_TVALID : lens);             // :447-450
+    const int row0 = win_row[w];
     for (int e = threadIdx.x; e < VT * DIAR_NMEL; e += 256) {
         const int t = e / DIAR_NMEL, c = e - t * DIAR_NMEL;
-        A[t * VC + c] = mel[((size_t)w * VT + t) * DIAR_NMEL + c];
+        float v = 0.0f;                                               // row 63: the masked +1 frame of the centred STFT
+        if (t < 2) v = edge[((size_t)3 * w + t) * DIAR_NMEL + c];
+        else if (t == 62) v = edge[((size_t)3 * w + 2) * DIAR_NMEL + c];
+        else if (t < 62) v = shared[((size_t)row0 + t) * DIAR_NMEL + c];
+        A[t * VP + c] = v;
     }
     __syncthreads();
     // JasperBlock: sub-convs (ReLU between them), + residual, ReLU (:300-318).  Three LDS planes: `in` holds the block
@@ -105,7 +154,7 @@ __global__ __launch_bounds__(256) void k_vad_marblenet(VadNet net, const float *
     // AdaptiveAvgPool1d(1) over all 64 frames, Linear(128 -> 2), softmax, P(speech) (:462-487)
     if (threadIdx.x < VC) {
         float sum = 0.0f;
-        for (int t = 0; t < VT; t++) sum += A[t * VC + threadIdx.x];
+        for (int t = 0; t < VT; t++) sum += A[t * VP + threadIdx.x];
         mean_s[threadIdx.x] = sum * (1.0f / (float)VT);
     }
     __syncthreads();
@@ -123,11 +172,12 @@ __global__ __launch_bounds__(256) void k_vad_marblenet(VadNet net, const float *
 }
 
 void init_diar_kernel_attributes() {
-    hipFuncSetAttribute((const void *)k_vad_marblenet, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * VT * VC * 4);
+    hipFuncSetAttribute((const void *)k_vad_marblenet, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * VT * VP * 4);
 }
-void launch_vad_marblenet(const VadNet &net, const float *mel, const int *lens_mel, float *prob, int W, hipStream_t st) {
+void launch_vad_marblenet(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
+                          float *prob, int W, hipStream_t st) {
     if (W <= 0) return;
-    hipLaunchKernelGGL(k_vad_marblenet, dim3(W), dim3(256), 3 * VT * VC * 4, st, net, mel, lens_mel, prob);
+    hipLaunchKernelGGL(k_vad_marblenet, dim3(W), dim3(256), 3 * VT * VP * 4, st, net, shared, edge, win_row, lens_mel, prob);
 }
 
 
@@ -143,27 +193,40 @@ __device__ __forceinline__ void store_a(void *base, size_t idx, float v, int bf1
 }
 
 // depthwise 'same' conv, dilation 1 (src/diarize_spk.cpp:256-282); kernel == 1 is the per-channel scaling of :263-267.
-// out row t >= lens = 0 (the mask in front of the pointwise conv), channels C..Cpad-1 = 0 (K padding of the GEMM)
+// out row t >= lens = 0 (the mask in front of the pointwise conv), channels C..Cpad-1 = 0 (K padding of the GEMM).
+// One thread per channel walks a tile of 16 frames with the 16 + kernel - 1 inputs it needs in registers.
+constexpr int DW_TILE = 16, DW_KMAX = 15;
 __global__ __launch_bounds__(256) void k_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad,
                                                        const int *lens, void *a_out, int out_bf16) {
-    const int t = blockIdx.x, s = blockIdx.y, L = lens[s], pad = (kernel - 1) / 2;
+    const int t0 = blockIdx.x * DW_TILE, s = blockIdx.y, L = lens[s], pad = (kernel - 1) / 2;
     const float *xs = x + (size_t)s * SPK_T * x_pitch;
     for (int c = threadIdx.x; c < Cpad; c += 256) {
-        float acc = 0.0f;
-        if (t < L && c < C) {
-            for (int i = 0; i < kernel; i++) {
-                const int tt = t + i - pad;
-                const float v = (tt >= 0 && tt < L) ? xs[(size_t)tt * x_pitch + c] : 0.0f;
-                const float prod = v * w[(size_t)i * C + c];
-                acc = i == 0 ? prod : acc + prod;
+        float in[DW_TILE + DW_KMAX - 1], wk[DW_KMAX];
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < DW_KMAX; i++) wk[i] = i < kernel ? w[(size_t)i * C + c] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < DW_TILE + DW_KMAX - 1; j++) {
+                const int tt = t0 + j - pad;
+                in[j] = (j < DW_TILE + kernel - 1 && tt >= 0 && tt < L) ? xs[(size_t)tt * x_pitch + c] : 0.0f;
             }
         }
-        store_a(a_out, ((size_t)s * SPK_T + t) * Cpad + c, acc, out_bf16);
+#pragma unroll
+        for (int u = 0; u < DW_TILE; u++) {
+            const int t = t0 + u;
+            float acc = 0.0f;
+            if (t < L && c < C) {
+#pragma unroll
+                for (int i = 0; i < DW_KMAX; i++)
+                    if (i < kernel) { const float prod = in[u + i] * wk[i]; acc = i == 0 ? prod : acc + prod; }
+            }
+            if (t < SPK_T) store_a(a_out, ((size_t)s * SPK_T + t) * Cpad + c, acc, out_bf16);
+        }
     }
 }
 void launch_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad, const int *lens, void *a_out,
                           int out_bf16, int S, hipStream_t st) {
-    hipLaunchKernelGGL(k_spk_depthwise, dim3(SPK_T, S), dim3(256), 0, st, x, x_pitch, w, kernel, C, Cpad, lens, a_out, out_bf16);
+    hipLaunchKernelGGL(k_spk_depthwise, dim3(SPK_T / DW_TILE, S), dim3(256), 0, st, x, x_pitch, w, kernel, C, Cpad, lens, a_out, out_bf16);
 }
 
 // masked copy into the GEMM operand type (input of the residual 1x1 conv :369-372 and of the attention conv)
@@ -176,43 +239,30 @@ void launch_spk_mask_cvt(const float *x, int C, const int *lens, void *a_out, in
     hipLaunchKernelGGL(k_spk_mask_cvt, dim3(SPK_T, S), dim3(256), 0, st, x, C, lens, a_out, out_bf16);
 }
 
-// squeeze-excite gate of one segment (:303-315): z = sigmoid(fc2 . relu(fc1 . masked_mean_T(y)))
-__global__ __launch_bounds__(256) void k_spk_se(const float *y, int C, const int *lens, const float *fc1, const float *fc2, float *z) {
-    extern __shared__ float sm[];                 // mean [C], hidden [C / 8]
-    float *mean = sm, *hid = sm + C;
-    const int s = blockIdx.x, L = lens[s], H = C / 8;
-    const float inv = 1.0f / (float)L;
-    const float *ys = y + (size_t)s * SPK_T * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float sum = 0.0f;
-        for (int t = 0; t < L; t++) sum += ys[(size_t)t * C + c];
-        mean[c] = sum * inv;
-    }
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j = wave; j < H; j += 4) {           // one wave per hidden unit: coalesced row of fc1
-        float acc = 0.0f;
-        for (int c = lane; c < C; c += 64) acc += fc1[(size_t)j * C + c] * mean[c];
-        acc = wave_sum(acc);
-        if (lane == 0) hid[j] = fmaxf(acc, 0.0f);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.0f;
-        for (int j = 0; j < H; j++) acc += fc2[(size_t)c * H + j] * hid[j];
-        z[(size_t)s * C + c] = 1.0f / (1.0f + expf(-acc));
-    }
+// squeeze-excite gate (:303-315): z = sigmoid(fc2 . relu(fc1 . masked_mean_T(y)))
+// (a) masked mean over time, one thread per (segment, channel), coalesced over channels
+__global__ __launch_bounds__(256) void k_spk_colmean(const float *y, int C, const int *lens, float *mean) {
+    const int s = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, L = lens[s];
+    if (c >= C) return;
+    const float *ys = y + (size_t)s * SPK_T * C + c;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int t = 0;
+    for (; t + 4 <= L; t += 4) { s0 += ys[(size_t)t * C]; s1 += ys[(size_t)(t + 1) * C]; s2 += ys[(size_t)(t + 2) * C]; s3 += ys[(size_t)(t + 3) * C]; }
+    for (; t < L; t++) s0 += ys[(size_t)t * C];
+    mean[(size_t)s * C + c] = ((s0 + s1) + (s2 + s3)) * (1.0f / (float)L);
 }
-void launch_spk_se(const float *y, int C, const int *lens, const float *fc1, const float *fc2, float *z, int S, hipStream_t st) {
-    hipLaunchKernelGGL(k_spk_se, dim3(S), dim3(256), (size_t)(C + C / 8) * 4, st, y, C, lens, fc1, fc2, z);
+// (b) the two small linears are [S][C] x [H][C]^T and [S][H] x [C][H]^T: f32 GEMMs over all segments (nasr_diar.hip);
+//     the sigmoid is applied where the gate is used (k_spk_combine)
+void launch_spk_colmean(const float *y, int C, const int *lens, float *mean, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_spk_colmean, dim3((C + 255) / 256, S), dim3(256), 0, st, y, C, lens, mean);
 }
 
-// block output: relu(mask(y) * z + residual)  (:365-377)
+// block output: relu(mask(y) * sigmoid(zpre) + residual)  (:303-315, :365-377)
 __global__ __launch_bounds__(256) void k_spk_combine(const float *y, const float *z, const float *r, int C, const int *lens, float *out) {
     const int t = blockIdx.x, s = blockIdx.y, L = lens[s];
     const size_t row = ((size_t)s * SPK_T + t) * C;
     for (int c = threadIdx.x; c < C; c += 256) {
-        float v = t < L ? y[row + c] * z[(size_t)s * C + c] : 0.0f;
+        float v = t < L ? y[row + c] * (1.0f / (1.0f + expf(-z[(size_t)s * C + c]))) : 0.0f;
         if (r) v += r[row + c];
         out[row + c] = fmaxf(v, 0.0f);
     }

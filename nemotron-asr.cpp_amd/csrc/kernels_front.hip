@@ -220,20 +220,13 @@ void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, co
 // window (y[0] = x[0], :83-93), the STFT is centred with zero padding (:119-125), power = re^2 + im^2 without the
 // sqrt round trip (:127-131), frames >= t_valid (the +1 frame of the centred STFT and the pad-to-16 tail) are zeros.
 // Operation order as in the reference (this file is compiled without FMA contraction).
-__global__ __launch_bounds__(256) void k_diar_logmel(DiarMelParams p) {
-    const int t = blockIdx.x, w = blockIdx.y;
-    float *out = p.mel + ((size_t)w * p.T_pad + t) * p.cpitch;
-    if (t >= p.t_valid) {
-        for (int c = threadIdx.x; c < p.cpitch; c += 256) out[c] = 0.0f;
-        return;
-    }
+__device__ __forceinline__ void diar_frame(const DiarMelParams &p, const float *x, int n_win, int t, float *out, int cpitch) {
     __shared__ float re[NFFT], im[NFFT], pw[NBINS + 3];
-    const float *x = p.audio + p.win_off[w];
     const int start = t * HOP - NFFT / 2;
     for (int i = threadIdx.x; i < NFFT; i += 256) {
         const int idx = start + i;
         float s = 0.0f;
-        if (idx >= 0 && idx < p.n_win) s = idx == 0 ? x[0] : __fsub_rn(x[idx], __fmul_rn(0.97f, x[idx - 1]));
+        if (idx >= 0 && idx < n_win) s = idx == 0 ? x[0] : __fsub_rn(x[idx], __fmul_rn(0.97f, x[idx - 1]));
         const float v = __fmul_rn(s, p.window[i]);
         const int j = (int)(__brev((unsigned)i) >> 23);
         re[j] = v;
@@ -262,9 +255,30 @@ __global__ __launch_bounds__(256) void k_diar_logmel(DiarMelParams p) {
         const int k_lo = p.fb_band[2 * threadIdx.x], k_hi = p.fb_band[2 * threadIdx.x + 1];
         for (int k = k_lo; k < k_hi; k++) sum = __fadd_rn(sum, __fmul_rn(p.fbT[k * DIAR_NMEL + threadIdx.x], pw[k]));
         out[threadIdx.x] = logf(__fadd_rn(sum, 5.960464477539063e-8f));
-    } else if ((int)threadIdx.x < p.cpitch) {
+    } else if ((int)threadIdx.x < cpitch) {
         out[threadIdx.x] = 0.0f;
     }
+}
+
+__global__ __launch_bounds__(256) void k_diar_logmel(DiarMelParams p) {
+    const int t = blockIdx.x, w = blockIdx.y;
+    float *out = p.mel + ((size_t)w * p.T_pad + t) * p.cpitch;
+    if (t >= p.t_valid) {
+        for (int c = threadIdx.x; c < p.cpitch; c += 256) out[c] = 0.0f;
+        return;
+    }
+    diar_frame(p, p.audio + p.win_off[w], p.n_win, t, out, p.cpitch);
+}
+
+// the sliding-window VAD: frame t of the window at sample offset i*160 covers the same samples as frame t+1 of the window
+// before it, and (away from the window's edges, where the zero padding and the restart of the pre-emphasis show) is the same
+// frame -- so frames are computed per descriptor, once for all the windows that share them (nasr_diar.hip)
+__global__ __launch_bounds__(256) void k_diar_frames(DiarMelParams p, const DiarFrameDesc *frames, float *out) {
+    const DiarFrameDesc f = frames[blockIdx.x];
+    diar_frame(p, p.audio + f.base, f.n, f.t, out + (size_t)blockIdx.x * DIAR_NMEL, DIAR_NMEL);
+}
+void launch_diar_frames(const DiarMelParams &p, const DiarFrameDesc *frames, int n_frames, float *out, hipStream_t st) {
+    if (n_frames > 0) hipLaunchKernelGGL(k_diar_frames, dim3(n_frames), dim3(256), 0, st, p, frames, out);
 }
 
 // per-feature normalisation over the t_valid frames (:182-199): mean and Bessel-corrected std in double, as the reference

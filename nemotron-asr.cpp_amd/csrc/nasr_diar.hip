@@ -63,12 +63,14 @@ struct nasr_diar {
     void *a1x_w = nullptr; float *a1_w = nullptr, *a1_b = nullptr, *a_bn_s = nullptr, *a_bn_b = nullptr, *zero_bias = nullptr;
     void *a2_w = nullptr; float *a2_b = nullptr, *e_bn_s = nullptr, *e_bn_b = nullptr, *emb_w = nullptr, *emb_b = nullptr;
     float *s_mel = nullptr, *X0 = nullptr, *X1 = nullptr, *Y = nullptr, *R = nullptr, *se_z = nullptr, *st_mean = nullptr, *st_std = nullptr;
-    float *att_c = nullptr, *att_g = nullptr, *pool = nullptr, *emb = nullptr;
+    float *att_c = nullptr, *att_g = nullptr, *pool = nullptr, *emb = nullptr, *se_h = nullptr;
     void *A = nullptr; int *s_lens = nullptr; long long *s_off = nullptr;
     // scratch
     float *audio = nullptr; size_t audio_cap = 0;       // staged input samples
-    long long *win_off = nullptr; int *lens = nullptr;   // [max_windows]
-    float *mel = nullptr, *prob = nullptr;               // [max_windows][64][80], [max_windows]
+    DiarFrameDesc *fr_desc = nullptr; size_t fr_cap = 0;  // VAD: frame descriptors, frames [n][80], per-window rows / lens, results
+    float *fr_mel = nullptr; size_t frm_cap = 0;
+    int *win_row = nullptr; size_t win_cap = 0;
+    float *prob = nullptr; size_t prob_cap = 0;
     char *pin = nullptr; size_t pin_cap = 0;             // pinned staging for descriptors / results
 };
 
@@ -135,6 +137,19 @@ int front_end_constants(nasr_diar *d, const std::string &ns, float **fbT, int **
     return upload(d, t, fbT) || upload(d, bd, band) ? -1 : 0;
 }
 
+// pointwise weights [N][K] -> MFMA A-fragment order for v_mfma_f32_16x16x4_f32 (same layout as the RNN-T decoder's,
+// nasr_engine.hip pack_f32_mfma): tile (nt, kg) = 16 rows x 16 k, lane q*16+r holds W[nt*16+r][kg*16+4q .. +4)
+std::vector<float> pack_mfma_f32(const std::vector<float> &w, int N, int K) {
+    const int NT = N / 16, KG = K / 16;
+    std::vector<float> out((size_t)NT * KG * 64 * 4);
+    for (int nt = 0; nt < NT; nt++)
+        for (int kg = 0; kg < KG; kg++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 4; j++)
+                    out[(((size_t)nt * KG + kg) * 64 + lane) * 4 + j] = w[(size_t)(nt * 16 + (lane & 15)) * K + kg * 16 + 4 * (lane >> 4) + j];
+    return out;
+}
+
 int load_vad(nasr_diar *d) {
     if (front_end_constants(d, "vad", &d->vad_fbT, &d->vad_band)) return -1;
     int si = 0;
@@ -154,7 +169,7 @@ int load_vad(nasr_diar *d) {
                 vs.dw = p;
             }
             const auto *pw = get(d, pre + ".mconv." + std::to_string(pw_i) + ".conv.weight", (size_t)t.cout * cin);
-            if (!pw || upload(d, *pw, &p)) return -1;
+            if (!pw || upload(d, pack_mfma_f32(*pw, t.cout, cin), &p)) return -1;
             vs.pw = p;
             std::vector<float> sc, bi;
             if (fold_bn(d, pre + ".mconv." + std::to_string(bn_i), t.cout, 1e-3f, sc, bi)) return -1;   // Jasper BN eps 1e-3 (:34-36)
@@ -168,7 +183,7 @@ int load_vad(nasr_diar *d) {
             vr.kernel = 1; vr.dil = 1; vr.cin = t.cin; vr.cout = t.cout; vr.dw = nullptr;
             float *p;
             const auto *pw = get(d, pre + ".res.0.0.conv.weight", (size_t)t.cout * t.cin);
-            if (!pw || upload(d, *pw, &p)) return -1;
+            if (!pw || upload(d, pack_mfma_f32(*pw, t.cout, t.cin), &p)) return -1;
             vr.pw = p;
             std::vector<float> sc, bi;
             if (fold_bn(d, pre + ".res.0.1", t.cout, 1e-3f, sc, bi)) return -1;
@@ -184,9 +199,6 @@ int load_vad(nasr_diar *d) {
     d->vad.dec_w = p;
     if (upload(d, *db, &p)) return -1;
     d->vad.dec_b = p;
-    if (dalloc(d, &d->win_off, (size_t)d->max_windows) || dalloc(d, &d->lens, (size_t)d->max_windows) ||
-        dalloc(d, &d->mel, (size_t)d->max_windows * VAD_T * DIAR_NMEL) || dalloc(d, &d->prob, (size_t)d->max_windows))
-        return -1;
     return 0;
 }
 
@@ -218,6 +230,10 @@ extern "C" void nasr_diar_destroy(nasr_diar *d) {
     if (d->st) hipStreamSynchronize(d->st);
     for (void *p : d->allocs) hipFree(p);
     if (d->audio) hipFree(d->audio);
+    if (d->fr_desc) hipFree(d->fr_desc);
+    if (d->fr_mel) hipFree(d->fr_mel);
+    if (d->win_row) hipFree(d->win_row);
+    if (d->prob) hipFree(d->prob);
     if (d->pin) hipHostFree(d->pin);
     if (d->st) hipStreamDestroy(d->st);
     delete d;
@@ -267,8 +283,26 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const
     return 0;
 }
 
+// grow-on-demand device scratch (the VAD's sizes depend on the call)
+template <typename Tp>
+static int ensure(nasr_diar *d, Tp **p, size_t *cap, size_t n) {
+    if (n <= *cap) return 0;
+    DCHK(hipStreamSynchronize(d->st));
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = n + n / 2 + 1024;
+    DCHK(hipMalloc((void **)p, *cap * sizeof(Tp)));
+    return 0;
+}
+
 // vad_session_run_batch (src/diarize_vad.cpp:490-503) for B buffers in one launch sequence: every 0.63 s window of
 // every buffer at a 10 ms shift -> P(speech).  audio[b]: n_samples[b] float samples in [-1, 1].
+//
+// The reference preprocesses each window on its own (64 STFT frames per window, 100 windows per second).  Local frame t
+// of the window at offset i*160 is the buffer's frame i+t; only frames 0, 1 (they contain the window's left zero
+// padding and the restart of the pre-emphasis, y[0] = x[0]) and 62 (right zero padding) depend on the window, frame 63 is
+// masked.  So per buffer the frames 2 .. n_windows+60 are computed ONCE and shared, plus three edge frames per window:
+// n_windows + 60 + 3 n_windows frames instead of 63 n_windows, bit-identical inputs to the network.
 extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, const int32_t *n_samples, float *const *probs_out,
                              const int32_t *probs_cap, int32_t *n_windows, uint32_t flags) {
     Guard g;
@@ -286,37 +320,54 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     if (n_windows) for (int b = 0; b < B; b++) n_windows[b] = first[b + 1] - first[b];
     if (W == 0) return 0;
     if (stage_audio(d, audio, n_samples, B, (flags & NASR_FLAG_PCM_DEVICE) != 0, base)) return -1;
-    // windows in tiles of max_windows
-    for (int w0 = 0; w0 < W; w0 += d->max_windows) {
-        const int Wt = std::min(d->max_windows, W - w0);
-        long long *h_off = (long long *)d->pin;
-        int *h_len = (int *)(d->pin + (size_t)d->max_windows * sizeof(long long));
-        float *h_prob = (float *)(d->pin + (size_t)d->max_windows * (sizeof(long long) + sizeof(int)));
-        int b = 0;
-        for (int i = 0; i < Wt; i++) {
-            const int w = w0 + i;
-            while (w >= first[b + 1]) b++;
-            h_off[i] = base[b] + (long long)(w - first[b]) * HOP;
-            h_len[i] = VAD_WINDOW / HOP;                                       // full windows: 63 valid frames
-        }
-        DCHK(hipMemcpyAsync(d->win_off, h_off, (size_t)Wt * sizeof(long long), hipMemcpyHostToDevice, d->st));
-        DCHK(hipMemcpyAsync(d->lens, h_len, (size_t)Wt * sizeof(int), hipMemcpyHostToDevice, d->st));
-        DiarMelParams mp;
-        memset(&mp, 0, sizeof(mp));
-        mp.audio = d->audio; mp.win_off = d->win_off; mp.n_win = VAD_WINDOW; mp.T_pad = VAD_T; mp.t_valid = VAD_TVALID;
-        mp.cpitch = DIAR_NMEL; mp.mel = d->mel; mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band;
-        mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
-        launch_diar_logmel(mp, Wt, false, d->st);
-        launch_vad_marblenet(d->vad, d->mel, d->lens, d->prob, Wt, d->st);
-        DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)Wt * sizeof(float), hipMemcpyDeviceToHost, d->st));
+    // frame descriptors: [shared frames of every buffer | 3 edge frames of every window], and per window its row in `shared`
+    size_t n_shared = 0;
+    for (int b = 0; b < B; b++) if (first[b + 1] > first[b]) n_shared += (size_t)(first[b + 1] - first[b]) + 60;
+    const size_t n_frames = n_shared + 3 * (size_t)W;
+    const size_t host_bytes = n_frames * sizeof(DiarFrameDesc) + (size_t)W * (2 * sizeof(int) + sizeof(float));
+    if (host_bytes > d->pin_cap) {
         DCHK(hipStreamSynchronize(d->st));
-        b = 0;
-        for (int i = 0; i < Wt; i++) {
-            const int w = w0 + i;
-            while (w >= first[b + 1]) b++;
-            const int k = w - first[b];
-            if (probs_out && probs_out[b] && probs_cap && k < probs_cap[b]) probs_out[b][k] = h_prob[i];
+        if (d->pin) hipHostFree(d->pin);
+        d->pin = nullptr;
+        d->pin_cap = host_bytes + host_bytes / 2;
+        DCHK(hipHostMalloc((void **)&d->pin, d->pin_cap, hipHostMallocDefault));
+    }
+    DiarFrameDesc *h_fr = (DiarFrameDesc *)d->pin;
+    int *h_row = (int *)(d->pin + n_frames * sizeof(DiarFrameDesc)), *h_len = h_row + W;
+    float *h_prob = (float *)(h_len + W);
+    size_t fs = 0;
+    for (int b = 0; b < B; b++) {
+        const int nw = first[b + 1] - first[b];
+        if (nw == 0) continue;
+        for (int gI = 2; gI <= nw + 61; gI++) { h_fr[fs + gI - 2].base = base[b]; h_fr[fs + gI - 2].n = n_samples[b]; h_fr[fs + gI - 2].t = gI; }
+        for (int i = 0; i < nw; i++) {
+            const int w = first[b] + i;
+            h_row[w] = (int)(fs + (size_t)i) - 2;                  // shared row of local frame t = h_row + t  (t >= 2)
+            h_len[w] = VAD_WINDOW / HOP;                           // full windows: 63 valid frames
+            const int tl[3] = {0, 1, 62};
+            for (int k = 0; k < 3; k++) {
+                DiarFrameDesc &f = h_fr[n_shared + 3 * (size_t)w + k];
+                f.base = base[b] + (long long)i * HOP; f.n = VAD_WINDOW; f.t = tl[k];
+            }
         }
+        fs += (size_t)nw + 60;
+    }
+    if (ensure(d, &d->fr_desc, &d->fr_cap, n_frames) || ensure(d, &d->fr_mel, &d->frm_cap, n_frames * DIAR_NMEL) ||
+        ensure(d, &d->win_row, &d->win_cap, (size_t)2 * W) || ensure(d, &d->prob, &d->prob_cap, (size_t)W))
+        return -1;
+    DCHK(hipMemcpyAsync(d->fr_desc, h_fr, n_frames * sizeof(DiarFrameDesc), hipMemcpyHostToDevice, d->st));
+    DCHK(hipMemcpyAsync(d->win_row, h_row, (size_t)2 * W * sizeof(int), hipMemcpyHostToDevice, d->st));
+    DiarMelParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.audio = d->audio; mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band; mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+    launch_diar_frames(mp, d->fr_desc, (int)n_frames, d->fr_mel, d->st);
+    launch_vad_marblenet(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
+    DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)W * sizeof(float), hipMemcpyDeviceToHost, d->st));
+    DCHK(hipStreamSynchronize(d->st));
+    for (int b = 0; b < B; b++) {
+        const int nw = first[b + 1] - first[b];
+        const int cap = probs_out && probs_out[b] && probs_cap ? probs_cap[b] : 0;
+        for (int i = 0; i < nw && i < cap; i++) probs_out[b][i] = h_prob[first[b] + i];
     }
     return 0;
 }
@@ -397,7 +448,7 @@ static int nasr_diar_load_spk(nasr_diar *d) {
     const size_t S = (size_t)d->max_segments, M = S * SPK_T;
     char *a = nullptr;
     if (dalloc(d, &d->s_mel, M * 96) || dalloc(d, &d->X0, M * C) || dalloc(d, &d->X1, M * C) || dalloc(d, &d->Y, M * C) ||
-        dalloc(d, &d->R, M * 1024) || dalloc(d, &a, M * C * (size_t)d->esz) || dalloc(d, &d->se_z, S * C) ||
+        dalloc(d, &d->R, M * 1024) || dalloc(d, &a, M * C * (size_t)d->esz) || dalloc(d, &d->se_z, 2 * S * C) || dalloc(d, &d->se_h, S * (C / 8)) ||
         dalloc(d, &d->st_mean, S * C) || dalloc(d, &d->st_std, S * C) || dalloc(d, &d->att_c, S * A) || dalloc(d, &d->att_g, M * A) ||
         dalloc(d, &d->pool, S * 2 * C) || dalloc(d, &d->emb, S * SPK_EMB) || dalloc(d, &d->s_lens, S) || dalloc(d, &d->s_off, S))
         return -1;
@@ -456,7 +507,19 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
                 cur = d->Y;
                 cur_pitch = ss.cout;
             }
-            launch_spk_se(d->Y, blk.cout, d->s_lens, blk.fc1, blk.fc2, d->se_z, St, d->st);      // SE before the residual (:365-368)
+            {   // SE gate before the residual (:303-315, :365-368): masked mean over time, two f32 GEMMs over the segments
+                float *mean = d->se_z + (size_t)d->max_segments * SPK_C, *hid = d->se_h;
+                launch_spk_colmean(d->Y, blk.cout, d->s_lens, mean, St, d->st);
+                GemmParams g1, g2;
+                memset(&g1, 0, sizeof(g1));
+                g1.A = mean; g1.W = blk.fc1; g1.M = St; g1.N = blk.cout / 8; g1.K = blk.cout; g1.lda = blk.cout; g1.splits = 1;
+                g1.epi = EPI_BIAS_RELU_F32; g1.out_f32 = hid; g1.ldo = blk.cout / 8; g1.bias = d->zero_bias;
+                launch_gemm_f32(g1, d->st);
+                memset(&g2, 0, sizeof(g2));
+                g2.A = hid; g2.W = blk.fc2; g2.M = St; g2.N = blk.cout; g2.K = blk.cout / 8; g2.lda = blk.cout / 8; g2.splits = 1;
+                g2.epi = EPI_BIAS_F32; g2.out_f32 = d->se_z; g2.ldo = blk.cout; g2.bias = d->zero_bias;
+                launch_gemm_f32(g2, d->st);
+            }
             const float *res = nullptr;
             if (blk.residual) {
                 launch_spk_mask_cvt(x, blk.cin, d->s_lens, d->A, d->bf16, St, d->st);

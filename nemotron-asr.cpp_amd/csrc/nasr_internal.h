@@ -245,6 +245,9 @@ struct DiarMelParams {            // one workgroup per (frame, window)
     const float *cos_t, *sin_t;   // [512]
 };
 void launch_diar_logmel(const DiarMelParams &p, int W, bool per_feature_normalize, hipStream_t st);
+// single frames: frame f = local frame `t` of the window [base, base + n) of the staged audio -> out[f][80]
+struct DiarFrameDesc { long long base; int n; int t; };
+void launch_diar_frames(const DiarMelParams &p, const DiarFrameDesc *frames, int n_frames, float *out, hipStream_t st);
 
 struct VadSub { const float *dw, *pw, *scale, *bias; int kernel, dil, cin, cout; };   // dw == nullptr: pointwise only
 struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blocks, 9 sub-convs, 3 residual paths
@@ -252,15 +255,18 @@ struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blo
     VadSub res[3];                // blocks 1..3
     const float *dec_w, *dec_b;   // [2][128], [2]
 };
-// one workgroup per window: mel [W][64][80] -> P(speech) [W]; lens_mel [W] valid frames (masked convs)
-void launch_vad_marblenet(const VadNet &net, const float *mel, const int *lens_mel, float *prob, int W, hipStream_t st);
+// one workgroup per window -> P(speech) [W]; lens_mel [W] valid frames (masked convs).  The 64 mel rows of window w:
+// rows 2..61 = shared[win_row[w].x + t] (frames that overlapping windows have in common, computed once per stream),
+// rows 0, 1, 62 = edge[3 w + {0, 1, 2}] (they see the window's own zero padding / pre-emphasis start), row 63 = 0
+void launch_vad_marblenet(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
+                          float *prob, int W, hipStream_t st);
 void init_diar_kernel_attributes();
 
 // TitaNet-L pieces (src/diarize_spk.cpp:320-515); activations [S * 160][C] f32, channels innermost
 void launch_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad, const int *lens, void *a_out,
                           int out_bf16, int S, hipStream_t st);               // masked 'same' depthwise conv -> GEMM A operand
 void launch_spk_mask_cvt(const float *x, int C, const int *lens, void *a_out, int out_bf16, int S, hipStream_t st);
-void launch_spk_se(const float *y, int C, const int *lens, const float *fc1, const float *fc2, float *z, int S, hipStream_t st);
+void launch_spk_colmean(const float *y, int C, const int *lens, float *mean, int S, hipStream_t st);   // masked mean over time (SE)
 void launch_spk_combine(const float *y, const float *z, const float *r, int C, const int *lens, float *out, int S, hipStream_t st);
 void launch_spk_stats(const float *x, int C, const int *lens, float *mean, float *stdv, int S, hipStream_t st);
 void launch_spk_att_const(const float *mean, const float *stdv, const float *w1, const float *b1, float *c, int C, int A, int S, hipStream_t st);

@@ -1,0 +1,38 @@
+"""Throughput of the diarization side-car on the GPU (BASELINE config 5 shape: 64 streams):
+VAD windows per second and speaker embeddings per second, random-init MarbleNet / TitaNet-L."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import __graft_entry__ as ge
+
+ge.load_package()
+from nemotron_asr_amd import capi, synth
+
+B = 64
+W = synth.make_diar_weights()
+for dtype, name in ((capi.DTYPE_BF16, "bf16"), (capi.DTYPE_F32, "f32")):
+    eng = capi.Diar(W, dtype=dtype, max_windows=8192, max_segments=96)
+    # one ASR step at R = 13 brings 1.12 s of new audio per stream: 112 new VAD windows (plus 0.63 s of history)
+    audio = [synth.make_pcm(s, 1.75 + 0.02)[:10080 + 111 * 160].astype(np.float32) / 32768.0 for s in range(B)]
+    eng.vad(audio)
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        out = eng.vad(audio)
+    dt = (time.perf_counter() - t0) / n
+    nw = sum(o.size for o in out)
+    print(f"[{name}] VAD: {nw} windows of {B} streams in {dt * 1e3:.2f} ms = {nw / dt / 1e3:.0f} k windows/s "
+          f"= {nw / 100.0 / dt:.0f} x real time (100 windows per audio-second)", flush=True)
+    segs = [synth.make_pcm(100 + s, 1.5 + 0.01)[:24000].astype(np.float32) / 32768.0 for s in range(96)]
+    eng.embed(segs)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        e = eng.embed(segs)
+    dt = (time.perf_counter() - t0) / n
+    print(f"[{name}] TitaNet-L: {len(segs)} sub-segments in {dt * 1e3:.2f} ms = {len(segs) / dt:.0f} embeddings/s "
+          f"({4.3 * len(segs) / dt / 1e3:.1f} TFLOP/s at 4.3 GFLOP each); 64 streams need ~85/s", flush=True)
+    eng.close()
