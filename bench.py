@@ -79,6 +79,9 @@ def parse():
                     help="audio seconds of the CPU-baseline sample (~10-20 s of CPU work on 16 host threads)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-buffered", action="store_true", help="skip the buffered-audio (file transcription) figure")
+    ap.add_argument("--diarize", action="store_true",
+                    help="BASELINE config 5: also time the diarization side-car on each step's audio (MarbleNet VAD on every "
+                         "10 ms window + TitaNet-L embeddings of 1.5 s sub-segments at a 0.75 s shift, random-init weights)")
     return ap.parse_args()
 
 
@@ -229,6 +232,33 @@ def main():
                         note="same engine, same stream semantics (80 ms lookahead, chunk-by-chunk caches), the 256 chunks of "
                              "a push go through every layer as one launch sequence; not the headline value")
 
+    # ---- diarization side-car on the same audio (BASELINE config 5) ---------------------------------------------------
+    diar = None
+    if args.diarize and rank == 0:
+        dW = synth.make_diar_weights()
+        deng = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * B), device=local_rank)
+        hist = 10080 - 160                                   # samples of history a new 10 ms hop needs
+        step_audio = [(p[:hist + n_step].astype(np.float32) / 32768.0) for p in pcm_host]          # host-resident float audio
+        n_seg = max(1, int(round(B * (n_step / synth.SAMPLE_RATE) / 0.75)))                          # sub-segment shift 0.75 s
+        segs = [(pcm_host[i % B][:24000].astype(np.float32) / 32768.0) for i in range(n_seg)]
+        deng.vad(step_audio); deng.embed(segs)
+        reps = 10
+        eng.synchronize()
+        tq = time.perf_counter()
+        for _ in range(reps):
+            pv = deng.vad(step_audio)
+        t_vad = (time.perf_counter() - tq) / reps
+        tq = time.perf_counter()
+        for _ in range(reps):
+            deng.embed(segs)
+        t_spk = (time.perf_counter() - tq) / reps
+        step_s = elapsed / args.steps
+        diar = dict(vad_windows_per_step=int(sum(x.size for x in pv)), vad_ms_per_step=round(1e3 * t_vad, 3),
+                    embeddings_per_step=n_seg, embed_ms_per_step=round(1e3 * t_spk, 3),
+                    asr_plus_diarization_rtfx=round(audio_per_step / (step_s + t_vad + t_spk), 1),
+                    note="run after the ASR step on the same stream (not overlapped); audio handed over from host memory")
+        deng.close()
+
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample ------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -276,6 +306,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "buffered_audio": buffered,
+            "diarization": diar,
             "kernels": [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in kernels],
             "setup_s": {"weights": round(t_weights, 1)},
         }

@@ -67,6 +67,7 @@ struct nasr_diar {
     void *A = nullptr; int *s_lens = nullptr; long long *s_off = nullptr;
     // scratch
     float *audio = nullptr; size_t audio_cap = 0;       // staged input samples
+    float *pin_audio = nullptr; size_t pin_audio_cap = 0;
     DiarFrameDesc *fr_desc = nullptr; size_t fr_cap = 0;  // VAD: frame descriptors, frames [n][80], per-window rows / lens, results
     float *fr_mel = nullptr; size_t frm_cap = 0;
     int *win_row = nullptr; size_t win_cap = 0;
@@ -213,10 +214,23 @@ int stage_audio(nasr_diar *d, const float *const *audio, const int32_t *n, int B
         d->audio_cap = total + 65536;
         DCHK(hipMalloc((void **)&d->audio, d->audio_cap * sizeof(float)));
     }
-    for (int b = 0; b < B; b++)
-        if (n[b] > 0)
-            DCHK(hipMemcpyAsync(d->audio + base[b], audio[b], (size_t)n[b] * sizeof(float),
-                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, d->st));
+    if (on_device) {
+        for (int b = 0; b < B; b++)
+            if (n[b] > 0) DCHK(hipMemcpyAsync(d->audio + base[b], audio[b], (size_t)n[b] * sizeof(float), hipMemcpyDeviceToDevice, d->st));
+    } else {
+        // host hand-over: gather into one pinned block, one H2D copy (pageable sources would be staged piecewise by the runtime)
+        if (total > d->pin_audio_cap) {
+            DCHK(hipStreamSynchronize(d->st));
+            if (d->pin_audio) hipHostFree(d->pin_audio);
+            d->pin_audio = nullptr;
+            d->pin_audio_cap = total + 65536;
+            DCHK(hipHostMalloc((void **)&d->pin_audio, d->pin_audio_cap * sizeof(float), hipHostMallocDefault));
+        }
+        DCHK(hipStreamSynchronize(d->st));          // the previous call's copy out of the pinned block has finished
+        for (int b = 0; b < B; b++)
+            if (n[b] > 0) memcpy(d->pin_audio + base[b], audio[b], (size_t)n[b] * sizeof(float));
+        DCHK(hipMemcpyAsync(d->audio, d->pin_audio, total * sizeof(float), hipMemcpyHostToDevice, d->st));
+    }
     return 0;
 }
 }  // namespace
@@ -235,6 +249,7 @@ extern "C" void nasr_diar_destroy(nasr_diar *d) {
     if (d->win_row) hipFree(d->win_row);
     if (d->prob) hipFree(d->prob);
     if (d->pin) hipHostFree(d->pin);
+    if (d->pin_audio) hipHostFree(d->pin_audio);
     if (d->st) hipStreamDestroy(d->st);
     delete d;
 }
