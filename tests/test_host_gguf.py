@@ -232,3 +232,45 @@ def test_server_batches_streams(tmp_path):
         except subprocess.TimeoutExpired:
             proc.kill()
     assert "streams per call" in proc.stderr.read()
+
+
+@pytest.mark.gpu
+def test_diarize_cli_end_to_end(tmp_path):
+    """diarize.gguf ("vad.*" + "spk.*", layouts of scripts/convert_diarize_to_gguf.py) -> C++ loader -> side-car engine:
+    window probabilities through the onset/offset rule, sub-segment embeddings == the oracle's."""
+    from oracle import diar_binding as db
+    W = synth.make_diar_weights()
+    model = tmp_path / "diarize.gguf"
+    gguf_io.write_gguf(model, W, {}, [], name="nemo-diarize-synthetic")
+    pcm = synth.make_pcm(4, 3.2)
+    audio = tmp_path / "d.pcm"
+    pcm.tofile(audio)
+    a = pcm.astype(np.float32) / 32768.0
+    om = db.DiarModel(W)
+    probs = om.vad_batch(a)
+    onset = float(np.median(probs))                     # a threshold that splits this (random-weight) probability track
+    cli = BIN / "diarize-amd"
+    assert cli.exists(), "run __graft_entry__.build()"
+    r = subprocess.run([str(cli), str(model), str(audio), "--f32", "--onset", repr(onset), "--offset", repr(onset), "--sub-shift", "0.75"],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == f"WINDOWS {probs.size}"
+    segs = [tuple(float(x) for x in ln.split()[1:]) for ln in lines if ln.startswith("SEGMENT")]
+    want, start = [], None                              # src/diarize_vad.cpp:507-563 with the default post-processing
+    for t, p in enumerate(probs):
+        if start is None and p >= onset:
+            start = t
+        elif start is not None and p < onset:
+            want.append((start * 0.01, t * 0.01)); start = None
+    if start is not None:
+        want.append((start * 0.01, probs.size * 0.01))
+    # a window whose probability sits within float noise of the threshold may flip: allow it, compare the rest
+    assert abs(len(segs) - len(want)) <= 2 and len(want) >= 1
+    if len(segs) == len(want):
+        assert np.abs(np.array(segs) - np.array(want)).max() < 0.011
+    emb = [[float(x) for x in ln.split()[2:]] for ln in lines if ln.startswith("EMBED")]
+    starts = list(range(0, a.size - 24000 + 1, 12000))
+    assert len(emb) == len(starts) and len(emb[0]) == 192
+    ref = np.stack([om.spk_embed(a[s:s + 24000]) for s in starts])
+    assert np.abs(np.array(emb) - ref).max() < 2e-3 * np.abs(ref).max()
