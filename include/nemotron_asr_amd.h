@@ -49,6 +49,7 @@ enum { NASR_TYPE_F32 = 0, NASR_TYPE_F16 = 1, NASR_TYPE_Q4_0 = 2, NASR_TYPE_Q8_0 
 enum {
     NASR_FLAG_PCM_DEVICE = 1u << 0, /* pcm[] are device pointers (inputs already resident in HBM) */
     NASR_FLAG_NO_SYNC    = 1u << 1, /* do not copy tokens back / synchronise; poll with nasr_engine_collect() */
+    NASR_FLAG_AUDIO_S16  = 1u << 2, /* nasr_diar_*: audio[] point at s16 PCM (sample / 32768), e.g. the ASR streams' own buffers */
 };
 
 /* model hyper-parameters = the `nemo.*` GGUF keys read at src/nemo-ggml.cpp:108-142
@@ -195,7 +196,8 @@ int  nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weig
 void nasr_diar_destroy(nasr_diar *d);
 /* vad_session_run_batch (src/diarize_vad.cpp:490-503) for B buffers in one launch sequence: P(speech) of every 0.63 s
  * window (10 080 samples) of audio[b] at a 10 ms shift (the reference runs each window as its own graph,
- * src/diarize_pipeline.cpp:204-211).  audio: float samples in [-1, 1] (host, or device with NASR_FLAG_PCM_DEVICE);
+ * src/diarize_pipeline.cpp:204-211).  audio: float samples in [-1, 1], or s16 PCM cast to the pointer type with
+ * NASR_FLAG_AUDIO_S16; host memory, or device memory with NASR_FLAG_PCM_DEVICE;
  * n_windows[b] = 1 + (n_samples[b] - 10080) / 160, or 0. */
 int  nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, const int32_t *n_samples, float *const *probs_out,
                    const int32_t *probs_cap, int32_t *n_windows, uint32_t flags);

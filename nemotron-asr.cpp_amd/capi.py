@@ -15,6 +15,7 @@ LIB_PATH = HERE / "libnemotron_asr_amd.so"
 DTYPE_F32, DTYPE_BF16 = 0, 1
 TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q8_0 = 0, 1, 2, 8
 FLAG_PCM_DEVICE, FLAG_NO_SYNC = 1, 2
+FLAG_AUDIO_S16 = 4
 TAP_MEL, TAP_SUBSAMPLED, TAP_LAYER_OUT, TAP_ENCODER_OUT, TAP_K_CACHE, TAP_V_CACHE, TAP_CONV_CACHE, TAP_DEC_STATE = range(8)
 
 EXPORTS = [
@@ -200,17 +201,35 @@ class Diar:
         self.close()
 
     def vad(self, audios: list) -> list:
-        """P(speech) of every 0.63 s window (10 ms shift) of each float32 buffer -> list of float32 arrays"""
+        """P(speech) of every 0.63 s window (10 ms shift) of each buffer (float32 in [-1, 1], or int16 PCM) -> float32 arrays"""
         B = len(audios)
-        bufs = [np.ascontiguousarray(a, np.float32) for a in audios]
-        n = (C.c_int32 * B)(*[b.size for b in bufs])
-        outs = [np.zeros(max(1, 1 + (b.size - 10080) // 160 if b.size >= 10080 else 1), np.float32) for b in bufs]
-        ap = (C.c_void_p * B)(*[b.ctypes.data for b in bufs])
+        s16 = all(np.asarray(a).dtype == np.int16 for a in audios)
+        bufs = [np.ascontiguousarray(a, np.int16 if s16 else np.float32) for a in audios]
+        return self._vad([b.ctypes.data for b in bufs], [b.size for b in bufs], FLAG_AUDIO_S16 if s16 else 0)
+
+    def vad_device_s16(self, ptrs: list, n_samples: list) -> list:
+        """same, on s16 PCM that is already in HBM (device pointers, e.g. Engine.upload): the ASR streams' own audio"""
+        return self._vad(ptrs, n_samples, FLAG_AUDIO_S16 | FLAG_PCM_DEVICE)
+
+    def _vad(self, ptrs, sizes, flags):
+        B = len(ptrs)
+        n = (C.c_int32 * B)(*sizes)
+        outs = [np.zeros(max(1, 1 + (sz - 10080) // 160 if sz >= 10080 else 1), np.float32) for sz in sizes]
+        ap = (C.c_void_p * B)(*ptrs)
         op = (C.c_void_p * B)(*[o.ctypes.data for o in outs])
         caps = (C.c_int32 * B)(*[o.size for o in outs])
         nw = (C.c_int32 * B)()
-        _chk(lib().nasr_diar_vad(self.h, B, ap, n, op, caps, nw, 0))
+        _chk(lib().nasr_diar_vad(self.h, B, ap, n, op, caps, nw, flags))
         return [outs[b][:nw[b]] for b in range(B)]
+
+    def embed_device_s16(self, ptrs: list, lens: list = None) -> np.ndarray:
+        """192-d embeddings of sub-segments given as device pointers to 24 000 s16 samples each"""
+        S = len(ptrs)
+        ln = (C.c_int32 * S)(*(lens or [24000] * S))
+        ap = (C.c_void_p * S)(*ptrs)
+        out = np.zeros((S, 192), np.float32)
+        _chk(lib().nasr_diar_embed(self.h, S, ap, ln, out.ctypes.data_as(C.POINTER(C.c_float)), FLAG_AUDIO_S16 | FLAG_PCM_DEVICE))
+        return out
 
     def embed(self, segments: list, lens: list = None) -> np.ndarray:
         """192-d embeddings of 1.5 s sub-segments (each zero padded to 24 000 samples) -> [S][192]"""

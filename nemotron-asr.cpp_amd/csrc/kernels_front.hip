@@ -220,13 +220,21 @@ void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, co
 // window (y[0] = x[0], :83-93), the STFT is centred with zero padding (:119-125), power = re^2 + im^2 without the
 // sqrt round trip (:127-131), frames >= t_valid (the +1 frame of the centred STFT and the pad-to-16 tail) are zeros.
 // Operation order as in the reference (this file is compiled without FMA contraction).
-__device__ __forceinline__ void diar_frame(const DiarMelParams &p, const float *x, int n_win, int t, float *out, int cpitch) {
+template <typename Tp>
+__device__ __forceinline__ float diar_sample(const Tp *x, int i);
+template <>
+__device__ __forceinline__ float diar_sample<float>(const float *x, int i) { return x[i]; }
+template <>
+__device__ __forceinline__ float diar_sample<int16_t>(const int16_t *x, int i) { return (float)x[i] / 32768.0f; }   // src/diarize_pipeline.cpp: s16 -> [-1, 1)
+
+template <typename Tp>
+__device__ __forceinline__ void diar_frame(const DiarMelParams &p, const Tp *x, int n_win, int t, float *out, int cpitch) {
     __shared__ float re[NFFT], im[NFFT], pw[NBINS + 3];
     const int start = t * HOP - NFFT / 2;
     for (int i = threadIdx.x; i < NFFT; i += 256) {
         const int idx = start + i;
         float s = 0.0f;
-        if (idx >= 0 && idx < n_win) s = idx == 0 ? x[0] : __fsub_rn(x[idx], __fmul_rn(0.97f, x[idx - 1]));
+        if (idx >= 0 && idx < n_win) s = idx == 0 ? diar_sample(x, 0) : __fsub_rn(diar_sample(x, idx), __fmul_rn(0.97f, diar_sample(x, idx - 1)));
         const float v = __fmul_rn(s, p.window[i]);
         const int j = (int)(__brev((unsigned)i) >> 23);
         re[j] = v;
@@ -267,7 +275,8 @@ __global__ __launch_bounds__(256) void k_diar_logmel(DiarMelParams p) {
         for (int c = threadIdx.x; c < p.cpitch; c += 256) out[c] = 0.0f;
         return;
     }
-    diar_frame(p, p.audio + p.win_off[w], p.n_win, t, out, p.cpitch);
+    if (p.audio_s16) diar_frame(p, p.audio_s16 + p.win_off[w], p.n_win, t, out, p.cpitch);
+    else diar_frame(p, p.audio + p.win_off[w], p.n_win, t, out, p.cpitch);
 }
 
 // the sliding-window VAD: frame t of the window at sample offset i*160 covers the same samples as frame t+1 of the window
@@ -275,7 +284,8 @@ __global__ __launch_bounds__(256) void k_diar_logmel(DiarMelParams p) {
 // frame -- so frames are computed per descriptor, once for all the windows that share them (nasr_diar.hip)
 __global__ __launch_bounds__(256) void k_diar_frames(DiarMelParams p, const DiarFrameDesc *frames, float *out) {
     const DiarFrameDesc f = frames[blockIdx.x];
-    diar_frame(p, p.audio + f.base, f.n, f.t, out + (size_t)blockIdx.x * DIAR_NMEL, DIAR_NMEL);
+    if (p.audio_s16) diar_frame(p, p.audio_s16 + f.base, f.n, f.t, out + (size_t)blockIdx.x * DIAR_NMEL, DIAR_NMEL);
+    else diar_frame(p, p.audio + f.base, f.n, f.t, out + (size_t)blockIdx.x * DIAR_NMEL, DIAR_NMEL);
 }
 void launch_diar_frames(const DiarMelParams &p, const DiarFrameDesc *frames, int n_frames, float *out, hipStream_t st) {
     if (n_frames > 0) hipLaunchKernelGGL(k_diar_frames, dim3(n_frames), dim3(256), 0, st, p, frames, out);

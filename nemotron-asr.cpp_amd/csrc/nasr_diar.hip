@@ -66,8 +66,8 @@ struct nasr_diar {
     float *att_c = nullptr, *att_g = nullptr, *pool = nullptr, *emb = nullptr, *se_h = nullptr;
     void *A = nullptr; int *s_lens = nullptr; long long *s_off = nullptr;
     // scratch
-    float *audio = nullptr; size_t audio_cap = 0;       // staged input samples
-    float *pin_audio = nullptr; size_t pin_audio_cap = 0;
+    char *audio = nullptr; size_t audio_cap = 0;        // staged input samples (float or s16), capacities in bytes
+    char *pin_audio = nullptr; size_t pin_audio_cap = 0;
     DiarFrameDesc *fr_desc = nullptr; size_t fr_cap = 0;  // VAD: frame descriptors, frames [n][80], per-window rows / lens, results
     float *fr_mel = nullptr; size_t frm_cap = 0;
     int *win_row = nullptr; size_t win_cap = 0;
@@ -203,35 +203,43 @@ int load_vad(nasr_diar *d) {
     return 0;
 }
 
-int stage_audio(nasr_diar *d, const float *const *audio, const int32_t *n, int B, bool on_device, std::vector<long long> &base) {
+// gathers the B input buffers (float, or s16 with NASR_FLAG_AUDIO_S16; host or device) into one device buffer;
+// base[b] = element offset of buffer b
+int stage_audio(nasr_diar *d, const float *const *audio, const int32_t *n, int B, uint32_t flags, std::vector<long long> &base) {
+    const bool on_device = (flags & NASR_FLAG_PCM_DEVICE) != 0;
+    const size_t esz = (flags & NASR_FLAG_AUDIO_S16) ? sizeof(int16_t) : sizeof(float);
     size_t total = 0;
     base.resize(B);
     for (int b = 0; b < B; b++) { base[b] = (long long)total; total += (size_t)std::max(n[b], 0); }
-    if (total > d->audio_cap) {
+    if (total * esz > d->audio_cap) {
         DCHK(hipStreamSynchronize(d->st));
         if (d->audio) hipFree(d->audio);
         d->audio = nullptr;
-        d->audio_cap = total + 65536;
-        DCHK(hipMalloc((void **)&d->audio, d->audio_cap * sizeof(float)));
+        d->audio_cap = total * esz + 262144;
+        DCHK(hipMalloc((void **)&d->audio, d->audio_cap));
     }
     if (on_device) {
         for (int b = 0; b < B; b++)
-            if (n[b] > 0) DCHK(hipMemcpyAsync(d->audio + base[b], audio[b], (size_t)n[b] * sizeof(float), hipMemcpyDeviceToDevice, d->st));
+            if (n[b] > 0) DCHK(hipMemcpyAsync(d->audio + (size_t)base[b] * esz, audio[b], (size_t)n[b] * esz, hipMemcpyDeviceToDevice, d->st));
     } else {
         // host hand-over: gather into one pinned block, one H2D copy (pageable sources would be staged piecewise by the runtime)
-        if (total > d->pin_audio_cap) {
+        if (total * esz > d->pin_audio_cap) {
             DCHK(hipStreamSynchronize(d->st));
             if (d->pin_audio) hipHostFree(d->pin_audio);
             d->pin_audio = nullptr;
-            d->pin_audio_cap = total + 65536;
-            DCHK(hipHostMalloc((void **)&d->pin_audio, d->pin_audio_cap * sizeof(float), hipHostMallocDefault));
+            d->pin_audio_cap = total * esz + 262144;
+            DCHK(hipHostMalloc((void **)&d->pin_audio, d->pin_audio_cap, hipHostMallocDefault));
         }
         DCHK(hipStreamSynchronize(d->st));          // the previous call's copy out of the pinned block has finished
         for (int b = 0; b < B; b++)
-            if (n[b] > 0) memcpy(d->pin_audio + base[b], audio[b], (size_t)n[b] * sizeof(float));
-        DCHK(hipMemcpyAsync(d->audio, d->pin_audio, total * sizeof(float), hipMemcpyHostToDevice, d->st));
+            if (n[b] > 0) memcpy(d->pin_audio + (size_t)base[b] * esz, audio[b], (size_t)n[b] * esz);
+        DCHK(hipMemcpyAsync(d->audio, d->pin_audio, total * esz, hipMemcpyHostToDevice, d->st));
     }
     return 0;
+}
+void set_audio(const nasr_diar *d, uint32_t flags, DiarMelParams &mp) {
+    if (flags & NASR_FLAG_AUDIO_S16) { mp.audio = nullptr; mp.audio_s16 = (const int16_t *)d->audio; }
+    else { mp.audio = (const float *)d->audio; mp.audio_s16 = nullptr; }
 }
 }  // namespace
 
@@ -334,7 +342,7 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     const int W = first[B];
     if (n_windows) for (int b = 0; b < B; b++) n_windows[b] = first[b + 1] - first[b];
     if (W == 0) return 0;
-    if (stage_audio(d, audio, n_samples, B, (flags & NASR_FLAG_PCM_DEVICE) != 0, base)) return -1;
+    if (stage_audio(d, audio, n_samples, B, flags, base)) return -1;
     // frame descriptors: [shared frames of every buffer | 3 edge frames of every window], and per window its row in `shared`
     size_t n_shared = 0;
     for (int b = 0; b < B; b++) if (first[b + 1] > first[b]) n_shared += (size_t)(first[b + 1] - first[b]) + 60;
@@ -374,7 +382,8 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     DCHK(hipMemcpyAsync(d->win_row, h_row, (size_t)2 * W * sizeof(int), hipMemcpyHostToDevice, d->st));
     DiarMelParams mp;
     memset(&mp, 0, sizeof(mp));
-    mp.audio = d->audio; mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band; mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+    set_audio(d, flags, mp);
+    mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band; mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
     launch_diar_frames(mp, d->fr_desc, (int)n_frames, d->fr_mel, d->st);
     launch_vad_marblenet(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
     DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)W * sizeof(float), hipMemcpyDeviceToHost, d->st));
@@ -491,7 +500,7 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         std::vector<int32_t> n(St, SPK_SEGMENT);
         std::vector<long long> base;
         for (int s = 0; s < St; s++) if (!audio[s0 + s]) return failf("segment %d: null audio", s0 + s);
-        if (stage_audio(d, audio + s0, n.data(), St, (flags & NASR_FLAG_PCM_DEVICE) != 0, base)) return -1;
+        if (stage_audio(d, audio + s0, n.data(), St, flags, base)) return -1;
         long long *h_off = (long long *)d->pin;
         int *h_len = (int *)(d->pin + (size_t)d->max_segments * sizeof(long long));
         for (int s = 0; s < St; s++) {
@@ -503,7 +512,8 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         DCHK(hipMemcpyAsync(d->s_lens, h_len, (size_t)St * sizeof(int), hipMemcpyHostToDevice, d->st));
         DiarMelParams mp;
         memset(&mp, 0, sizeof(mp));
-        mp.audio = d->audio; mp.win_off = d->s_off; mp.n_win = SPK_SEGMENT; mp.T_pad = SPK_T; mp.t_valid = SPK_TVALID;
+        set_audio(d, flags, mp);
+        mp.win_off = d->s_off; mp.n_win = SPK_SEGMENT; mp.T_pad = SPK_T; mp.t_valid = SPK_TVALID;
         mp.cpitch = 96; mp.mel = d->s_mel; mp.window = d->window; mp.fbT = d->spk_fbT; mp.fb_band = d->spk_band;
         mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
         launch_diar_logmel(mp, St, true, d->st);                        // per-feature normalisation on (:578)

@@ -233,7 +233,8 @@ constexpr int SPK_SEGMENT = 24000, SPK_T = 160, SPK_TVALID = 150;   // src/diari
 constexpr int SPK_EMB = 192, SPK_C = 3072, SPK_ATT = 128;
 
 struct DiarMelParams {            // one workgroup per (frame, window)
-    const float *audio;           // all windows index into this buffer
+    const float *audio;           // all windows index into this buffer ...
+    const int16_t *audio_s16;     // ... or into this one (s16 PCM, sample / 32768: the ASR stream's own buffers), if not null
     const long long *win_off;     // [W] sample offset of every window
     int n_win;                    // samples per window (10080 / 24000)
     int T_pad, t_valid;           // frames written per window (64 / 160), of which valid (63 / 150)

@@ -54,6 +54,26 @@ def test_speaker_embeddings_match_oracle(dtype, tol):
     eng.close()
 
 
+def test_s16_device_resident_audio_equals_float_host_audio(Wv):
+    """NASR_FLAG_AUDIO_S16 | NASR_FLAG_PCM_DEVICE: the side-car reads s16 PCM that is already in HBM (the ASR streams' own
+    buffers) -- same probabilities / embeddings as float host audio (x / 32768 is exact in f32)."""
+    W = dict(Wv)
+    W.update(synth.make_diar_weights(vad=False))
+    eng = capi.Diar(W, dtype=capi.DTYPE_F32)
+    asr = capi.Engine(synth.make_weights(n_layers=1), n_layers=1, dtype=capi.DTYPE_BF16, max_streams=1)   # only for its device allocator
+    pcm = [synth.make_pcm(30 + b, 1.6)[:24000 + 800 * b] for b in range(2)]
+    dev = [asr.upload(p) for p in pcm]
+    host = eng.vad([p.astype(np.float32) / 32768.0 for p in pcm])
+    for got in (eng.vad(pcm), eng.vad_device_s16(dev, [p.size for p in pcm])):
+        for g, h in zip(got, host):
+            assert g.size == h.size > 0 and np.abs(g - h).max() < 1e-6
+    e_host = eng.embed([p[:24000].astype(np.float32) / 32768.0 for p in pcm])
+    e_dev = eng.embed_device_s16(dev)
+    assert np.abs(e_dev - e_host).max() < 1e-5 * np.abs(e_host).max()
+    eng.close()
+    asr.close()
+
+
 def test_vad_errors(Wv):
     eng = capi.Diar(Wv)
     with pytest.raises(capi.NasrError):
