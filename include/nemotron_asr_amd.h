@@ -205,6 +205,13 @@ int  nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, const int32_t
  * padded by the caller), lens_samples[s] of them real; emb_out = [S][192]. */
 int  nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, const int32_t *lens_samples, float *emb_out, uint32_t flags);
 
+/* parity tap: diarize_compute_logmel (src/diarize_audio.cpp:136-227) of one whole host buffer on the device front end,
+ * which = 0: the 'vad.*' filterbank, 1: 'spk.*'.  mel_out = [80][t_padded] row-major like the reference's output
+ * (t_padded = t_valid rounded up to 16, t_valid = n_samples / 160); this is what tests/test_diarize_preproc.cpp checks
+ * against the NeMo fixture (threshold 1e-3). */
+int  nasr_diar_logmel(nasr_diar *d, int which, const float *audio, int32_t n_samples, int per_feature_normalize,
+                      float *mel_out, int64_t cap, int32_t *t_valid_out);
+
 #ifdef __cplusplus
 }
 #endif

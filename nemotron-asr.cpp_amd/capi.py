@@ -25,7 +25,7 @@ EXPORTS = [
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize",
-    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_vad", "nasr_diar_embed",
+    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel",
 ]
 
 
@@ -75,6 +75,7 @@ def lib():
         L.nasr_diar_destroy.restype = None
         L.nasr_diar_vad.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
         L.nasr_diar_embed.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(C.c_float), C.c_uint32]
+        L.nasr_diar_logmel.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int32, C.c_int, C.POINTER(C.c_float), C.c_int64, ip]
         L.nasr_stream_get_token_frames.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
         L.nasr_engine_step.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
         L.nasr_engine_step_mel.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
@@ -230,6 +231,17 @@ class Diar:
         out = np.zeros((S, 192), np.float32)
         _chk(lib().nasr_diar_embed(self.h, S, ap, ln, out.ctypes.data_as(C.POINTER(C.c_float)), FLAG_AUDIO_S16 | FLAG_PCM_DEVICE))
         return out
+
+    def logmel(self, audio: np.ndarray, which: str = "vad", normalize: bool = False):
+        """parity tap: diarize_compute_logmel of one buffer on the device front end -> ([80][t_padded], t_valid)"""
+        a = np.ascontiguousarray(audio, np.float32)
+        t_valid = a.size // 160
+        t_pad = (t_valid + 15) // 16 * 16
+        out = np.empty((80, t_pad), np.float32)
+        tv = C.c_int32(0)
+        _chk(lib().nasr_diar_logmel(self.h, 0 if which == "vad" else 1, a.ctypes.data_as(C.POINTER(C.c_float)), a.size,
+                                    int(normalize), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(tv)))
+        return out, tv.value
 
     def embed(self, segments: list, lens: list = None) -> np.ndarray:
         """192-d embeddings of 1.5 s sub-segments (each zero padded to 24 000 samples) -> [S][192]"""

@@ -186,7 +186,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char qu_s[16 * 256], qv_s[16 * 256], w_s[16 * 256];
     __shared__ __attribute__((aligned(16))) char vt_s[128 * 256];
-    __shared__ float sk[16 * 96], sp[16 * 112];
+    constexpr int SKP = 100, SPP = 116;                    // row pitches (floats) of the score tiles: 96 / 112 + 4, so the 16 query rows of a float4 store spread over the banks
+    __shared__ __attribute__((aligned(16))) float sk[16 * SKP], sp[16 * SPP];
     const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
     const int TS = p.TS > 0 ? p.TS : p.T;
     const int QB = T <= 2 ? 16 : T;                          // query rows per workgroup
@@ -201,59 +202,87 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     const bf16_t *vbase = kbase + (size_t)KVC * D;
     const bf16_t *pbase = (const bf16_t *)p.posproj + h * DH;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    // ---- every global read of the workgroup is requested up front (they depend only on the row descriptor): the V
+    // rows, this wave's K / relative-position tiles and the queries arrive in ONE round trip instead of three ----
+    float qreg[8];                                         // the queries first: the previous kernel wrote them
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int e = threadIdx.x + it * 256, i = e >> 7, d = e & 127;
+        qreg[it] = i < nrows ? p.q[(row0 + i) * D + h * DH + d] : 0.0f;
+    }
+    uint4 vreg[6];
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int e = threadIdx.x + it * 256, c = e & 15, j = e >> 4;      // 8 consecutive d of span key j
+        vreg[it] = make_uint4(0, 0, 0, 0);
+        if (j < span) {
+            int ring = head0 + j;
+            if (ring >= KVC) ring -= KVC;
+            vreg[it] = *(const uint4 *)(vbase + (size_t)ring * D + c * 8);
+        }
+    }
+    uint4 av[4][4];                                        // tiles wave, wave + 4, wave + 8, wave + 12 of the 6 key + 7 position tiles
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int t = wave + 4 * n;
+        if (t < 13) {
+            const bf16_t *arow;
+            if (t < 6) {
+                int j = t * 16 + r;
+                if (j >= span) j = span - 1;
+                int ring = head0 + j;
+                if (ring >= KVC) ring -= KVC;
+                arow = kbase + (size_t)ring * D;
+            } else {
+                int rr = (t - 6) * 16 + r;
+                if (rr >= n_rel) rr = n_rel - 1;
+                arow = pbase + (size_t)rr * D;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) av[n][ks] = *(const uint4 *)(arow + ks * 32 + q * 8);
+        }
+    }
     // ---- phase 0: queries (+u, +v) -> bf16 LDS; V tile -> transposed LDS (zero padded to 96 keys) ----
-    for (int e = threadIdx.x; e < 16 * DH; e += 256) {
-        const int i = e >> 7, d = e & 127;
-        const float qq = i < nrows ? p.q[(row0 + i) * D + h * DH + d] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int e = threadIdx.x + it * 256, i = e >> 7, d = e & 127;
+        const float qq = qreg[it];
         const int off = i * 256 + ((((d >> 3) ^ i) & 15) << 4) + (d & 7) * 2;
         *(bf16_t *)(qu_s + off) = f32_to_bf16(qq + p.bias_u[h * DH + d]);
         *(bf16_t *)(qv_s + off) = f32_to_bf16(qq + p.bias_v[h * DH + d]);
     }
-    for (int e = threadIdx.x; e < 96 * 16; e += 256) {
-        const int c = e & 15, j = e >> 4;               // 8 consecutive d of key j
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (j < span) {
-            int ring = head0 + j;
-            if (ring >= KVC) ring -= KVC;
-            v = *(const uint4 *)(vbase + (size_t)ring * D + c * 8);
-        }
-        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+    // V^T image: row d = 256 B = 16 chunks of 8 keys; chunk (j >> 3) sits at ((j >> 3) ^ d ^ (d >> 4)) & 15.  The 16 lanes
+    // that hold the 16 d-groups of one key write 16 different chunks (d & 15 alone takes two values there: 16-way
+    // conflicts, SQ_LDS_BANK_CONFLICT 85 % of the LDS cycles of this kernel before)
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int e = threadIdx.x + it * 256, c = e & 15, j = e >> 4;
+        const uint32_t w4[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int d = c * 8 + u;
             const bf16_t val = (bf16_t)((u & 1) ? (w4[u >> 1] >> 16) : (w4[u >> 1] & 0xffffu));
-            *(bf16_t *)(vt_s + d * 256 + ((((j >> 3) ^ d) & 15) << 4) + (j & 7) * 2) = val;
+            *(bf16_t *)(vt_s + d * 256 + ((((j >> 3) ^ d ^ (d >> 4)) & 15) << 4) + (j & 7) * 2) = val;
         }
     }
     __syncthreads();
     // ---- phase 1: 6 key tiles + 7 relative-position tiles on the MFMA -------------------------------
-    for (int t = wave; t < 13; t += 4) {
-        const bool isk = t < 6;
-        const bf16_t *arow;
-        if (isk) {
-            int j = t * 16 + r;
-            if (j >= span) j = span - 1;
-            int ring = head0 + j;
-            if (ring >= KVC) ring -= KVC;
-            arow = kbase + (size_t)ring * D;
-        } else {
-            int rr = (t - 6) * 16 + r;
-            if (rr >= n_rel) rr = n_rel - 1;
-            arow = pbase + (size_t)rr * D;
-        }
-        const char *bq = isk ? qu_s : qv_s;
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        uint4 av[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) av[ks] = *(const uint4 *)(arow + ks * 32 + q * 8);
+    for (int n = 0; n < 4; n++) {
+        const int t = wave + 4 * n;
+        if (t < 13) {
+            const bool isk = t < 6;
+            const char *bq = isk ? qu_s : qv_s;
+            f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const uint4 bv = *(const uint4 *)(bq + r * 256 + ((((ks << 2) | q) ^ r) << 4));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[ks]), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+            for (int ks = 0; ks < 4; ks++) {
+                const uint4 bv = *(const uint4 *)(bq + r * 256 + ((((ks << 2) | q) ^ r) << 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av[n][ks]), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+            }
+            // D[j][i]: lane holds query i = r, rows 4q + reg
+            float *dst = isk ? sk + r * SKP + t * 16 + q * 4 : sp + r * SPP + (t - 6) * 16 + q * 4;
+            *(float4 *)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        // D[j][i]: lane holds query i = r, rows 4q + reg
-        float *dst = isk ? sk + r * 96 + t * 16 + q * 4 : sp + r * 112 + (t - 6) * 16 + q * 4;
-        *(float4 *)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
     // ---- phase 2: rel-shift gather + mask + softmax -> bf16 weights over the span (zero outside the row's window) ----
@@ -266,8 +295,8 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         const int j0 = lane - wo, j1 = lane + 64 - wo;           // window index of span positions lane, lane + 64
         const bool in0 = i < nrows && j0 >= 0 && j0 < KV, in1 = i < nrows && j1 >= 0 && j1 < KV;
         float v0 = -INFINITY, v1 = -INFINITY;
-        if (in0) { v0 = (sk[i * 96 + lane] + sp[i * 112 + j0 + T - 1 - ic]) * scale; if (j0 < mask_upto) v0 += -1e9f; }
-        if (in1) { v1 = (sk[i * 96 + lane + 64] + sp[i * 112 + j1 + T - 1 - ic]) * scale; if (j1 < mask_upto) v1 += -1e9f; }
+        if (in0) { v0 = (sk[i * SKP + lane] + sp[i * SPP + j0 + T - 1 - ic]) * scale; if (j0 < mask_upto) v0 += -1e9f; }
+        if (in1) { v1 = (sk[i * SKP + lane + 64] + sp[i * SPP + j1 + T - 1 - ic]) * scale; if (j1 < mask_upto) v1 += -1e9f; }
         const float mx = wave_max(fmaxf(v0, v1));
         const float e0 = in0 ? __expf(v0 - mx) : 0.0f;
         const float e1 = in1 ? __expf(v1 - mx) : 0.0f;
@@ -284,7 +313,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
             const int d = dt * 16 + r;
-            const uint4 av = *(const uint4 *)(vt_s + d * 256 + (((((ks << 2) | q) ^ d) & 15) << 4));
+            const uint4 av = *(const uint4 *)(vt_s + d * 256 + (((((ks << 2) | q) ^ d ^ (d >> 4)) & 15) << 4));
             const uint4 bv = *(const uint4 *)(w_s + r * 256 + (((((ks << 2) | q) ^ r) & 15) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
         }

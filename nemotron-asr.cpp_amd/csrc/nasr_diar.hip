@@ -396,6 +396,46 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     return 0;
 }
 
+// parity tap: diarize_compute_logmel (src/diarize_audio.cpp:136-227) of ONE whole buffer on the device front end --
+// what tests/test_diarize_preproc.cpp checks against the NeMo fixture.  Row-major [80][t_padded] like the reference.
+extern "C" int nasr_diar_logmel(nasr_diar *d, int which, const float *audio, int32_t n_samples, int per_feature_normalize,
+                                float *mel_out, int64_t cap, int32_t *t_valid_out) {
+    Guard g;
+    if (!d || !audio || n_samples < HOP) return failf("null argument or fewer than %d samples", HOP);
+    const bool spk = which != 0;
+    if (spk ? !d->has_spk : !d->has_vad) return failf("this diarization engine was created without '%s.*' tensors", spk ? "spk" : "vad");
+    DCHK(hipSetDevice(d->device));
+    const int t_valid = n_samples / HOP, t_pad = (t_valid + 15) / 16 * 16;
+    if (t_valid_out) *t_valid_out = t_valid;
+    if (!mel_out || cap < (int64_t)DIAR_NMEL * t_pad) return failf("mel_out holds %lld floats, need %lld", (long long)cap, (long long)DIAR_NMEL * t_pad);
+    std::vector<long long> base;
+    if (stage_audio(d, &audio, &n_samples, 1, 0, base)) return -1;
+    float *mel = nullptr;
+    long long *off = nullptr;
+    DCHK(hipMalloc((void **)&mel, (size_t)t_pad * DIAR_NMEL * sizeof(float)));
+    if (hipMalloc((void **)&off, sizeof(long long)) != hipSuccess) { hipFree(mel); return failf("hipMalloc failed"); }
+    const long long zero = 0;
+    DiarMelParams mp;
+    memset(&mp, 0, sizeof(mp));
+    set_audio(d, 0, mp);
+    mp.win_off = off; mp.n_win = n_samples; mp.T_pad = t_pad; mp.t_valid = t_valid; mp.cpitch = DIAR_NMEL; mp.mel = mel;
+    mp.window = d->window; mp.fbT = spk ? d->spk_fbT : d->vad_fbT; mp.fb_band = spk ? d->spk_band : d->vad_band;
+    mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+    std::vector<float> h((size_t)t_pad * DIAR_NMEL);
+    hipError_t e1 = hipMemcpyAsync(off, &zero, sizeof(zero), hipMemcpyHostToDevice, d->st);
+    if (e1 == hipSuccess) {
+        launch_diar_logmel(mp, 1, per_feature_normalize != 0, d->st);
+        e1 = hipMemcpyAsync(h.data(), mel, h.size() * sizeof(float), hipMemcpyDeviceToHost, d->st);
+    }
+    const hipError_t e2 = hipStreamSynchronize(d->st);
+    hipFree(mel);
+    hipFree(off);
+    if (e1 != hipSuccess || e2 != hipSuccess) return failf("nasr_diar_logmel: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    for (int t = 0; t < t_pad; t++)
+        for (int m = 0; m < DIAR_NMEL; m++) mel_out[(size_t)m * t_pad + t] = h[(size_t)t * DIAR_NMEL + m];
+    return 0;
+}
+
 // pointwise conv weights [cout][cin] with the folded BN scale multiplied in, K padded to a multiple of 32, in the GEMM's
 // layout (packed bf16 tiles or f32 row-major)
 static int upload_gemm_weight(nasr_diar *d, const std::vector<float> &w, const std::vector<float> *scale, int cout, int cin, int cin_pad, void **out) {

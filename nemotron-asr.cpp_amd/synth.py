@@ -366,6 +366,31 @@ def mel_filterbank_n(n_mels: int) -> np.ndarray:
     return fb.astype(np.float32)
 
 
+def slaney_filterbank(n_mels: int = 80, fmax: float = SAMPLE_RATE / 2) -> np.ndarray:
+    """The filterbank NeMo's featurizer really holds (`featurizer.fb` of a converted checkpoint):
+    librosa.filters.mel(sr=16000, n_fft=512, n_mels, fmin=0, fmax, htk=False, norm='slaney') -- linear below 1 kHz,
+    logarithmic above, area-normalised triangles.  With it the NeMo-generated fixtures the reference commits
+    (tests/diarize/{vad,spk}_ref/{input_audio,mel}.f32) pin the 80-mel front end without any checkpoint."""
+    f_sp, min_log_hz, logstep = 200.0 / 3.0, 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz2mel(f):
+        f = np.asarray(f, np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+    def mel2hz(m):
+        m = np.asarray(m, np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    freqs = np.linspace(0.0, SAMPLE_RATE / 2, N_BINS)
+    pts = mel2hz(np.linspace(hz2mel(0.0), hz2mel(fmax), n_mels + 2))
+    fb = np.zeros((n_mels, N_BINS), dtype=np.float64)
+    for m in range(n_mels):
+        lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
+        fb[m] = np.maximum(0.0, np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce))) * (2.0 / (hi - lo))
+    return fb.astype(np.float32)
+
+
 def _bn(seed, prefix, C, w):
     w[prefix + ".weight"] = _tensor(seed, prefix + ".weight", (C,), 0.05, center=1.0)
     w[prefix + ".bias"] = _tensor(seed, prefix + ".bias", (C,), 0.05)

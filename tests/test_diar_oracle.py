@@ -12,6 +12,7 @@ from oracle import binding as ob
 from oracle import diar_binding as db
 
 GOLD = Path(__file__).parent / "golden" / "diar_golden_v1.npz"
+NEMO = Path(__file__).parent / "golden" / "nemo_diar_v1.npz"     # NeMo-generated fixtures the reference's tests hold
 
 
 def _audio(seed, n):
@@ -48,6 +49,19 @@ def test_logmel_matches_compiled_reference(W, n, norm):
     ref, tvr = db.ref_logmel(a, fb, win, norm)
     assert mel.shape == ref.shape and tv == tvr
     assert np.abs(mel - ref).max() < (2e-3 if norm else 2e-5)
+
+
+@pytest.mark.parametrize("which,norm", [("vad_ref", False), ("spk_ref", True)])
+def test_logmel_matches_nemo_fixture(which, norm):
+    """The reference's own check of this stage (tests/test_diarize_preproc.cpp: max_abs < 1e-3 against the PyTorch
+    fixture), with NeMo's filterbank rebuilt from its definition (librosa Slaney) instead of read from diarize.gguf:
+    83 200 samples without normalisation (MarbleNet) and 24 000 with per-feature normalisation (TitaNet)."""
+    g = np.load(NEMO)
+    audio, ref = g[f"{which}_audio"], g[f"{which}_mel"]
+    mel, tv = db.logmel(audio, synth.slaney_filterbank(80), synth.hann_window(), norm)
+    assert mel.shape == ref.shape and tv == audio.size // 160
+    assert np.abs(mel[:, :tv] - ref[:, :tv]).max() < 2e-4          # measured 7e-5; the reference accepts 1e-3
+    assert (mel[:, tv:] == 0).all() and (ref[:, tv:] == 0).all()
 
 
 def test_vad_window_properties(model):

@@ -74,6 +74,24 @@ def test_s16_device_resident_audio_equals_float_host_audio(Wv):
     asr.close()
 
 
+@pytest.mark.parametrize("which,norm", [("vad_ref", False), ("spk_ref", True)])
+def test_front_end_matches_nemo_fixture(which, norm):
+    """The device front end against the NeMo-generated fixtures of the reference's tests/diarize/ (the check of
+    tests/test_diarize_preproc.cpp, threshold 1e-3), with NeMo's Slaney filterbank in place of the synthetic one."""
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / "golden" / "nemo_diar_v1.npz")
+    ns = which[:3]
+    W = synth.make_diar_weights(vad=ns == "vad", spk=ns == "spk")
+    W[f"{ns}.preprocessor.featurizer.fb"] = synth.slaney_filterbank(80)
+    eng = capi.Diar(W, dtype=capi.DTYPE_F32, max_segments=1)
+    audio, ref = g[f"{which}_audio"], g[f"{which}_mel"]
+    mel, tv = eng.logmel(audio, ns, norm)
+    assert mel.shape == ref.shape and tv == audio.size // 160
+    assert np.abs(mel[:, :tv] - ref[:, :tv]).max() < 2e-4
+    assert (mel[:, tv:] == 0).all()
+    eng.close()
+
+
 def test_vad_errors(Wv):
     eng = capi.Diar(Wv)
     with pytest.raises(capi.NasrError):
