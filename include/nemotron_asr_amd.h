@@ -186,8 +186,9 @@ int nasr_engine_synchronize(nasr_engine *e);
 /* ---- diarization side-car (BASELINE config 5): MarbleNet VAD + TitaNet-L speaker embeddings ----------------------
  * Replaces the compute of vad_session / spk_session (src/diarize_vad.h:95-135, src/diarize_spk.h:95-120).  weights =
  * the tensors of diarize.gguf ("vad.*" and/or "spk.*", F32, layouts of scripts/convert_diarize_to_gguf.py:129-158),
- * same descriptor type as nasr_engine_create.  Not in scope: the onset/offset state machine, sub-segment cursor,
- * clustering and RTTM output of src/diarize_pipeline.cpp / src/diarize_cluster.cpp (host control flow). */
+ * same descriptor type as nasr_engine_create.  The onset/offset state machine, sub-segment cursor, NME-SC clustering and
+ * RTTM output of src/diarize_pipeline.cpp / src/diarize_cluster.cpp are host control flow ABOVE this ABI:
+ * nemotron-asr.cpp_amd/host/diarize_pipeline_amd.h, diarize_cluster_amd.h. */
 typedef struct nasr_diar nasr_diar;
 /* dtype: NASR_DTYPE_BF16 = TitaNet's pointwise convolutions on the bf16 MFMA (f32 accumulate), NASR_DTYPE_F32 = all f32;
  * MarbleNet is always f32.  max_windows / max_segments size the scratch (larger calls are tiled). */

@@ -1,6 +1,6 @@
 // diarize_amd.h -- host side of the diarization side-car over libnemotron_asr_amd.so: the part of the reference's
 // vad_session / spk_session API (src/diarize_vad.h:95-146, src/diarize_spk.h:95-120) that sits on the compute, plus the
-// segment extraction of src/diarize_vad.cpp:507-563.  Clustering and RTTM output are out of scope.
+// segment extraction of src/diarize_vad.cpp:507-563.  The pipeline above them: diarize_pipeline_amd.h, diarize_cluster_amd.h.
 #pragma once
 #include <string>
 #include <vector>

@@ -274,3 +274,143 @@ def test_diarize_cli_end_to_end(tmp_path):
     assert len(emb) == len(starts) and len(emb[0]) == 192
     ref = np.stack([om.spk_embed(a[s:s + 24000]) for s in starts])
     assert np.abs(np.array(emb) - ref).max() < 2e-3 * np.abs(ref).max()
+
+
+def _pipeline_restatement(probs, total, onset, offset, min_off=60, shift=12000, window=24000, min_seg=8000):
+    """The reference's try_advance / finalize_open_segment (src/diarize_pipeline.cpp:198-263, :341-363) fed one sample at a
+    time: when VAD frame f is evaluated the audio reaches the end of its window, f * 160 + 10080."""
+    segs, subs = [], []
+    in_speech, off_run, start_f, k, seg_id, next_id = False, 0, -1, 0, -1, 0
+
+    def tail(seg_end, at_eof):
+        nonlocal k
+        seg_start = start_f * 160
+        covered = seg_start + ((k - 1) * shift + window if k > 0 else 0)
+        left = seg_end - covered
+        if left >= min_seg and (k > 0 or at_eof):
+            subs.append((seg_id, covered, min(left, 24000))); k += 1
+        elif k == 0 and seg_end - seg_start >= min_seg:
+            subs.append((seg_id, seg_start, min(seg_end - seg_start, 24000))); k += 1
+
+    for f, p in enumerate(probs):
+        if not in_speech:
+            if p >= onset:
+                in_speech, seg_id, start_f, k, off_run = True, next_id, f, 0, 0
+                next_id += 1
+        elif p < offset:
+            off_run += 1
+            if off_run >= min_off:
+                end_f = max(f + 1 - off_run, start_f)
+                tail(end_f * 160, False)
+                segs.append((start_f, end_f))
+                in_speech, off_run = False, 0
+        else:
+            off_run = 0
+        if in_speech:
+            while start_f * 160 + k * shift + window <= f * 160 + 10080:
+                subs.append((seg_id, start_f * 160 + k * shift, window)); k += 1
+    if in_speech:
+        tail(min(len(probs) * 160, total), True)
+        segs.append((start_f, len(probs)))
+    return segs, subs
+
+
+@pytest.mark.gpu
+def test_diarize_pipeline_segments_subsegments_clusters_rttm(tmp_path):
+    """The whole side-car pipeline (host/diarize_pipeline_amd.cpp) through `diarize-amd --rttm`: batched VAD -> onset / offset
+    state machine -> 1.5 s sub-segments -> batched embeddings -> NME-SC -> RTTM.  Segments and sub-segments equal a
+    restatement of the reference's frame-by-frame loop; the result does not depend on the push size; the RTTM spans are
+    the merged speaker timeline of the labelled sub-segments."""
+    from nemotron_asr_amd import capi
+    W = synth.make_diar_weights()
+    model = tmp_path / "diarize.gguf"
+    gguf_io.write_gguf(model, W, {}, [], name="nemo-diarize-synthetic")
+    sr = 16000
+    parts = [(0.9, None), (3.4, 5), (1.3, None), (0.8, 6), (1.0, None), (4.1, 7), (0.9, None), (0.3, 5), (1.2, None), (2.2, 6)]
+    pcm = np.concatenate([np.zeros(int(d * sr), np.int16) if s is None else synth.make_pcm(s, d + 0.01)[:int(d * sr)] for d, s in parts])
+    audio = tmp_path / "d.pcm"
+    pcm.tofile(audio)
+    eng = capi.Diar(W, dtype=capi.DTYPE_F32)
+    probs = eng.vad([pcm.astype(np.float32) / 32768.0])[0]
+    eng.close()
+    lo, hi = np.percentile(probs, 30), np.percentile(probs, 70)
+    onset, offset = float(lo + 0.6 * (hi - lo)), float(lo + 0.4 * (hi - lo))
+    want_segs, want_subs = _pipeline_restatement(probs, pcm.size, np.float32(onset), np.float32(offset))
+    assert len(want_subs) >= 4, "test audio should produce several sub-segments"
+    cli = BIN / "diarize-amd"
+    outs = []
+    for extra in ([], ["--push-ms", "89"], ["--push-ms", "1000"]):
+        rttm = tmp_path / f"o{len(outs)}.rttm"
+        r = subprocess.run([str(cli), str(model), str(audio), "--f32", "--onset", repr(onset), "--offset", repr(offset), "--rttm", str(rttm),
+                            "--num-speakers", "2"] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append((r.stdout, rttm.read_text()))
+    assert outs[0] == outs[1] == outs[2]                                  # push-size independence
+    lines = outs[0][0].splitlines()
+    assert lines[0] == f"WINDOWS {probs.size}"
+    segs = [tuple(float(x) for x in ln.split()[1:3]) for ln in lines if ln.startswith("SEGMENT")]
+    assert len(segs) == len(want_segs)
+    assert np.abs(np.array(segs) - np.array(want_segs) * 0.01).max() < 0.006
+    subs = [ln.split() for ln in lines if ln.startswith("SUBSEG")]
+    got_subs = [(int(s[4]), float(s[1]), float(s[2])) for s in subs]
+    assert len(got_subs) == len(want_subs)
+    for (gid, gs, ge), (wid, ws, wl) in zip(got_subs, want_subs):
+        assert gid == wid and abs(gs - ws / sr) < 1e-3 and abs(ge - (ws + wl) / sr) < 1e-3
+    labels = [int(s[6]) for s in subs]
+    assert set(labels) <= {0, 1} and len(set(labels)) == 2               # --num-speakers 2
+    # RTTM = the speaker timeline (src/diarize_pipeline.cpp:371-420): same speaker touching -> one span, else cut at the midpoint
+    spans = []
+    for (_, s, e), lab in sorted(zip(got_subs, labels), key=lambda t: t[0][1]):
+        if spans and spans[-1][2] == lab and s <= spans[-1][1] + 1e-3:
+            spans[-1][1] = max(spans[-1][1], e)
+            continue
+        if spans and s < spans[-1][1]:
+            mid = 0.5 * (s + spans[-1][1])
+            spans[-1][1] = mid
+            s = mid
+        spans.append([s, e, lab])
+    rt = [ln.split() for ln in outs[0][1].splitlines()]
+    assert len(rt) == len(spans) and all(r[0] == "SPEAKER" and r[1] == "session" and r[2] == "1" for r in rt)
+    for r, (s, e, lab) in zip(rt, spans):
+        assert abs(float(r[3]) - s) < 2e-3 and abs(float(r[4]) - (e - s)) < 2e-3 and r[7] == f"spk_{lab}"
+
+
+@pytest.mark.gpu
+def test_asr_cli_with_diarization(tmp_path):
+    """`nemotron-asr-amd ... --diarize diarize.gguf --rttm F --json F` (reference src/transcribe_stream.cpp:146-170, :243-290):
+    the transcript is unchanged, every word is tagged with a speaker by its emission time, RTTM and per-word JSON are written."""
+    from nemotron_asr_amd import capi
+    n_layers = 2
+    W = synth.make_weights(n_layers=n_layers)
+    vocab = gguf_io.synthetic_vocab()
+    model = tmp_path / "model.gguf"
+    gguf_io.write_gguf(model, W, gguf_io.default_hparams(n_layers=n_layers), vocab)
+    dW = synth.make_diar_weights()
+    dmodel = tmp_path / "diarize.gguf"
+    gguf_io.write_gguf(dmodel, dW, {}, [], name="nemo-diarize-synthetic")
+    pcm = np.concatenate([synth.make_pcm(2, 6.0), np.zeros(16000, np.int16), synth.make_pcm(3, 5.0)])
+    audio = tmp_path / "a.pcm"
+    pcm.tofile(audio)
+    eng = capi.Diar(dW, dtype=capi.DTYPE_F32)
+    probs = eng.vad([pcm.astype(np.float32) / 32768.0])[0]
+    eng.close()
+    onset = float(np.percentile(probs, 40))
+    cli = BIN / "nemotron-asr-amd"
+    plain = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32"], capture_output=True, text=True, timeout=180)
+    assert plain.returncode == 0, plain.stderr
+    rttm, js = tmp_path / "o.rttm", tmp_path / "o.jsonl"
+    r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--diarize", str(dmodel), "--rttm", str(rttm), "--json", str(js),
+                        "--num-speakers", "2", "--vad-onset", repr(onset), "--vad-offset", repr(onset)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == plain.stdout.splitlines()[0] and len(lines[0].split()) > 3        # same transcript
+    tagged = [ln for ln in lines[1:] if ln.startswith("[spk_")]
+    assert tagged and "Speaker-tagged transcript" in r.stderr and "Finalizing diarization" in r.stderr
+    words = [w for ln in tagged for w in ln.split()[1:]]
+    assert words == lines[0].split()                                                   # every word once, in order
+    assert all(ln.split()[0] in ("[spk_0]", "[spk_1]", "[spk_-1]") for ln in tagged)
+    spans = [ln.split() for ln in rttm.read_text().splitlines()]
+    assert spans and all(s[0] == "SPEAKER" and s[7] in ("spk_0", "spk_1") and float(s[4]) > 0 for s in spans)
+    recs = [json.loads(ln) for ln in js.read_text().splitlines()]
+    assert [rec["word"] for rec in recs] == words and all(0 < rec["at"] <= pcm.size / 16000 + 0.1 for rec in recs)
+    assert recs == sorted(recs, key=lambda rec: rec["at"])
