@@ -164,7 +164,12 @@ enum {
     NASR_TAP_DEC_STATE   = 7, /* h[2][640], c[2][640], then prev_token as float                */
 };
 /* engine options: "fused" (1: small-M fused layer kernels, default) / "graph" (1: hipGraph replay of the
- * steady-state step, default).  Both are pure performance switches; results are unchanged. */
+ * steady-state step, default) / "multichunk" (1, default) are pure performance switches; results are unchanged.
+ * "pipeline" (0, default): with 1, a graph step is split into an encoder graph and a decode graph; the decode graph of
+ * step s runs on a second HIP stream beside the encoder graph of step s + 1.  The same tokens come out, one call later:
+ * nasr_engine_step returns what has been decoded so far (the previous step's tokens); nasr_engine_finalize,
+ * nasr_engine_collect and every other entry point first complete the step in flight.  Throughput option for callers
+ * that push back to back (a server draining a backlog, a file); a live stream keeps the default. */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);

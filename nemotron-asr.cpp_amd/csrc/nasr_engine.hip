@@ -98,6 +98,7 @@ struct nasr_stream {
     int64_t samples_in;
     int last_T, last_row;            // rows of the last chunk (for taps)
     bool alive;
+    std::vector<int32_t> tok_queue;  // tokens gathered from the device, not yet handed to the caller
 };
 
 struct nasr_engine {
@@ -132,6 +133,26 @@ struct nasr_engine {
     char *gh = nullptr;                                                               // pinned host block
     int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active
     int64_t graph_replays = 0, eager_steps = 0, decode_fallbacks = 0, decode_fallback_rounds = 0;
+    // pipelined graph steps (option "pipeline"): the decode graph of step s runs on st2 beside the encoder graph of step
+    // s + 1; buffers the two graphs hand over exist twice (parity = step & 1)
+    bool opt_pipeline = false;
+    hipStream_t st2 = nullptr;
+    struct Pipe {
+        char *g_desc = nullptr, *gh = nullptr;            // descriptor block of the encoder graph (device / pinned)
+        int *gh_collect = nullptr, *collect_dev = nullptr;
+        int *g_dmeta = nullptr, *gh_dmeta = nullptr;      // k_collect meta of the decode graph [2 B] (device / pinned)
+        float *encproj = nullptr;                         // [w_rows][640]: encoder graph -> decode graph
+        hipEvent_t enc_done = nullptr, dec_done = nullptr;
+        std::map<int64_t, hipGraphExec_t> enc_graphs, dec_graphs;
+        bool pending = false;                             // a decode graph of this parity is in flight / not yet consumed
+        std::vector<nasr_stream *> streams;
+        int T = 0, G = 0;
+        int64_t key = 0;
+    } pipe[2];
+    int pipe_parity = 0;
+    bool pipe_ready = false;
+    size_t desc_bytes = 0, col_bytes = 0;
+    int64_t pipe_steps = 0;
     void *a, *hbuf, *ctx, *cbuf, *sub_b;
     float *predg;                    // [slot][640] cached joint.pred output of the LSTM candidate
     unsigned long long *key;
@@ -624,6 +645,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     {
         const size_t desc_bytes = S * (sizeof(RowDesc) + sizeof(PcmDesc) + 2 * sizeof(int)) + M * sizeof(RowDesc) + 64;
         const size_t col_bytes = (S * (1 + COLLECT_STRIDE) + 4) * sizeof(int);
+        e->desc_bytes = desc_bytes; e->col_bytes = col_bytes;
         if (hipHostMalloc((void **)&e->gh, desc_bytes + col_bytes, hipHostMallocDefault) != hipSuccess) { engine_destroy_impl(e); return fail("hipHostMalloc failed"); }
         e->gh_collect = (int *)(e->gh + desc_bytes);
         if (dalloc(e, &e->g_desc, desc_bytes)) { engine_destroy_impl(e); return -1; }
@@ -661,11 +683,22 @@ static void engine_destroy_impl(nasr_engine *e) {
     hipSetDevice(e->device);
     if (e->st) hipStreamSynchronize(e->st);
     if (getenv("NASR_STATS"))
-        fprintf(stderr, "nasr: graph replays %lld, eager steps %lld, decode fallbacks %lld (%lld rounds)\n", (long long)e->graph_replays,
-                (long long)e->eager_steps, (long long)e->decode_fallbacks, (long long)e->decode_fallback_rounds);
+        fprintf(stderr, "nasr: graph replays %lld (%lld pipelined), eager steps %lld, decode fallbacks %lld (%lld rounds)\n", (long long)e->graph_replays,
+                (long long)e->pipe_steps, (long long)e->eager_steps, (long long)e->decode_fallbacks, (long long)e->decode_fallback_rounds);
     for (auto *s : e->slots) delete s;
     for (void *p : e->allocs) hipFree(p);
     for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
+    if (e->st2) hipStreamSynchronize(e->st2);
+    for (int p = 0; p < 2; p++) {
+        nasr_engine::Pipe &P = e->pipe[p];
+        for (auto &kv : P.enc_graphs) hipGraphExecDestroy(kv.second);
+        for (auto &kv : P.dec_graphs) hipGraphExecDestroy(kv.second);
+        if (P.gh_dmeta) hipHostFree(P.gh_dmeta);
+        if (p == 1 && P.gh) hipHostFree(P.gh);           // parity 0 shares the engine's own block
+        if (P.enc_done) hipEventDestroy(P.enc_done);
+        if (P.dec_done) hipEventDestroy(P.dec_done);
+    }
+    if (e->st2) hipStreamDestroy(e->st2);
     if (e->gh) hipHostFree(e->gh);
     if (e->pin) hipHostFree(e->pin);
     if (e->ddesc) hipFree(e->ddesc);
@@ -699,6 +732,8 @@ static int stage_desc(nasr_engine *e, const std::vector<Tp> &host, const Tp **de
     *dev_out = (const Tp *)dp;
     return 0;
 }
+
+static int pipe_drain(nasr_engine *e);     // completes a pipelined step that is still in flight (defined with the graph steps)
 
 // ---- streams ------------------------------------------------------------------------------------
 static int stream_zero_state(nasr_stream *s) {
@@ -761,6 +796,8 @@ extern "C" int nasr_stream_reset(nasr_stream *s) {
     ApiGuard api_guard;
     if (!s) return fail("null stream");
     HIPCHK(hipSetDevice(s->e->device));
+    if (pipe_drain(s->e)) return -1;
+    s->tok_queue.clear();
     // NOTE: the reference's reset leaves stale conv-cache/K/V contents in place
     // (src/nemo-stream.cpp:95-115); here a reset stream == a fresh stream.
     return stream_zero_state(s);
@@ -771,6 +808,7 @@ extern "C" int nasr_stream_destroy(nasr_stream *s) {
     if (!s) return 0;
     nasr_engine *e = s->e;
     hipSetDevice(e->device);
+    pipe_drain(e);
     hipStreamSynchronize(e->st);
     e->slots[s->slot] = nullptr;
     delete s;
@@ -1110,10 +1148,10 @@ static void make_dec_params(nasr_engine *e, const RowDesc *rows, int B, int T, D
     dp.dlist = e->dlist; dp.rowmap = e->rowmap; dp.tok_ring = e->tok_ring; dp.tok_frame = e->tok_frame;
 }
 
-static void enqueue_decode_iters(nasr_engine *e, const DecParams &dp, int B, int n, int &it) {
+static void enqueue_decode_iters(nasr_engine *e, const DecParams &dp, int B, int n, int &it, hipStream_t st = nullptr) {
     ProfScope ps(e, "k_dec_iter", (double)n * (4.0 * 4 * HID * HID * 4 + (double)JNT * HID * 4 + (double)VOCAB * JNT * 4),
                  (double)n * 2.0 * B * (4.0 * 4 * HID * HID + JNT * HID + VOCAB * JNT));
-    for (int k = 0; k < n; k++) launch_decode_iter(dp, it++, e->st);
+    for (int k = 0; k < n; k++) launch_decode_iter(dp, it++, st ? st : e->st);
 }
 
 // host mirror of the stream manager bookkeeping after a chunk (:1085, :1189-1195)
@@ -1202,11 +1240,42 @@ __global__ void k_collect(const int *slots, const int *tok_read, int B, const De
         out[(size_t)b * (1 + stride) + 1 + i] = tok_ring[(size_t)slot * TOK_CAP + ((rd + i) & (TOK_CAP - 1))];
 }
 
-static int consume_collect(nasr_engine *e, const int *host, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
-                           const int32_t *tokens_cap, int32_t *n_tokens);
+// Tokens gathered from the device go to the stream's host queue; every token-returning entry point ends with deliver().
+static int consume_collect(nasr_engine *e, const int *host, nasr_stream *const *streams, int B) {
+    for (int b = 0; b < B; b++) {
+        const int *rec = &host[(size_t)b * (1 + COLLECT_STRIDE)];
+        const int n_new = rec[0];
+        if (n_new < 0 || n_new > TOK_CAP) return fail("token ring overrun on stream %d (%d new tokens)", b, n_new);
+        std::vector<int32_t> &q = streams[b]->tok_queue;
+        if (n_new <= COLLECT_STRIDE) {
+            q.insert(q.end(), rec + 1, rec + 1 + n_new);
+        } else {   // rare long push: fetch straight from the ring
+            std::vector<int> ring(TOK_CAP);
+            HIPCHK(hipMemcpy(ring.data(), e->tok_ring + (size_t)streams[b]->slot * TOK_CAP, TOK_CAP * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n_new; i++) q.push_back(ring[(streams[b]->tok_read + i) & (TOK_CAP - 1)]);
+        }
+        streams[b]->tok_read += n_new;
+    }
+    return 0;
+}
+
+// hands the queued tokens of the B streams to the caller (at most tokens_cap[b]; the count is the true count)
+static void deliver(nasr_stream *const *streams, int B, int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
+    for (int b = 0; b < B; b++) {
+        std::vector<int32_t> &q = streams[b]->tok_queue;
+        const int cap = tokens_out && tokens_out[b] && tokens_cap ? tokens_cap[b] : 0;
+        const int n_copy = std::min((int)q.size(), cap);
+        for (int i = 0; i < n_copy; i++) tokens_out[b][i] = q[(size_t)i];
+        if (n_tokens) n_tokens[b] = (int32_t)q.size();
+        q.clear();
+    }
+}
+
+static int pipe_drain(nasr_engine *e);
 
 static int collect_tokens(nasr_engine *e, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
                           const int32_t *tokens_cap, int32_t *n_tokens) {
+    if (pipe_drain(e)) return -1;
     std::vector<int> meta(2 * (size_t)B);
     for (int b = 0; b < B; b++) { meta[b] = streams[b]->slot; meta[B + b] = streams[b]->tok_read; }
     const int *dmeta;
@@ -1215,27 +1284,8 @@ static int collect_tokens(nasr_engine *e, nasr_stream *const *streams, int B, in
     std::vector<int> host((size_t)B * (1 + COLLECT_STRIDE));
     HIPCHK(hipMemcpyAsync(host.data(), e->collect_dev, host.size() * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
-    return consume_collect(e, host.data(), streams, B, tokens_out, tokens_cap, n_tokens);
-}
-
-static int consume_collect(nasr_engine *e, const int *host, nasr_stream *const *streams, int B, int32_t *const *tokens_out,
-                           const int32_t *tokens_cap, int32_t *n_tokens) {
-    for (int b = 0; b < B; b++) {
-        const int *rec = &host[(size_t)b * (1 + COLLECT_STRIDE)];
-        const int n_new = rec[0];
-        if (n_new < 0 || n_new > TOK_CAP) return fail("token ring overrun on stream %d (%d new tokens)", b, n_new);
-        const int cap = tokens_out && tokens_out[b] && tokens_cap ? tokens_cap[b] : 0;
-        const int n_copy = std::min(n_new, cap);
-        if (n_new <= COLLECT_STRIDE) {
-            for (int i = 0; i < n_copy; i++) tokens_out[b][i] = rec[1 + i];
-        } else if (n_copy > 0) {   // rare long push: fetch straight from the ring
-            std::vector<int> ring(TOK_CAP);
-            HIPCHK(hipMemcpy(ring.data(), e->tok_ring + (size_t)streams[b]->slot * TOK_CAP, TOK_CAP * 4, hipMemcpyDeviceToHost));
-            for (int i = 0; i < n_copy; i++) tokens_out[b][i] = ring[(streams[b]->tok_read + i) & (TOK_CAP - 1)];
-        }
-        if (n_tokens) n_tokens[b] = n_new;
-        streams[b]->tok_read += n_new;
-    }
+    if (consume_collect(e, host.data(), streams, B)) return -1;
+    deliver(streams, B, tokens_out, tokens_cap, n_tokens);
     return 0;
 }
 
@@ -1255,6 +1305,12 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     if (!strcmp(key, "fused")) e->opt_fused = value != 0;
     else if (!strcmp(key, "graph")) e->opt_graph = value != 0;
     else if (!strcmp(key, "multichunk")) e->opt_multichunk = value != 0;
+    else if (!strcmp(key, "pipeline")) {
+        ApiGuard api_guard;
+        HIPCHK(hipSetDevice(e->device));
+        if (pipe_drain(e)) return -1;
+        e->opt_pipeline = value != 0;
+    }
     else return fail("unknown option '%s'", key);
     return 0;
 }
@@ -1263,6 +1319,7 @@ extern "C" int nasr_engine_set_debug(nasr_engine *e, int enable) {
     ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     if (enable && ensure_debug_buffers(e)) return -1;
     e->debug = enable != 0;
     return 0;
@@ -1322,6 +1379,206 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraph
     return 0;
 }
 
+// ---- pipelined graph steps (engine option "pipeline") ------------------------------------------------------------------
+// A step is two graphs: the encoder graph (descriptors, front end, subsampling, layers, joint.enc projection) on the
+// engine's stream and the decode graph (begin, iterations, token gather, D2H) on a second stream.  The decode graph of
+// step s is launched when the encoder graph of step s has finished and runs BESIDE the encoder graph of step s + 1, which
+// the host has already launched: at batch 1 the decode tail (12 dependent launches), the read-back and the host turn-around (together ~7 % of a
+// step) leave the critical path.  The price is one step of token latency at this synchronous interface: the call of step s
+// returns the tokens of step s - 1; finalize / collect / any other entry point first completes what is in flight.
+// Two independent launch chains share the chip almost for free (tests/micro/overlap_probe.py: the 24-layer chain slows by
+// 10 % beside a second chain that is busy ALL the time; the decode graph is busy 5 % of it).
+static int pipe_blind_iterations(int frames) {
+    // off the critical path an idle iteration is free: give one frame its worst case (10 symbols + the closing blank)
+    const int worst = frames * MAX_SYMBOLS + 1;
+    static const int cap = getenv("NASR_PIPE_ITERS") ? atoi(getenv("NASR_PIPE_ITERS")) : 12;
+    return std::max(decode_blind_iterations(frames), std::min(worst, cap));
+}
+
+static int ensure_pipe(nasr_engine *e) {
+    if (e->pipe_ready) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+    const size_t S = (size_t)e->max_streams, M = (size_t)e->w_rows;
+    for (int p = 0; p < 2; p++) {
+        nasr_engine::Pipe &P = e->pipe[p];
+        HIPCHK(hipEventCreateWithFlags(&P.enc_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&P.dec_done, hipEventDisableTiming));
+        if (p == 0) {
+            P.g_desc = e->g_desc; P.gh = e->gh; P.gh_collect = e->gh_collect; P.collect_dev = e->collect_dev; P.encproj = e->encproj;
+        } else {
+            HIPCHK(hipHostMalloc((void **)&P.gh, e->desc_bytes + e->col_bytes, hipHostMallocDefault));
+            P.gh_collect = (int *)(P.gh + e->desc_bytes);
+            if (dalloc(e, &P.g_desc, e->desc_bytes) || dalloc(e, &P.collect_dev, S * (1 + COLLECT_STRIDE) + 4) || dalloc(e, &P.encproj, M * JNT)) return -1;
+        }
+        HIPCHK(hipHostMalloc((void **)&P.gh_dmeta, 2 * S * sizeof(int), hipHostMallocDefault));
+        if (dalloc(e, &P.g_dmeta, 2 * S)) return -1;
+    }
+    e->pipe_ready = true;
+    return 0;
+}
+
+static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, hipGraphExec_t *enc_out, hipGraphExec_t *dec_out) {
+    nasr_engine::Pipe &P = e->pipe[p];
+    const GraphDescLayout L = graph_desc_layout(B, G);
+    const RowDesc *g_rows = (const RowDesc *)(P.g_desc + L.rows), *g_vrows = (const RowDesc *)(P.g_desc + L.vrows);
+    const PcmDesc *g_pcm = (const PcmDesc *)(P.g_desc + L.pcm);
+    hipGraph_t graph = nullptr;
+    // encoder graph on the engine's stream; its last kernel writes this parity's joint.enc buffer
+    HIPCHK(hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
+    float *const encproj_saved = e->encproj;
+    e->encproj = P.encproj;
+    auto enc_body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(P.g_desc, P.gh, L.total, hipMemcpyHostToDevice, e->st));
+        MelParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+        launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
+        return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G) ? -1 : 0;
+    };
+    int rc = enc_body();
+    e->encproj = encproj_saved;
+    hipError_t ce = hipStreamEndCapture(e->st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+    if (ce != hipSuccess) return fail("hipStreamEndCapture (encoder graph) failed: %s", hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(enc_out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ie != hipSuccess) return fail("hipGraphInstantiate (encoder graph) failed: %s", hipGetErrorString(ie));
+    // decode graph on the second stream
+    graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->st2, hipStreamCaptureModeThreadLocal));
+    auto dec_body = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, e->st2));
+        DecParams dp;
+        make_dec_params(e, g_rows, B, T * G, dp);
+        dp.encproj = P.encproj;
+        launch_decode_begin(dp, e->st2);
+        int it = 0;
+        for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, e->st2);
+        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st2, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
+        return 0;
+    };
+    rc = dec_body();
+    ce = hipStreamEndCapture(e->st2, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+    if (ce != hipSuccess) return fail("hipStreamEndCapture (decode graph) failed: %s", hipGetErrorString(ce));
+    ie = hipGraphInstantiate(dec_out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ie != hipSuccess) return fail("hipGraphInstantiate (decode graph) failed: %s", hipGetErrorString(ie));
+    return 0;
+}
+
+// Completes the step of parity p whose encoder graph is in flight: waits for it, launches its decode graph on the second
+// stream (by now the NEXT step's encoder graph is queued behind it on the engine's stream and starts at once), waits for
+// that, finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
+// The decode graph is launched only once its input is ready: a launch parked behind an event wait for the ~1 ms the
+// encoder takes made every boundary of the encoder chain slower (1.21 vs 1.07 ms per step at batch 1, measured).
+static int pipe_finish(nasr_engine *e, int p) {
+    nasr_engine::Pipe &P = e->pipe[p];
+    if (!P.pending) return 0;
+    const int B = (int)P.streams.size(), TS = P.T * P.G;
+    HIPCHK(hipEventSynchronize(P.enc_done));
+    for (int b = 0; b < B; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[B + b] = P.streams[b]->tok_read; }
+    HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], e->st2));
+    HIPCHK(hipStreamSynchronize(e->st2));
+    int *gh_active = P.gh_collect + (size_t)B * (1 + COLLECT_STRIDE);      // k_collect appends n_active to its records
+    if (*gh_active != 0) {
+        const GraphDescLayout L = graph_desc_layout(B, P.G);
+        DecParams dp;
+        make_dec_params(e, (const RowDesc *)(P.g_desc + L.rows), B, TS, dp);
+        dp.encproj = P.encproj;
+        int itn = pipe_blind_iterations(TS), round = 8;
+        e->decode_fallbacks++;
+        for (;;) {
+            e->decode_fallback_rounds++;
+            enqueue_decode_iters(e, dp, B, round, itn, e->st2);
+            HIPCHK(hipMemcpyAsync(gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st2));
+            HIPCHK(hipStreamSynchronize(e->st2));
+            if (*gh_active == 0) break;
+            if (itn > TS * MAX_SYMBOLS + 64) return fail("decode did not terminate");
+            round = std::min(2 * round, 32);
+        }
+        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st2, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
+        HIPCHK(hipStreamSynchronize(e->st2));
+    }
+    P.pending = false;
+    return consume_collect(e, P.gh_collect, P.streams.data(), B);
+}
+
+// completes whatever the pipeline has in flight (tokens stay queued on their streams); cheap when nothing is
+static int pipe_drain(nasr_engine *e) {
+    if (!e->pipe_ready) return 0;
+    for (int k = 0; k < 2; k++)
+        if (pipe_finish(e, e->pipe_parity ^ k)) return -1;                 // the older step first
+    return 0;
+}
+
+static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev, const int32_t *n_samples, int G,
+                     int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
+    if (ensure_pipe(e)) return -1;
+    const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
+    const int p = e->pipe_parity;
+    nasr_engine::Pipe &P = e->pipe[p];
+    if (pipe_finish(e, p)) return -1;                      // not in steady state: this parity was consumed a step ago
+    const int64_t key = ((int64_t)B << 32) | ((int64_t)T << 16) | (int64_t)G;
+    auto ge = P.enc_graphs.find(key);
+    if (ge == P.enc_graphs.end()) {
+        if (pipe_drain(e)) return -1;
+        HIPCHK(hipStreamSynchronize(e->st));
+        hipGraphExec_t enc = nullptr, dec = nullptr;
+        {
+            CaptureExclusive alone;
+            if (build_pipe_graphs(e, p, B, T, R, G, &enc, &dec)) return -1;
+        }
+        ge = P.enc_graphs.emplace(key, enc).first;
+        P.dec_graphs[key] = dec;
+    }
+    const GraphDescLayout L = graph_desc_layout(B, G);
+    RowDesc *gh_rows = (RowDesc *)(P.gh + L.rows), *gh_vrows = (RowDesc *)(P.gh + L.vrows);
+    PcmDesc *gh_pcm = (PcmDesc *)(P.gh + L.pcm);
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = streams[b];
+        PcmDesc &d = gh_pcm[b];
+        memset(&d, 0, sizeof(d));
+        d.pcm = pcm_dev[b]; d.slot = s->slot; d.n = n_samples[b]; d.cnt = s->abuf_cnt; d.par = s->abuf_par;
+        const int avail = d.cnt + d.n;
+        d.n_frames = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
+        d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
+        d.consumed = d.n_frames * HOP;
+        fill_row_desc(gh_rows[b], s, T * G);
+        for (int g = 0; g < G; g++) {
+            RowDesc &v = gh_vrows[b * G + g];
+            v = gh_rows[b];
+            v.mel_start = (s->mel_start + g * shift) & (MEL_RING - 1);
+        }
+    }
+    HIPCHK(hipGraphLaunch(ge->second, e->st));
+    HIPCHK(hipEventRecord(P.enc_done, e->st));
+    for (int b = 0; b < B; b++) {                          // every count is a pure function of the samples pushed
+        nasr_stream *s = streams[b];
+        const PcmDesc &d = gh_pcm[b];
+        s->abuf_cnt = d.cnt + d.n - d.consumed;
+        if (d.n_frames > 0) s->abuf_par ^= 1;
+        s->mel_count += d.n_frames;
+        const int par = s->cc_par;
+        for (int g = 0; g < G; g++) chunk_bookkeeping(s, b);
+        s->cc_par = par ^ 1;
+        s->last_T = T * G; s->last_row = b;
+    }
+    P.pending = true;
+    P.streams.assign(streams, streams + B);
+    P.T = T; P.G = G; P.key = key;
+    // the previous step: its encoder graph is finishing or done, this step's is queued right behind it; decode it now
+    if (pipe_finish(e, p ^ 1)) return -1;
+    e->pipe_parity ^= 1;
+    e->graph_replays++;
+    e->pipe_steps++;
+    deliver(streams, B, tokens_out, tokens_cap, n_tokens);
+    return 1;
+}
+
 // returns 1 if the step was executed through the graph, 0 if not eligible, <0 on error
 static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev,
                           const int32_t *n_samples, int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
@@ -1347,6 +1604,8 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         // Needs the fused small-M path and the new rows to fit in the K/V ring next to the 70-row window.
         if (!e->opt_multichunk || B * G * T > e->w_rows || G * T > MAXNEW) return 0;
     }
+    if (e->opt_pipeline) return pipe_step(e, streams, B, pcm_dev, n_samples, G, tokens_out, tokens_cap, n_tokens);
+    if (pipe_drain(e)) return -1;
     const int64_t key = ((int64_t)B << 32) | ((int64_t)T << 16) | (int64_t)G;
     auto it = e->graphs.find(key);
     if (it == e->graphs.end()) {
@@ -1419,7 +1678,9 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         streams[b]->cc_par = par ^ 1;
         streams[b]->last_T = T * G; streams[b]->last_row = b;
     }
-    return consume_collect(e, e->gh_collect, streams, B, tokens_out, tokens_cap, n_tokens) ? -1 : 1;
+    if (consume_collect(e, e->gh_collect, streams, B)) return -1;
+    deliver(streams, B, tokens_out, tokens_cap, n_tokens);
+    return 1;
 }
 
 // one piece of a push (device-resident PCM): the graph-replayed launch sequence when eligible, else the eager
@@ -1432,6 +1693,7 @@ static int push_piece(nasr_engine *e, nasr_stream *const *streams, int B, const 
         if (gr < 0) return -1;
         if (gr == 1) return 0;
     }
+    if (pipe_drain(e)) return -1;
     e->eager_steps++;
     // sub-pushes of at most MAX_PUSH samples keep the audio buffer and the mel ring bounded
     for (;;) {
@@ -1561,6 +1823,7 @@ extern "C" int nasr_engine_step_mel(nasr_engine *e, nasr_stream *const *streams,
     if (validate_batch(e, streams, B)) return -1;
     if (!mel || !n_frames) return fail("null mel / n_frames");
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     std::vector<int> off(B, 0);
     const int piece = 8 * streams[0]->T;   // one shift at a time keeps the ring bounded
     for (;;) {
@@ -1611,6 +1874,7 @@ extern "C" int nasr_engine_finalize(nasr_engine *e, nasr_stream *const *streams,
     ApiGuard api_guard;
     if (validate_batch(e, streams, B)) return -1;
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     // src/nemo-stream.cpp:1234-1258: frames > 9 -> n_valid = (frames-9)/8 outputs of one zero-padded step
     std::vector<nasr_stream *> rows;
     std::vector<int> nd;
@@ -1658,6 +1922,7 @@ extern "C" int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first,
     if (first < 0 || count < 0) return fail("negative token range");
     nasr_engine *e = s->e;
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     HIPCHK(hipStreamSynchronize(e->st));
     DecCtrl c;
     HIPCHK(hipMemcpy(&c, e->ctrl + s->slot, sizeof(c), hipMemcpyDeviceToHost));
@@ -1675,6 +1940,7 @@ extern "C" int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *ou
     if (!s || !out) return fail("null argument");
     nasr_engine *e = s->e;
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     DecCtrl c;
     HIPCHK(hipStreamSynchronize(e->st));
     HIPCHK(hipMemcpy(&c, e->ctrl + s->slot, sizeof(c), hipMemcpyDeviceToHost));
@@ -1693,6 +1959,7 @@ extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, flo
     if (!s || !out) return fail("null argument");
     nasr_engine *e = s->e;
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     HIPCHK(hipStreamSynchronize(e->st));
     const size_t slot = (size_t)s->slot;
     const int T = s->last_T;
@@ -1765,6 +2032,7 @@ extern "C" int nasr_engine_profile(nasr_engine *e, int enable) {
     ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
     prof_flush(e);
     if (enable) for (auto &s : e->prof.stats) { s.launches = 0; s.total_ms = 0; s.bytes = 0; s.flops = 0; }
     e->prof.on = enable != 0;
@@ -1812,6 +2080,7 @@ extern "C" int nasr_engine_synchronize(nasr_engine *e) {
     ApiGuard api_guard;
     if (!e) return fail("null engine");
     HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;                       // the decode graph in flight, if any (its tokens stay queued)
     HIPCHK(hipStreamSynchronize(e->st));
     return 0;
 }

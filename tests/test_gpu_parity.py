@@ -185,6 +185,64 @@ def test_graph_replay_equals_eager(W, om32, dtype, R, B):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype,R,B", [(capi.DTYPE_F32, 0, 2), (capi.DTYPE_BF16, 0, 1), (capi.DTYPE_BF16, 13, 3), (capi.DTYPE_F32, 1, 1)])
+def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
+    """Engine option "pipeline": the decode graph of step s runs on a second HIP stream beside the encoder graph of step
+    s + 1 and the call of step s returns the tokens of step s - 1.  Same kernels on the same inputs: the token stream, the
+    encoder output, the decoder state and the decode-iteration count equal the synchronous path bit for bit -- also when
+    two groups of streams alternate, when a ragged (non-graph) push or a debug call lands in the middle of the pipeline,
+    and when the iteration budget of the decode graph falls short (burst of symbols on one frame)."""
+    eng = capi.Engine(W, n_layers=N_LAYERS, dtype=dtype, max_streams=2 * B + 1)
+    piece = synth.shift_samples(R)
+    secs = 3.0 if R < 13 else 9.0
+    pcms = [synth.make_pcm(60 + b, secs) for b in range(2 * B)]
+    n_steps = pcms[0].size // piece
+    res = {}
+    for mode in (0, 1):
+        eng.set_option("pipeline", mode)
+        grp = [[eng.stream(R) for _ in range(B)] for _ in range(2)]      # two groups of streams take turns
+        toks = [[] for _ in range(2 * B)]
+        lag = []
+        for k in range(n_steps):
+            for g in range(2):
+                if k == n_steps // 2 and g == 0:
+                    # a ragged push (two half pieces): not graph-eligible -> drains the pipeline, runs eagerly
+                    for half in (slice(k * piece, k * piece + 100), slice(k * piece + 100, (k + 1) * piece)):
+                        out = eng.step(grp[g], [p[half] for p in pcms[g * B:(g + 1) * B]])
+                        for b in range(B):
+                            toks[g * B + b] += out[b]
+                    continue
+                out = eng.step(grp[g], [p[k * piece:(k + 1) * piece] for p in pcms[g * B:(g + 1) * B]])
+                lag.append(sum(len(o) for o in out))
+                for b in range(B):
+                    toks[g * B + b] += out[b]
+            if k == n_steps // 3:
+                assert grp[1][0].stats().chunks > 0               # a stats call in the middle of the pipeline drains it
+        for g in range(2):
+            out = eng.finalize(grp[g])
+            for b in range(B):
+                toks[g * B + b] += out[b]
+        enc = np.stack([s.tap(capi.TAP_ENCODER_OUT) for g in range(2) for s in grp[g]])
+        dec = np.stack([s.tap(capi.TAP_DEC_STATE) for g in range(2) for s in grp[g]])
+        stats = [(s.stats().chunks, s.stats().decode_iterations, s.stats().tokens) for g in range(2) for s in grp[g]]
+        res[mode] = (toks, enc, dec, stats)
+        for g in range(2):
+            for s in grp[g]:
+                s.destroy()
+    assert res[1][0] == res[0][0] and sum(len(t) for t in res[0][0]) > 0
+    assert np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2])
+    assert [st[0] for st in res[1][3]] == [st[0] for st in res[0][3]] and res[0][3][0][0] > 5
+    assert [st[2] for st in res[1][3]] == [st[2] for st in res[0][3]]
+    if dtype == capi.DTYPE_F32:          # token-exact against the oracle, stream 0
+        ost = ob.OracleStream(om32, R)
+        to = []
+        for k in range(n_steps):
+            to += ost.process(pcms[0][k * piece:(k + 1) * piece])
+        to += ost.finalize()
+        assert res[1][0][0] == to
+    eng.close()
+
+
 def test_large_m_tiled_gemm_path(W, om16):
     """B = 10 streams x T = 14 rows = 140 rows: the LDS-DMA tiled GEMM (2 m-chunks, ragged tail rows)."""
     R, T, B = 13, 14, 10
