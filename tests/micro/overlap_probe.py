@@ -35,6 +35,7 @@ def make(n_layers, steps):
         ptr = (C.c_void_p * 1)(dev + 2 * k * 1280)
         if L.nasr_engine_step(eng.h, h, 1, ptr, ns, tp, cap, nt, capi.FLAG_PCM_DEVICE) < 0:
             raise RuntimeError(L.nasr_last_error().decode())
+    step.keep = (tok, st)                      # buffers the engine writes into must outlive make()
     return eng, step
 
 
