@@ -1,0 +1,409 @@
+// micro-benchmark: where do the cycles of the large-M GEMM (k_gemm_tiled2, csrc/kernels_gemm.hip) go?
+// The kernel body is repeated here with parts switched off:
+//   mode 0  the kernel as shipped (LDS-DMA ring, ds_read, MFMA, epilogue)
+//   mode 1  LDS-DMA only: the ring is filled and waited for, nothing is read or multiplied (pure per-CU ingest rate)
+//   mode 2  LDS-DMA + ds_read_b128 of every fragment, no MFMA
+//   mode 3  ds_read + MFMA on a ring filled once (no DMA in the loop: LDS / MFMA side alone)
+//   mode 7  candidate: 8 loader waves + 8 consumer waves (k_probe_roles)
+//   mode 6  candidate: weight fragments global -> registers (no LDS), activation panel through the ring
+//   mode 5  candidate: software pipeline inside the wave (reads of chunk i+1 and DMA of chunk i+4 before the MFMAs of chunk i)
+//   mode 4  candidate: all 12 ds_read_b128 of a chunk first, the next chunk's DMA issued under them, 16 MFMAs back to back
+// build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../nemotron-asr.cpp_amd/csrc gemm_probe.hip -o gemm_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "nasr_internal.h"
+#include "nasr_epilogue.h"
+using namespace nasr;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int TM = 128, G2_P = 3, G2_NS = 4, G2_SLOT = 32768;
+__device__ __forceinline__ int panel_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int MODE>
+__global__ __launch_bounds__(512) void k_probe(GemmParams p, int n_groups, int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = c1 - c0, m0 = mc * TM, ntile0 = (ng * 4 + ng4) * 2;
+    const uint4 *wpd = (const uint4 *)p.W + (size_t)(ntile0 + mh) * KT * 64 + lane;
+    const int prow = lane >> 3, pc = lane & 7;
+    const char *asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = wave * 16 + i * 8 + prow;
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kc, int slot) {
+        const unsigned sb = ring_base + slot * G2_SLOT;
+#pragma unroll
+        for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+        const unsigned wb = sb + 16384 + ng4 * 4096 + mh * 2048;
+        glds16(wpd + (size_t)(2 * kc) * 64, wb);
+        glds16(wpd + (size_t)(2 * kc + 1) * 64, wb + 1024);
+    };
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 sink = make_uint4(0, 0, 0, 0);
+    if (MODE == 6) {
+        // the weight fragments go straight from global memory to registers (4 global_load_dwordx4 per wave and chunk, three
+        // chunks ahead); only the activation panel uses the LDS ring: half the DMA instructions (their ISSUE, ~100+ cycles
+        // each, is what a wave cannot overlap with its own MFMAs) and a third less LDS traffic
+        const uint4 *wsrc[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) wsrc[j] = (const uint4 *)p.W + (size_t)(ntile0 + j) * KT * 64 + lane;
+        auto issue_a = [&](int kc, int slot) {
+            const unsigned sb = ring_base + slot * G2_SLOT;
+#pragma unroll
+            for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+        };
+        uint4 wreg[3][2][2];
+        auto load_w = [&](int kc, uint4 (&w)[2][2]) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) w[j][k2] = wsrc[j][(size_t)(2 * kc + k2) * 64];
+        };
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (u < nchunks) { issue_a(c0 + u, u); load_w(c0 + u, wreg[u]); }
+        for (int i0 = 0; i0 < nchunks; i0 += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int i = i0 + u;
+                if (i < nchunks) {
+                    const int rem = nchunks - 1 - i < 2 ? nchunks - 1 - i : 2;      // younger chunks in flight: 6 VMEM ops per wave each
+                    if (rem >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (rem == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const char *sp = ring + (i & (G2_NS - 1)) * G2_SLOT;
+                    uint4 bv[2][4];
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) bv[k2][mt] = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
+                    if (i + 3 < nchunks) issue_a(c0 + i + 3, (i + 3) & (G2_NS - 1));
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                        for (int mt = 0; mt < 4; mt++) {
+                            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[k2][mt]);
+                            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[u][0][k2]), bf, acc[0][mt], 0, 0, 0);
+                            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wreg[u][1][k2]), bf, acc[1][mt], 0, 0, 0);
+                        }
+                    if (i + 3 < nchunks) load_w(c0 + i + 3, wreg[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+        return;
+    }
+    if (MODE == 5) {
+        // software pipeline inside the wave: the fragments of chunk i + 1 are read (and the DMA of chunk i + 4 issued) BEFORE
+        // the 16 MFMAs of chunk i, so the LDS phase of one chunk runs under the MFMA phase of the previous one
+        auto rd = [&](int i, uint4 (&w)[2][2], uint4 (&bv)[2][4]) {
+            const char *sp = ring + (i & (G2_NS - 1)) * G2_SLOT;
+            const char *wl = sp + 16384 + ng4 * 4096 + lane * 16;
+            w[0][0] = *(const uint4 *)(wl);
+            w[0][1] = *(const uint4 *)(wl + 1024);
+            w[1][0] = *(const uint4 *)(wl + 2048);
+            w[1][1] = *(const uint4 *)(wl + 3072);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) bv[k2][mt] = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
+        };
+        auto mm = [&](uint4 (&w)[2][2], uint4 (&bv)[2][4]) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[k2][mt]);
+                    acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                    acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+                }
+        };
+        auto wait_landed = [&](int later) {      // this wave's DMA pieces: at most `later` younger chunks may still be in flight
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto step = [&](int i, uint4 (&cw)[2][2], uint4 (&cb)[2][4], uint4 (&nw)[2][2], uint4 (&nb)[2][4]) {
+            const bool more = i + 1 < nchunks;
+            if (more) wait_landed(nchunks - 2 - i < 2 ? nchunks - 2 - i : 2);     // chunk i + 1 has landed (issued so far: up to i + 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave has chunk i in registers
+            __builtin_amdgcn_s_barrier();                                          // ... and so has every wave: slot i is free, chunk i + 1 complete
+            if (more) rd(i + 1, nw, nb);
+            if (i + G2_NS < nchunks) issue(c0 + i + G2_NS, i & (G2_NS - 1));
+            mm(cw, cb);
+        };
+#pragma unroll
+        for (int i = 0; i < G2_NS; i++)
+            if (i < nchunks) issue(c0 + i, i);
+        uint4 wA[2][2], bA[2][4], wB[2][2], bB[2][4];
+        wait_landed(nchunks - 1 < 3 ? nchunks - 1 : 3 > 2 ? 2 : 2);                // chunk 0 (up to 3 younger chunks in flight: vmcnt(12) is not needed, 8 is safe)
+        __builtin_amdgcn_s_barrier();
+        rd(0, wA, bA);
+        for (int i = 0; i < nchunks; i += 2) {
+            step(i, wA, bA, wB, bB);
+            if (i + 1 < nchunks) step(i + 1, wB, bB, wA, bA);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < G2_P; i++)
+        if (i < nchunks) issue(c0 + i, i);
+    for (int i = 0; i < nchunks; i++) {
+        if (MODE != 3 || i < G2_P) {
+            const int rem = nchunks - 1 - i < G2_P - 1 ? nchunks - 1 - i : G2_P - 1;
+            if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char *sp = ring + ((MODE == 3 ? i % G2_P : i) & (G2_NS - 1)) * G2_SLOT;
+        if (MODE == 4) {
+            // all 12 fragments of the chunk requested at once, the next DMA issued while they are in flight (its slot was
+            // consumed in iteration i - 1, which every wave has left: the barrier above), then 16 MFMAs back to back
+            const char *wl = sp + 16384 + ng4 * 4096 + lane * 16;
+            uint4 w[2][2], bv[2][4];
+            w[0][0] = *(const uint4 *)(wl);
+            w[0][1] = *(const uint4 *)(wl + 1024);
+            w[1][0] = *(const uint4 *)(wl + 2048);
+            w[1][1] = *(const uint4 *)(wl + 3072);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) bv[k2][mt] = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
+            if (i + G2_P < nchunks) issue(c0 + i + G2_P, (i + G2_P) & (G2_NS - 1));
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[k2][mt]);
+                    acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                    acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+                }
+            continue;
+        }
+        if (MODE != 1) {
+            const char *wl = sp + 16384 + ng4 * 4096 + lane * 16;
+            uint4 w[2][2];
+            w[0][0] = *(const uint4 *)(wl);
+            w[0][1] = *(const uint4 *)(wl + 1024);
+            w[1][0] = *(const uint4 *)(wl + 2048);
+            w[1][1] = *(const uint4 *)(wl + 3072);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const uint4 bv = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
+                    if (MODE == 2) {
+                        sink.x ^= bv.x ^ w[0][k2].x ^ w[1][k2].y; sink.y ^= bv.y; sink.z ^= bv.z; sink.w ^= bv.w;
+                    } else {
+                        const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                        acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (MODE != 3 && i + G2_P < nchunks) issue(c0 + i + G2_P, (i + G2_P) & (G2_NS - 1));
+    }
+    if (MODE == 1 || MODE == 2) {
+        if ((sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x12345678u && p.M < 0) p.out_f32[0] = 1.f;   // keep the reads alive
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+}
+// mode 7: role-specialised waves.  16 waves: 8 loaders (two per SIMD) only issue the LDS-DMA of the ring, 8 consumers (same
+// tiling as the shipped kernel: 32 n x 64 m each) only read fragments and issue MFMAs, one chunk ahead in registers.  One
+// s_barrier per chunk for all 16 waves: at barrier i chunk i has landed (every loader waited for its own pieces) and every
+// consumer has chunk i - 1 in registers (lgkmcnt(0) before the barrier), so the loaders may overwrite slot (i - 1) & 3 with
+// chunk i + 3 while the consumers read chunk i and multiply chunk i - 1.
+__global__ __launch_bounds__(1024) void k_probe_roles(GemmParams p, int n_groups, int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool loader = wave16 >= 8;
+    const int wave = wave16 & 7;
+    const int ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = c1 - c0, m0 = mc * TM, ntile0 = (ng * 4 + ng4) * 2;
+    if (loader) {
+        const uint4 *wpd = (const uint4 *)p.W + (size_t)(ntile0 + mh) * KT * 64 + lane;
+        const int prow = lane >> 3, pc = lane & 7;
+        const char *asrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = wave * 16 + i * 8 + prow;
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+        }
+        const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+        auto issue = [&](int kc, int slot) {
+            const unsigned sb = ring_base + slot * G2_SLOT;
+#pragma unroll
+            for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+            const unsigned wb = sb + 16384 + ng4 * 4096 + mh * 2048;
+            glds16(wpd + (size_t)(2 * kc) * 64, wb);
+            glds16(wpd + (size_t)(2 * kc + 1) * 64, wb + 1024);
+        };
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (i < nchunks) issue(c0 + i, i);
+        for (int i = 0; i <= nchunks; i++) {                 // barriers 0 .. nchunks (the consumers' last one closes the pipeline)
+            if (i < nchunks) {
+                const int rem = nchunks - 1 - i < 2 ? nchunks - 1 - i : 2;
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (i + 3 < nchunks) issue(c0 + i + 3, (i + 3) & 3);
+        }
+        return;
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragments of HALF a chunk (one 32-deep k-tile: 2 weight + 4 activation fragments = 24 VGPRs) per register set, two sets:
+    // while one half is multiplied the next one is being read (1024 threads leave 128 VGPRs per wave)
+    auto rd = [&](int i, int k2, uint4 (&w)[2], uint4 (&bv)[4]) {
+        const char *sp = ring + (i & 3) * G2_SLOT;
+        const char *wl = sp + 16384 + ng4 * 4096 + lane * 16 + k2 * 1024;
+        w[0] = *(const uint4 *)(wl);
+        w[1] = *(const uint4 *)(wl + 2048);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) bv[mt] = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
+    };
+    auto mm = [&](uint4 (&w)[2], uint4 (&bv)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[mt]);
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0]), bf, acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1]), bf, acc[1][mt], 0, 0, 0);
+        }
+    };
+    uint4 wA[2], bA[4], wB[2], bB[4];
+    // barrier i: chunk i has landed.  Then: read (i, half 0) -> A | multiply (i - 1, half 1) from B | read (i, half 1) -> B |
+    // multiply (i, half 0) from A | all reads of chunk i complete before barrier i + 1
+    for (int i = 0; i <= nchunks; i++) {
+        __builtin_amdgcn_s_barrier();
+        if (i < nchunks) rd(i, 0, wA, bA);
+        __builtin_amdgcn_sched_barrier(0);                 // keep the order: reads issued, THEN the MFMAs of the other set, THEN the wait
+        if (i > 0) mm(wB, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < nchunks) {
+            rd(i, 1, wB, bB);                              // (the compiler's own lgkmcnt(6) lets set A through with set B in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            mm(wA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk i is complete before the barrier frees its slot
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+}
+static double run_roles(const GemmParams &p, hipStream_t st, int reps) {
+    const int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+    const dim3 grid(n_groups * m_chunks * p.splits);
+    hipFuncSetAttribute((const void *)k_probe_roles, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_probe_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    hipEventRecord(a, st);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    hipEventRecord(b, st);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return 1e3 * ms / reps;
+}
+template <int MODE> static double run(const GemmParams &p, hipStream_t st, int reps) {
+    const int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+    const dim3 grid(n_groups * m_chunks * p.splits);
+    hipFuncSetAttribute((const void *)k_probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_probe<MODE>, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    hipEventRecord(a, st);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe<MODE>, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    hipEventRecord(b, st);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return 1e3 * ms / reps;
+}
+int main() {
+    hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    const int M = 896;
+    struct Shape { const char *name; int N, K, splits, epi; } shapes[] = {
+        {"W1   N=4096 K=1024", 4096, 1024, 1, EPI_SILU_ACT}, {"W2   N=1024 K=4096 split 4", 1024, 4096, 4, EPI_PART_F32},
+        {"Wo   N=1024 K=1024 split 4", 1024, 1024, 4, EPI_PART_F32}, {"pw1  N=2048 K=1024 split 2", 2048, 1024, 2, EPI_PART_F32}};
+    // a pool of weight buffers larger than the caches, cycled through, so that every launch streams its weights from HBM
+    const size_t pool = (size_t)512 << 20;
+    char *wpool; hipMalloc(&wpool, pool); hipMemset(wpool, 0x11, pool);
+    char *A; hipMalloc(&A, (size_t)M * 4096 * 2); hipMemset(A, 0x22, (size_t)M * 4096 * 2);
+    char *out; hipMalloc(&out, (size_t)8 * M * 4096 * 4);
+    for (const Shape &s : shapes) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.A = A; p.W = wpool; p.M = M; p.N = s.N; p.K = s.K; p.lda = s.K; p.splits = s.splits; p.epi = s.epi;
+        p.out_f32 = (float *)out; p.ldo = s.N; p.out_act = out; p.ldo_act = s.N;
+        const double flops = 2.0 * M * s.N * s.K, bytes_cu = (128.0 + 128.0) * (s.K / s.splits) * 2;
+        const double t0 = run<0>(p, st, 200), t1 = run<1>(p, st, 200), t2 = run<2>(p, st, 200), t3 = run<3>(p, st, 200), t4 = run<4>(p, st, 200), t5 = run<5>(p, st, 200), t6 = run<6>(p, st, 200), t7 = run_roles(p, st, 200);
+        printf("%-28s full %6.2f us (%5.0f TFLOP/s) | DMA only %6.2f us (%4.0f GB/s per CU) | DMA+ds_read %6.2f | ds_read+MFMA, no DMA %6.2f | reads up front, DMA under them %6.2f (%5.0f TFLOP/s) | pipelined in the wave %6.2f (%5.0f TFLOP/s) | W to registers %6.2f (%5.0f TFLOP/s) | loader + consumer waves %6.2f (%5.0f TFLOP/s)\n",
+               s.name, t0, flops / t0 * 1e-6, t1, bytes_cu / t1 * 1e-3, t2, t3, t4, flops / t4 * 1e-6, t5, flops / t5 * 1e-6, t6, flops / t6 * 1e-6, t7, flops / t7 * 1e-6);
+    }
+    return 0;
+}
