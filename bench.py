@@ -52,6 +52,12 @@ def pmc_traffic(category, B, R, dtype, layers):
     profiles/ (FETCH_SIZE x2 correction + WRITE_SIZE, MI355X_MICROARCH.md).  PMC counters cannot be
     collected from inside this process; the number is reported only for the configuration it was
     measured on (batch 1, R 0, bf16, 24 layers) and is null otherwise."""
+    if (B, R, dtype, layers, category) == (64, 13, "bf16", 24, "k_gemm_tiled"):       # BASELINE configs[2]/[3] shape
+        f64 = ROOT / "profiles" / "r1f_pmc_batch64_R13.json"
+        if not f64.exists():
+            return None
+        d = json.loads(f64.read_text())["derived"]["k_gemm_tiled2"]
+        return int(d["fabric_read_bytes"] + d["write_bytes"])
     f = ROOT / "profiles" / "r1_pmc_traffic_batch1_R0.json"
     if (B, R, dtype, layers) != (1, 0, "bf16", 24) or not f.exists() or category not in _SYMBOL:
         return None
@@ -193,7 +199,8 @@ def main():
             if dom["name"] == "k_gemm_tiled":
                 ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
                 roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS,
-                                unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                                unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
+                                traffic=pmc_traffic(dom["name"], B * args.chunks_per_step, R, args.dtype, args.layers),
                                 peak_measured=MFMA_MEASURED_TFLOPS, frac_of_measured=round(ach / MFMA_MEASURED_TFLOPS, 4),
                                 hbm_frac=round(dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 avg_launch_us=round(avg_ms * 1e3, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),

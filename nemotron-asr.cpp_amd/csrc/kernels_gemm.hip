@@ -214,8 +214,127 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
                            acc[j][mt][2], acc[j][mt][3]);
 }
 
+// ------------------------------------------------------------------------------------
+// the same tile and ring with ROLE-SPECIALISED waves (tests/micro/gemm_probe.hip, mode 7): in k_gemm_tiled2 every wave
+// issues its share of the LDS-DMA (4 instructions of ~100 cycles per chunk), reads its fragments and multiplies -- one
+// after the other, and all eight waves in the same phase behind the per-chunk barrier: 0.5 us per chunk where the DMA
+// alone needs 0.17 and the MFMAs 0.21.  Here 16 waves share one workgroup: 8 loaders (two per SIMD) do nothing but issue
+// the DMA of the ring, 8 consumers (the tiling of k_gemm_tiled2: 32 n x 64 m each) do nothing but read fragments and issue
+// MFMAs, half a chunk ahead in registers.  One s_barrier per chunk for all 16 waves: at barrier i chunk i has landed (every
+// loader waited for its own pieces) and every consumer holds what it still needs of chunk i - 1 in registers (lgkmcnt(0)
+// before the barrier), so the loaders overwrite slot (i - 1) & 3 with chunk i + 3 while the consumers work on chunk i.
+// 13.0 instead of 15.2 us on the W1 shape, 12.5 instead of 13.6 on W2 (M = 896); slightly slower below 8 chunks per
+// workgroup, where k_gemm_tiled2 stays.  1024 threads leave 128 VGPRs per wave: fragments of half a chunk per register set.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups, int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool loader = wave16 >= 8;
+    const int wave = wave16 & 7;
+    const int ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = c1 - c0, m0 = mc * TM, ntile0 = (ng * 4 + ng4) * 2;
+    if (loader) {
+        const uint4 *wpd = (const uint4 *)p.W + (size_t)(ntile0 + mh) * KT * 64 + lane;
+        const int prow = lane >> 3, pc = lane & 7;
+        const char *asrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = wave * 16 + i * 8 + prow;
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+        }
+        const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+        auto issue = [&](int kc, int slot) {
+            const unsigned sb = ring_base + slot * G2_SLOT;
+#pragma unroll
+            for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+            const unsigned wb = sb + 16384 + ng4 * 4096 + mh * 2048;
+            glds16(wpd + (size_t)(2 * kc) * 64, wb);
+            glds16(wpd + (size_t)(2 * kc + 1) * 64, wb + 1024);
+        };
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (i < nchunks) issue(c0 + i, i);
+        for (int i = 0; i <= nchunks; i++) {                 // barriers 0 .. nchunks (the consumers' last one closes the pipeline)
+            if (i < nchunks) {
+                const int rem = nchunks - 1 - i < 2 ? nchunks - 1 - i : 2;
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (i + 3 < nchunks) issue(c0 + i + 3, (i + 3) & 3);
+        }
+        return;
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragments of HALF a chunk (one 32-deep k-tile: 2 weight + 4 activation fragments = 24 VGPRs) per register set, two sets:
+    // while one half is multiplied the next one is being read (1024 threads leave 128 VGPRs per wave).  The reads are issued
+    // from inline asm and waited for by hand (LDS returns in order: lgkmcnt(6) = the older set has arrived): the compiler's own
+    // wait insertion puts lgkmcnt(0) in front of the second half's MFMAs and serialises it.
+#define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    const unsigned w_addr = lds0 + 16384 + ng4 * 4096 + lane * 16;
+    unsigned b_addr[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) b_addr[k2] = lds0 + panel_off(mh * 64 + r, k2 * 4 + q);     // + mt * 2048: the swizzle depends on r only
+    uint4 wA[2], bA[4], wB[2], bB[4];
+    auto mm = [&](uint4 (&w)[2], uint4 (&bv)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[mt]);
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0]), bf, acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1]), bf, acc[1][mt], 0, 0, 0);
+        }
+    };
+    // barrier i: chunk i has landed.  Then: read (i, half 0) -> A | multiply (i - 1, half 1) from B | read (i, half 1) -> B |
+    // multiply (i, half 0) from A | all reads of chunk i complete before barrier i + 1
+    for (int i = 0; i <= nchunks; i++) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned so = (unsigned)(i & 3) * G2_SLOT;
+        if (i < nchunks) {
+            const unsigned wa = w_addr + so, ba = b_addr[0] + so;
+            LDS_RD(wA[0], wa, 0); LDS_RD(wA[1], wa, 2048);
+            LDS_RD(bA[0], ba, 0); LDS_RD(bA[1], ba, 2048); LDS_RD(bA[2], ba, 4096); LDS_RD(bA[3], ba, 6144);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i > 0) mm(wB, bB);                             // set B arrived before the last barrier (lgkmcnt(0) below)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < nchunks) {
+            const unsigned wa = w_addr + so + 1024, ba = b_addr[1] + so;
+            LDS_RD(wB[0], wa, 0); LDS_RD(wB[1], wa, 2048);
+            LDS_RD(bB[0], ba, 0); LDS_RD(bB[1], ba, 2048); LDS_RD(bB[2], ba, 4096); LDS_RD(bB[3], ba, 6144);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // set A is in (6 younger reads in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            mm(wA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk i complete before the barrier frees its slot
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+}
+
 void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_tiled2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_roles, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
 }
 
 int gemm_skinny_max_m() {
@@ -234,7 +353,11 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     } else {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
         dim3 grid(n_groups * m_chunks * p.splits);
-        hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+        static const int roles_min_chunks = getenv("NASR_ROLES_MIN_CHUNKS") ? atoi(getenv("NASR_ROLES_MIN_CHUNKS")) : 8;
+        if ((p.K >> 6) / p.splits >= roles_min_chunks)
+            hipLaunchKernelGGL(k_gemm_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+        else
+            hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
     }
 }
 

@@ -314,15 +314,16 @@ __global__ __launch_bounds__(1024) void k_probe_roles(GemmParams p, int n_groups
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // fragments of HALF a chunk (one 32-deep k-tile: 2 weight + 4 activation fragments = 24 VGPRs) per register set, two sets:
-    // while one half is multiplied the next one is being read (1024 threads leave 128 VGPRs per wave)
-    auto rd = [&](int i, int k2, uint4 (&w)[2], uint4 (&bv)[4]) {
-        const char *sp = ring + (i & 3) * G2_SLOT;
-        const char *wl = sp + 16384 + ng4 * 4096 + lane * 16 + k2 * 1024;
-        w[0] = *(const uint4 *)(wl);
-        w[1] = *(const uint4 *)(wl + 2048);
+    // while one half is multiplied the next one is being read (1024 threads leave 128 VGPRs per wave).  The reads are issued
+    // from inline asm and waited for by hand (LDS returns in order: lgkmcnt(6) = the older set has arrived): the compiler's own
+    // wait insertion puts lgkmcnt(0) in front of the second half's MFMAs and serialises it.
+#define LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    const unsigned w_addr = lds0 + 16384 + ng4 * 4096 + lane * 16;
+    unsigned b_addr[2];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) bv[mt] = *(const uint4 *)(sp + panel_off((mh * 4 + mt) * 16 + r, k2 * 4 + q));
-    };
+    for (int k2 = 0; k2 < 2; k2++) b_addr[k2] = lds0 + panel_off(mh * 64 + r, k2 * 4 + q);     // + mt * 2048: the swizzle depends on r only
+    uint4 wA[2], bA[4], wB[2], bB[4];
     auto mm = [&](uint4 (&w)[2], uint4 (&bv)[4]) {
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
@@ -331,21 +332,28 @@ __global__ __launch_bounds__(1024) void k_probe_roles(GemmParams p, int n_groups
             acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1]), bf, acc[1][mt], 0, 0, 0);
         }
     };
-    uint4 wA[2], bA[4], wB[2], bB[4];
     // barrier i: chunk i has landed.  Then: read (i, half 0) -> A | multiply (i - 1, half 1) from B | read (i, half 1) -> B |
     // multiply (i, half 0) from A | all reads of chunk i complete before barrier i + 1
     for (int i = 0; i <= nchunks; i++) {
         __builtin_amdgcn_s_barrier();
-        if (i < nchunks) rd(i, 0, wA, bA);
-        __builtin_amdgcn_sched_barrier(0);                 // keep the order: reads issued, THEN the MFMAs of the other set, THEN the wait
-        if (i > 0) mm(wB, bB);
+        const unsigned so = (unsigned)(i & 3) * G2_SLOT;
+        if (i < nchunks) {
+            const unsigned wa = w_addr + so, ba = b_addr[0] + so;
+            LDS_RD(wA[0], wa, 0); LDS_RD(wA[1], wa, 2048);
+            LDS_RD(bA[0], ba, 0); LDS_RD(bA[1], ba, 2048); LDS_RD(bA[2], ba, 4096); LDS_RD(bA[3], ba, 6144);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i > 0) mm(wB, bB);                             // set B arrived before the last barrier (lgkmcnt(0) below)
         __builtin_amdgcn_sched_barrier(0);
         if (i < nchunks) {
-            rd(i, 1, wB, bB);                              // (the compiler's own lgkmcnt(6) lets set A through with set B in flight)
+            const unsigned wa = w_addr + so + 1024, ba = b_addr[1] + so;
+            LDS_RD(wB[0], wa, 0); LDS_RD(wB[1], wa, 2048);
+            LDS_RD(bB[0], ba, 0); LDS_RD(bB[1], ba, 2048); LDS_RD(bB[2], ba, 4096); LDS_RD(bB[3], ba, 6144);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");   // set A is in (6 younger reads in flight)
             __builtin_amdgcn_sched_barrier(0);
             mm(wA, bA);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk i is complete before the barrier frees its slot
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk i complete before the barrier frees its slot
         }
     }
 #pragma unroll
@@ -354,7 +362,9 @@ __global__ __launch_bounds__(1024) void k_probe_roles(GemmParams p, int n_groups
         for (int mt = 0; mt < 4; mt++)
             epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
 }
-static double run_roles(const GemmParams &p, hipStream_t st, int reps) {
+static size_t g_cold_stride = 0;     // > 0: every launch reads its weights from a different part of the pool (cold: from HBM)
+static double run_roles(const GemmParams &p0, hipStream_t st, int reps) {
+    GemmParams p = p0;
     const int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
     const dim3 grid(n_groups * m_chunks * p.splits);
     hipFuncSetAttribute((const void *)k_probe_roles, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
@@ -362,7 +372,10 @@ static double run_roles(const GemmParams &p, hipStream_t st, int reps) {
     hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_probe_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
     hipEventRecord(a, st);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    for (int i = 0; i < reps; i++) {
+        p.W = (const char *)p0.W + (g_cold_stride ? (size_t)(i % 24) * g_cold_stride : 0);
+        hipLaunchKernelGGL(k_probe_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    }
     hipEventRecord(b, st);
     hipEventSynchronize(b);
     float ms = 0;
@@ -402,6 +415,10 @@ int main() {
         p.out_f32 = (float *)out; p.ldo = s.N; p.out_act = out; p.ldo_act = s.N;
         const double flops = 2.0 * M * s.N * s.K, bytes_cu = (128.0 + 128.0) * (s.K / s.splits) * 2;
         const double t0 = run<0>(p, st, 200), t1 = run<1>(p, st, 200), t2 = run<2>(p, st, 200), t3 = run<3>(p, st, 200), t4 = run<4>(p, st, 200), t5 = run<5>(p, st, 200), t6 = run<6>(p, st, 200), t7 = run_roles(p, st, 200);
+        g_cold_stride = (size_t)20 << 20;
+        const double t7c = run_roles(p, st, 200);
+        g_cold_stride = 0;
+        printf("    %-24s loader + consumer waves, weights cold (a different 20 MiB-spaced buffer every launch, 480 MiB cycle): %6.2f us\n", s.name, t7c);
         printf("%-28s full %6.2f us (%5.0f TFLOP/s) | DMA only %6.2f us (%4.0f GB/s per CU) | DMA+ds_read %6.2f | ds_read+MFMA, no DMA %6.2f | reads up front, DMA under them %6.2f (%5.0f TFLOP/s) | pipelined in the wave %6.2f (%5.0f TFLOP/s) | W to registers %6.2f (%5.0f TFLOP/s) | loader + consumer waves %6.2f (%5.0f TFLOP/s)\n",
                s.name, t0, flops / t0 * 1e-6, t1, bytes_cu / t1 * 1e-3, t2, t3, t4, flops / t4 * 1e-6, t5, flops / t5 * 1e-6, t6, flops / t6 * 1e-6, t7, flops / t7 * 1e-6);
     }
