@@ -128,6 +128,25 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// Epilogue of the 128 x 128 tile through LDS.  Straight from the accumulators a wave-store writes 16 rows x 64 B (f32) or
+// 32 B (bf16): partial lines, and the epilogue cost 3.7-5.3 us of a 8-15 us GEMM (tests/micro/gemm_probe.hip, mode 8: W1
+// 15.2 us with, 9.8 us without its stores).  The ring is free once the K loop is over: the accumulators are parked in it as
+// an f32 tile [128][132] and every thread then handles 4 consecutive columns of one row, so that a wave writes two whole
+// rows of the tile (2 x 512 B of f32 / 2 x 256 B of bf16) per instruction.  Same epi_quad, same values, other thread.
+constexpr int STG_LD = 132;      // floats per staged row (128 + 4: the 16 rows of a float4 store spread over the banks)
+__device__ __forceinline__ void stage_acc(float *stage, int m_local, int n_local, const f32x4 &a) {
+    *(float4 *)(stage + m_local * STG_LD + n_local) = make_float4(a[0], a[1], a[2], a[3]);
+}
+template <int NTHREADS>
+__device__ __forceinline__ void staged_epilogue(const GemmParams &p, int split, int m0, int n_base, const float *stage) {
+#pragma unroll 4
+    for (int e = threadIdx.x; e < TM * 32; e += NTHREADS) {
+        const int row = e >> 5, c4 = (e & 31) * 4;
+        const float4 v = *(const float4 *)(stage + row * STG_LD + c4);
+        epi_quad<true>(p, split, m0 + row, n_base + c4, v.x, v.y, v.z, v.w);
+    }
+}
+
 __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups, int m_chunks) {
     // 8 waves = 2 per SIMD: wave w owns n-tile pair (w & 3) x m-tiles [(w >> 2) * 4, +4).  One wave's
     // LDS-DMA issue (expensive: ~100+ cycles per 1 KiB instruction) overlaps its SIMD partner's MFMAs.
@@ -206,12 +225,14 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
         }
         if (i + G2_P < nchunks) issue(c0 + i + G2_P, (i + G2_P) & (G2_NS - 1));
     }
+    __syncthreads();                           // every wave is done with the ring
+    float *stage = (float *)ring;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-            epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1],
-                           acc[j][mt][2], acc[j][mt][3]);
+        for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (ng4 * 2 + j) * 16 + q * 4, acc[j][mt]);
+    __syncthreads();
+    staged_epilogue<512>(p, split, m0, ng * 128, stage);
 }
 
 // ------------------------------------------------------------------------------------
@@ -275,6 +296,9 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
             __builtin_amdgcn_s_barrier();
             if (i + 3 < nchunks) issue(c0 + i + 3, (i + 3) & 3);
         }
+        __syncthreads();                       // (consumers: done with the ring) ...
+        __syncthreads();                       // ... (consumers: accumulators parked in it): the loaders help to store them
+        staged_epilogue<1024>(p, split, m0, ng * 128, (const float *)ring);
         return;
     }
     f32x4 acc[2][4];
@@ -325,11 +349,14 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk i complete before the barrier frees its slot
         }
     }
+    __syncthreads();
+    float *stage = (float *)ring;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-            epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+        for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (ng4 * 2 + j) * 16 + q * 4, acc[j][mt]);
+    __syncthreads();
+    staged_epilogue<1024>(p, split, m0, ng * 128, stage);
 }
 
 void init_gemm_kernel_attributes() {
