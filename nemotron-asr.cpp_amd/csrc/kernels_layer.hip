@@ -32,14 +32,14 @@ __device__ __forceinline__ float4 ln4(float4 v, const float *w, const float *b, 
     return ln4(v, *(const float4 *)(w + c4), *(const float4 *)(b + c4), sh);
 }
 
-__device__ __forceinline__ void store_act4(void *base, size_t off, float4 v, int bf16) {
+__device__ __forceinline__ void store_act4(void *base, size_t off, float4 v, int bf16) {      // write-through (nasr_wave.h)
     if (bf16) {
         uint2 r;
         r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
         r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-        *(uint2 *)((bf16_t *)base + off) = r;
+        store_wt_u2((bf16_t *)base + off, r);
     } else {
-        *(float4 *)((float *)base + off) = v;
+        store_wt_f4((float *)base + off, v);
     }
 }
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_post(PostParams p) {
         v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
     }
     if (p.ln_out) v = ln4(v, w1, b1, sh);
-    if (p.splits > 0 || p.ln_out) *(float4 *)(p.x + (size_t)m * D + c4) = v;
+    if (p.splits > 0 || p.ln_out) store_wt_f4(p.x + (size_t)m * D + c4, v);
     if (p.copy_out) *(float4 *)(p.copy_out + (size_t)m * D + c4) = v;
     if (p.ln2_w) {
         float4 a = ln4(v, w2, b2, sh);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
             uint2 o;
             o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
             o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
-            *(uint2 *)((bf16_t *)p.ctx_out + (row0 + r) * D + h * DH + dt * 16 + q * 4) = o;
+            store_wt_u2((bf16_t *)p.ctx_out + (row0 + r) * D + h * DH + dt * 16 + q * 4, o);
         }
     }
 }

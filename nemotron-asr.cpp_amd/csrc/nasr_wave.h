@@ -33,4 +33,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+// Write-through stores (sc0 sc1) for bulk outputs that the NEXT kernel reads: the bytes go to memory as they are produced
+// instead of sitting dirty in this XCD's L2 until the end-of-kernel write-back (tests/micro/gemm_probe.hip, mode 9).
+typedef __attribute__((ext_vector_type(4))) float wt_f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned wt_u32x2;
+__device__ __forceinline__ void store_wt_f4(float *p, float4 v) {
+    const wt_f32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store_wt_u2(void *p, uint2 v) {
+    const wt_u32x2 w = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+
 }  // namespace nasr
