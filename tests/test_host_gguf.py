@@ -124,6 +124,10 @@ def test_cli_end_to_end(tmp_path):
     stamped = "".join((" {%.2f}" % (np.float32(f) * 1280 / 16000) + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t]
                       for t, f in zip(ref, ost.token_frames()))
     assert lines[-2] == stamped
+    # pipelined steps: same transcript and tokens (each delta is printed one read later, the rest by finalize)
+    r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--print-tokens", "--pipeline"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert [int(x) for x in r.stdout.splitlines()[-1].split()[1:]] == ref
     r = subprocess.run([str(cli), str(model), str(audio), "80", "5"], capture_output=True, text=True)
     assert r.returncode == 1 and "right_context" in r.stderr
 
