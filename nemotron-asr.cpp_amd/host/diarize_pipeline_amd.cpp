@@ -32,6 +32,7 @@ struct diarize_pipeline {
     int n_off_run = 0, open_seg_id = -1, next_seg_id = 0, min_off_frames = 60;
     int64_t open_start_frame = -1, open_next_sub = 0;
     std::vector<vad_segment> segments;
+    std::vector<std::pair<int64_t, int64_t>> segment_frames;      // the same in VAD frames
     std::vector<diarize_subsegment> subs;
     std::vector<float> embs;              // [subs][192], L2-normalised
     std::vector<PendingSub> pending;
@@ -62,6 +63,7 @@ void queue_tail(diarize_pipeline &p, int64_t seg_end, bool at_eof) {
 
 void close_segment(diarize_pipeline &p, int64_t end_frame) {             // :153-165
     p.segments.push_back({(float)p.open_start_frame * 0.01f, (float)end_frame * 0.01f});
+    p.segment_frames.push_back({p.open_start_frame, end_frame});
     p.in_speech = false;
     p.open_seg_id = -1;
     p.open_start_frame = -1;
@@ -293,6 +295,36 @@ std::string diarize_pipeline_finalize(diarize_pipeline *p) {             // :437
                 f << "SPEAKER session 1 " << s.start_sec << " " << (s.end_sec - s.start_sec) << " <NA> <NA> spk_" << s.speaker << " <NA> <NA>\n";
     }
     return out;
+}
+
+extern "C" int nasr_diar_plan(const float *probs, int n_probs, long long total_samples, float onset, float offset,
+                              float min_duration_off_sec, float sub_window_sec, float sub_shift_sec, float min_seg_sec,
+                              long long *segs_out, int segs_cap, int *n_segs, long long *subs_out, int subs_cap, int *n_subs) {
+    if (!probs || n_probs < 0 || !n_segs || !n_subs) return -1;
+    diarize_pipeline p;                                   // no model: only the host state machine runs
+    p.cfg = diarize_pipeline_default_cfg();
+    p.cfg.vad_post.onset = onset; p.cfg.vad_post.offset = offset; p.cfg.vad_post.min_duration_off = min_duration_off_sec;
+    p.cfg.sub_window_sec = sub_window_sec; p.cfg.sub_shift_sec = sub_shift_sec; p.cfg.min_seg_sec = min_seg_sec;
+    p.min_off_frames = (int)std::ceil(min_duration_off_sec / p.cfg.vad_post.frame_period_sec);
+    p.total = total_samples;
+    for (int i = 0; i < n_probs; i++) step_frame(p, probs[i]);
+    if (p.in_speech) {                                    // finalize: end of input = end of speech
+        const int64_t end_frame = p.vad_next;
+        queue_tail(p, std::min<int64_t>(end_frame * VAD_SHIFT, p.total), true);
+        close_segment(p, end_frame);
+    }
+    *n_segs = (int)p.segment_frames.size();
+    *n_subs = (int)p.pending.size();
+    int rc = 0;
+    for (int i = 0; i < *n_segs; i++) {
+        if (!segs_out || i >= segs_cap) { rc = -1; break; }
+        segs_out[2 * i] = p.segment_frames[(size_t)i].first; segs_out[2 * i + 1] = p.segment_frames[(size_t)i].second;
+    }
+    for (int i = 0; i < *n_subs; i++) {
+        if (!subs_out || i >= subs_cap) { rc = -1; break; }
+        subs_out[3 * i] = p.pending[(size_t)i].seg_id; subs_out[3 * i + 1] = p.pending[(size_t)i].start; subs_out[3 * i + 2] = p.pending[(size_t)i].lens;
+    }
+    return rc;
 }
 
 size_t diarize_pipeline_n_embeddings(const diarize_pipeline *p) { return p ? p->subs.size() + p->pending.size() : 0; }

@@ -45,6 +45,14 @@ size_t diarize_pipeline_n_embeddings(const diarize_pipeline *p);
 size_t diarize_pipeline_n_segments(const diarize_pipeline *p);
 size_t diarize_pipeline_n_words(const diarize_pipeline *p);
 
+// The segment / sub-segment plan of a probability track WITHOUT a model or a GPU (host logic only, for tests and tools):
+// runs the onset / offset state machine and the sub-segment cursor over probs[0..n) as push_audio + finalize would for an
+// audio of total_samples samples.  segs_out: (start_frame, end_frame) pairs; subs_out: (segment id, start sample, samples)
+// triples.  Returns 0, or -1 when a capacity is too small (the counts are still written).
+extern "C" int nasr_diar_plan(const float *probs, int n_probs, long long total_samples, float onset, float offset,
+                              float min_duration_off_sec, float sub_window_sec, float sub_shift_sec, float min_seg_sec,
+                              long long *segs_out, int segs_cap, int *n_segs, long long *subs_out, int subs_cap, int *n_subs);
+
 // introspection for tests / tools
 struct diarize_subsegment { int seg_id; float start_sec, end_sec; int speaker; };   // speaker = -1 before finalize
 std::vector<diarize_subsegment> diarize_pipeline_subsegments(const diarize_pipeline *p);
