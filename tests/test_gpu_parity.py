@@ -574,3 +574,63 @@ def test_error_behaviour(eng32):
 def test_smoke_entry():
     from nemotron_asr_amd import smoke
     assert smoke.run(verbose=False)
+
+
+def test_pipelined_decode_fallback_path(tmp_path):
+    """The decode graph of a pipelined step carries a fixed number of iterations; a burst of symbols beyond it is finished
+    eagerly on the second stream before the next decode graph is launched.  With the budget cut to its minimum
+    (NASR_PIPE_ITERS=1, own process: the knob is read once) the fallback runs many times -- tokens still equal synchronous
+    stepping and the f32 oracle."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / "run.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {str(root)!r})
+import __graft_entry__ as ge
+ge.load_package()
+from nemotron_asr_amd import capi, synth
+from oracle import binding as ob
+W = synth.make_weights(n_layers=2)
+B, R = 4, 1
+piece = synth.shift_samples(R)
+pcms = [synth.make_pcm(80 + b, 6.0) for b in range(B)]
+res = {{}}
+for mode in (0, 1):
+    eng = capi.Engine(W, n_layers=2, dtype=capi.DTYPE_F32, max_streams=B)
+    eng.set_option("pipeline", mode)
+    sts = [eng.stream(R) for _ in range(B)]
+    toks = [[] for _ in range(B)]
+    for k in range(pcms[0].size // piece):
+        out = eng.step(sts, [p[k * piece:(k + 1) * piece] for p in pcms])
+        for b in range(B):
+            toks[b] += out[b]
+    out = eng.finalize(sts)
+    for b in range(B):
+        toks[b] += out[b]
+    res[mode] = toks
+    for s in sts:
+        s.destroy()
+    eng.close()
+assert res[0] == res[1], "pipelined tokens differ"
+om = ob.OracleModel(W, 2)
+for b in range(B):
+    ost = ob.OracleStream(om, R)
+    ref = []
+    for k in range(pcms[b].size // piece):
+        ref += ost.process(pcms[b][k * piece:(k + 1) * piece])
+    ref += ost.finalize()
+    assert res[1][b] == ref, "oracle mismatch on stream %d" % b
+print("TOKENS", sum(len(t) for t in res[1]))
+""")
+    env = dict(os.environ, NASR_PIPE_ITERS="1", NASR_STATS="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert int(r.stdout.split("TOKENS")[1].split()[0]) > 20
+    stats = [ln for ln in r.stderr.splitlines() if "decode fallbacks" in ln]
+    assert len(stats) == 2
+    n_fallback = int(stats[1].split("decode fallbacks")[1].split()[0])        # second engine = pipelined
+    assert "pipelined" in stats[1] and n_fallback > 0, stats
