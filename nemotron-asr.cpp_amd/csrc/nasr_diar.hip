@@ -489,7 +489,10 @@ static int nasr_diar_load_spk(nasr_diar *d) {
         }
         const std::string se = pre + ".mconv." + std::to_string(5 * (t.repeat - 1) + 3);                 // :151-158
         const auto *f1 = get(d, se + ".fc.0.weight", (size_t)(t.cout / 8) * t.cout), *f2 = get(d, se + ".fc.2.weight", (size_t)t.cout * (t.cout / 8));
-        if (!f1 || !f2 || upload(d, *f1, &blk.fc1) || upload(d, *f2, &blk.fc2)) return -1;
+        // SE gate and embedding layers run on the f32 MFMA (k_encproj: packed weights, K split over the waves): through the
+        // k-ascending parity GEMM their few rows (one per segment) made grids of 12-36 workgroups with K up to 6 144 --
+        // 2.1 of the 4.9 ms of an embedding call
+        if (!f1 || !f2 || upload(d, pack_mfma_f32(*f1, t.cout / 8, t.cout), &blk.fc1) || upload(d, pack_mfma_f32(*f2, t.cout, t.cout / 8), &blk.fc2)) return -1;
     }
     const int C = SPK_C, A = SPK_ATT;
     const std::string dp = "spk.decoder";
@@ -507,7 +510,7 @@ static int nasr_diar_load_spk(nasr_diar *d) {
     if (upload_gemm_weight(d, a1x, nullptr, A, C, C, &d->a1x_w) || upload(d, *a1w, &d->a1_w) || upload(d, *a1b, &d->a1_b) ||
         upload(d, as, &d->a_bn_s) || upload(d, ab, &d->a_bn_b) || upload(d, zeros, &d->zero_bias) ||
         upload_gemm_weight(d, *a2w, nullptr, C, A, A, &d->a2_w) || upload(d, *a2b, &d->a2_b) || upload(d, es, &d->e_bn_s) ||
-        upload(d, ebn, &d->e_bn_b) || upload(d, *ew, &d->emb_w) || upload(d, *eb, &d->emb_b))
+        upload(d, ebn, &d->e_bn_b) || upload(d, pack_mfma_f32(*ew, SPK_EMB, 2 * SPK_C), &d->emb_w) || upload(d, *eb, &d->emb_b))
         return -1;
     const size_t S = (size_t)d->max_segments, M = S * SPK_T;
     char *a = nullptr;
@@ -575,15 +578,9 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
             {   // SE gate before the residual (:303-315, :365-368): masked mean over time, two f32 GEMMs over the segments
                 float *mean = d->se_z + (size_t)d->max_segments * SPK_C, *hid = d->se_h;
                 launch_spk_colmean(d->Y, blk.cout, d->s_lens, mean, St, d->st);
-                GemmParams g1, g2;
-                memset(&g1, 0, sizeof(g1));
-                g1.A = mean; g1.W = blk.fc1; g1.M = St; g1.N = blk.cout / 8; g1.K = blk.cout; g1.lda = blk.cout; g1.splits = 1;
-                g1.epi = EPI_BIAS_RELU_F32; g1.out_f32 = hid; g1.ldo = blk.cout / 8; g1.bias = d->zero_bias;
-                launch_gemm_f32(g1, d->st);
-                memset(&g2, 0, sizeof(g2));
-                g2.A = hid; g2.W = blk.fc2; g2.M = St; g2.N = blk.cout; g2.K = blk.cout / 8; g2.lda = blk.cout / 8; g2.splits = 1;
-                g2.epi = EPI_BIAS_F32; g2.out_f32 = d->se_z; g2.ldo = blk.cout; g2.bias = d->zero_bias;
-                launch_gemm_f32(g2, d->st);
+                launch_encproj(mean, blk.fc1, d->zero_bias, hid, St, blk.cout, blk.cout / 8, d->st);
+                launch_relu(hid, (int64_t)St * (blk.cout / 8), d->st);
+                launch_encproj(hid, blk.fc2, d->zero_bias, d->se_z, St, blk.cout / 8, blk.cout, d->st);
             }
             const float *res = nullptr;
             if (blk.residual) {
@@ -605,13 +602,7 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         launch_spk_att_post(d->att_g, d->att_c, d->a_bn_s, d->a_bn_b, d->A, d->bf16, SPK_ATT, St, d->st);
         spk_gemm(d, d->A, SPK_ATT, d->a2_w, M, SPK_C, SPK_ATT, d->a2_b, false, d->Y);                   // attention logits
         launch_spk_asp(x, d->Y, SPK_C, d->s_lens, d->e_bn_s, d->e_bn_b, d->pool, St, d->st);
-        {
-            GemmParams ge;
-            memset(&ge, 0, sizeof(ge));
-            ge.A = d->pool; ge.W = d->emb_w; ge.M = St; ge.N = SPK_EMB; ge.K = 2 * SPK_C; ge.lda = 2 * SPK_C; ge.splits = 1;
-            ge.epi = EPI_BIAS_F32; ge.out_f32 = d->emb; ge.ldo = SPK_EMB; ge.bias = d->emb_b;
-            launch_gemm_f32(ge, d->st);                                 // [S][6144] x [192][6144]^T, always f32
-        }
+        launch_encproj(d->pool, d->emb_w, d->emb_b, d->emb, St, 2 * SPK_C, SPK_EMB, d->st);      // [S][6144] x [192][6144]^T, always f32
         float *h_emb = (float *)(d->pin + (size_t)d->max_segments * (sizeof(long long) + sizeof(int)));
         DCHK(hipMemcpyAsync(h_emb, d->emb, (size_t)St * SPK_EMB * sizeof(float), hipMemcpyDeviceToHost, d->st));
         DCHK(hipStreamSynchronize(d->st));
