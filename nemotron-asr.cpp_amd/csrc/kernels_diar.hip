@@ -325,18 +325,42 @@ void launch_spk_att_post(const float *g, const float *c, const float *bn_scale, 
 
 // attentive statistics (:432-487): per channel softmax over the valid frames, weighted mean and std; then the folded
 // BN of the embedding layer.  pool = [S][2C] (mu ; sigma)
+// One thread per (segment, channel).  The frame's weight e_t = exp(l_t - max) / Z is computed once and kept in registers (150
+// of them); logits are read once and x twice (for mu, then for sigma around mu), every load of a pass independent of the
+// arithmetic: 3 streams instead of 6 dependent ones (305 -> see DESIGN us for 96 segments).  Same terms in the same order.
 __global__ __launch_bounds__(256) void k_spk_asp(const float *x, const float *logits, int C, const int *lens, const float *sc, const float *bi, float *pool) {
     const int s = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, L = lens[s];
     if (c >= C) return;
     const float *xs = x + (size_t)s * SPK_T * C + c, *ls = logits + (size_t)s * SPK_T * C + c;
+    float e[SPK_TVALID];
+#pragma unroll
+    for (int t = 0; t < SPK_TVALID; t++) e[t] = t < L ? ls[(size_t)t * C] : -INFINITY;     // frames >= L carry -1e9 in the reference: exp() == 0 exactly
     float mx = -INFINITY;
-    for (int t = 0; t < L; t++) mx = fmaxf(mx, ls[(size_t)t * C]);     // frames >= L carry -1e9: exp() == 0 exactly
+#pragma unroll
+    for (int t = 0; t < SPK_TVALID; t++) if (t < L) mx = fmaxf(mx, e[t]);
     float Z = 0.0f;
-    for (int t = 0; t < L; t++) Z += expf(ls[(size_t)t * C] - mx);
+#pragma unroll
+    for (int t = 0; t < SPK_TVALID; t++) if (t < L) { e[t] = expf(e[t] - mx); Z += e[t]; }
+#pragma unroll
+    for (int t = 0; t < SPK_TVALID; t++) e[t] = t < L ? e[t] / Z : 0.0f;
     float mu = 0.0f;
-    for (int t = 0; t < L; t++) mu += xs[(size_t)t * C] * (expf(ls[(size_t)t * C] - mx) / Z);
+#pragma unroll
+    for (int t0 = 0; t0 < SPK_TVALID; t0 += 10) {
+        float xv[10];
+#pragma unroll
+        for (int u = 0; u < 10; u++) xv[u] = t0 + u < L ? xs[(size_t)(t0 + u) * C] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 10; u++) if (t0 + u < L) mu += xv[u] * e[t0 + u];
+    }
     float sg = 0.0f;
-    for (int t = 0; t < L; t++) { const float d = xs[(size_t)t * C] - mu; sg += d * d * (expf(ls[(size_t)t * C] - mx) / Z); }
+#pragma unroll
+    for (int t0 = 0; t0 < SPK_TVALID; t0 += 10) {
+        float xv[10];
+#pragma unroll
+        for (int u = 0; u < 10; u++) xv[u] = t0 + u < L ? xs[(size_t)(t0 + u) * C] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 10; u++) if (t0 + u < L) { const float d = xv[u] - mu; sg += d * d * e[t0 + u]; }
+    }
     // masked frames: x_masked = 0 with weight exp(-1e9 - mx) = 0 -> no contribution to mu or sigma
     sg = sqrtf(fmaxf(sg, 1e-10f));
     pool[(size_t)s * 2 * C + c] = mu * sc[c] + bi[c];
