@@ -195,7 +195,7 @@ __device__ __forceinline__ void store_a(void *base, size_t idx, float v, int bf1
 // depthwise 'same' conv, dilation 1 (src/diarize_spk.cpp:256-282); kernel == 1 is the per-channel scaling of :263-267.
 // out row t >= lens = 0 (the mask in front of the pointwise conv), channels C..Cpad-1 = 0 (K padding of the GEMM).
 // One thread per channel walks a tile of 16 frames with the 16 + kernel - 1 inputs it needs in registers.
-constexpr int DW_TILE = 16, DW_KMAX = 15;
+constexpr int DW_TILE = 32, DW_KMAX = 15;
 __global__ __launch_bounds__(256) void k_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad,
                                                        const int *lens, void *a_out, int out_bf16) {
     const int t0 = blockIdx.x * DW_TILE, s = blockIdx.y, L = lens[s], pad = (kernel - 1) / 2;
