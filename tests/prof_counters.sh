@@ -10,7 +10,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for G in "${GROUPS_[@]}"; do
-  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-profile-pass --no-buffered "$@" > $OUT/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i ($G) failed"; tail -5 $OUT/pmc_${TAG}_$i.log; }
+  if [ -n "$PROF_SCRIPT" ]; then      # another driver script instead of bench.py (e.g. tests/micro/diar_timeline.py)
+    rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -- python3 $GRAFT_REPO_ROOT/$PROF_SCRIPT "$@" > $OUT/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i ($G) failed"; tail -5 $OUT/pmc_${TAG}_$i.log; }
+  else
+    rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-profile-pass --no-buffered "$@" > $OUT/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i ($G) failed"; tail -5 $OUT/pmc_${TAG}_$i.log; }
+  fi
   i=$((i+1))
 done
 python3 - <<PY
