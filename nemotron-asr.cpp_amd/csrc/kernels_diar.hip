@@ -57,36 +57,40 @@ __device__ __forceinline__ void vad_depthwise(const float *x, float *y, const Va
 // then y[t][o] = D * scale[o] + bias[o] (+ what y holds: the residual branch lands on top of the main branch) (relu)
 // (:226-229, :255-265).  Weights are packed at upload in A-fragment order (tile = 16 out channels x 16 k, lane q*16+r
 // holds W[nt*16+r][kg*16+4q..+4)); a wave owns Cout/64 column tiles and walks the four 16-frame tiles.
-template <bool ADD, bool RELU>
-__device__ __forceinline__ void vad_pointwise(const float *x, float *y, const VadSub &s, int lens) {
-    const int KG = s.cin >> 4, NTW = s.cout >> 6;            // k-groups of 16; column tiles per wave (1 or 2)
+// Shapes are compile-time (KG = cin / 16 k-groups, NTW = cout / 64 column tiles per wave): with run-time loop bounds the
+// kernel issued ~13 scalar / vector instructions per MFMA (PMC: 40 % of the wave cycles issuing, profiles/r1g_pmc_diarization.json).
+template <bool ADD, bool RELU, int KG, int NTW>
+__device__ __forceinline__ void vad_pointwise_t(const float *x, float *y, const VadSub &s, int lens) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    // frame masks of the four 16-frame tiles, as multipliers: x * 1 is x exactly, x * 0 replaces the select (inputs are finite)
+    float mk[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) mk[mt] = mt * 16 + r < lens ? 1.0f : 0.0f;
+    const float *xb = x + r * VP + q * 4;
+#pragma unroll
     for (int j = 0; j < NTW; j++) {
         const int nt = wave * NTW + j;
         const float4 *wt = (const float4 *)s.pw + (size_t)nt * KG * 64 + lane;
         const int o = nt * 16 + q * 4;                       // lane holds out channels o..o+3 of frame mt*16 + r
         // every global load of this column tile first (weights of all k-groups, BN scale / bias): one round trip
-        float4 wv[8];
+        float4 wv[KG];
 #pragma unroll
-        for (int kg = 0; kg < 8; kg++) wv[kg] = kg < KG ? wt[(size_t)kg * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int kg = 0; kg < KG; kg++) wv[kg] = wt[(size_t)kg * 64];
         const float4 sc = *(const float4 *)(s.scale + o), bi = *(const float4 *)(s.bias + o);
         f32x4_d acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x4_d){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kg = 0; kg < 8; kg++) {
-            if (kg < KG) {
-                const float4 w = wv[kg];
+        for (int kg = 0; kg < KG; kg++) {
+            const float4 w = wv[kg];
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    const int t = mt * 16 + r;
-                    float4 xv = *(const float4 *)(x + t * VP + kg * 16 + q * 4);
-                    if (t >= lens) xv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, xv.x, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, xv.y, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, xv.z, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, xv.w, acc[mt], 0, 0, 0);
-                }
+            for (int mt = 0; mt < 4; mt++) {
+                float4 xv = *(const float4 *)(xb + mt * 16 * VP + kg * 16);
+                xv.x *= mk[mt]; xv.y *= mk[mt]; xv.z *= mk[mt]; xv.w *= mk[mt];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, xv.x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, xv.y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, xv.z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, xv.w, acc[mt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -98,6 +102,15 @@ __device__ __forceinline__ void vad_pointwise(const float *x, float *y, const Va
             *(float4 *)dst = v;
         }
     }
+}
+template <bool ADD, bool RELU>
+__device__ __forceinline__ void vad_pointwise(const float *x, float *y, const VadSub &s, int lens) {
+    // the MarbleNet shapes (src/diarize_vad.cpp:25-32): 80 -> 128, 128 -> 64, 64 -> 64, 64 -> 128, 128 -> 128
+    if (s.cin == 80) vad_pointwise_t<ADD, RELU, 5, 2>(x, y, s, lens);
+    else if (s.cin == 128 && s.cout == 64) vad_pointwise_t<ADD, RELU, 8, 1>(x, y, s, lens);
+    else if (s.cin == 64 && s.cout == 64) vad_pointwise_t<ADD, RELU, 4, 1>(x, y, s, lens);
+    else if (s.cin == 64) vad_pointwise_t<ADD, RELU, 4, 2>(x, y, s, lens);
+    else vad_pointwise_t<ADD, RELU, 8, 2>(x, y, s, lens);
 }
 
 __global__ __launch_bounds__(256) void k_vad_marblenet(VadNet net, const float *shared, const float *edge, const int *win_row,
