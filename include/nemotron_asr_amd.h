@@ -81,6 +81,11 @@ typedef struct nasr_weight_desc {
     const void *data;   /* host memory, only read during nasr_engine_create */
 } nasr_weight_desc;
 
+/* host utility, no GPU involved: the f32 values nasr_engine_create derives from one GGUF tensor at upload (F16 / Q8_0 /
+ * Q4_0 are dequantised: d * q per block of 32, layouts of scripts/convert_to_gguf.py:118-204).  Returns the number of
+ * elements written or < 0. */
+int64_t nasr_tensor_to_f32(const nasr_weight_desc *t, float *out, int64_t cap);
+
 typedef struct nasr_stream_stats {
     int64_t samples_in;        /* PCM samples pushed                                       */
     int32_t chunks;            /* encoder steps run      (nemo_stream_context::total_chunks_processed) */
@@ -115,10 +120,22 @@ void nasr_engine_destroy(nasr_engine *e);
  * 9 zero mel frames :73-74, cache_valid_len = 0 :81), nemo_stream_reset (:1307-1311),
  * nemo_stream_free (:1313-1317), nemo_stream_set_language (:735-749). ------------------ */
 int nasr_stream_create(nasr_engine *e, int right_context, int prompt_index, nasr_stream **out);
+/* reset == a fresh stream (every cache zeroed) */
 int nasr_stream_reset(nasr_stream *s);
+/* nemo_stream_reset AS CODED in the reference (src/nemo-stream.cpp:95-115, :31-34, :1307-1311): transcript, decoder state,
+ * mel buffer (9 zero frames), cache_valid_len and the counters are reset, but the conv cache and the K/V rows are left as
+ * they are (stale K/V is hidden by the validity mask, the stale conv cache is NOT: the first kernel_size-1 frames after the
+ * reset see it) and the per-stream preprocessor keeps its carry (un-framed samples, last_sample).  NASR_RESET_REFERENCE
+ * reproduces exactly that; the host mirror's nemo_stream_reset() uses it. */
+enum { NASR_RESET_FRESH = 0, NASR_RESET_REFERENCE = 1 };
+int nasr_stream_reset_ex(nasr_stream *s, int mode);
 int nasr_stream_destroy(nasr_stream *s);
 int nasr_stream_set_prompt(nasr_stream *s, int prompt_index);
 int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out);
+/* the host-mirror part of the stats only (samples_in, chunks, cache_valid_len, mel_frames_buffered; reserved = tokens decoded
+ * but not yet handed over; decode_iterations = tokens = -1): no device synchronisation, no copy, does not complete a
+ * pipelined step in flight -- for per-call bookkeeping on a server's hot path */
+int nasr_stream_get_progress(const nasr_stream *s, nasr_stream_stats *out);
 /* timed_token.frame_idx (src/nemo-ggml.h:383-395; time = frame * 1280 / 16000 s): absolute encoder-frame
  * index of tokens [first, first + count) of this stream, counted from create/reset.  Only the most recent
  * 4096 tokens are kept on the device.  Returns the number written, < 0 on error. */
@@ -129,7 +146,9 @@ int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first, int32_t co
  * every full chunk through process_mel_chunk_streaming (:1013-1128: encoder graph compute
  * :1063, decode_one_step per frame :1107-1118) + the mel-buffer shift (:1189-1195).
  * pcm[b] has n_samples[b] samples (0 allowed).  New token ids of stream b are written to
- * tokens_out[b][0..n_tokens[b]) (at most tokens_cap[b]; the count is always the true count). */
+ * tokens_out[b][0..n_tokens[b]), n_tokens[b] <= tokens_cap[b].  Tokens that do not fit are never dropped: they stay queued
+ * on the stream and come out of the next step / collect / finalize call (n_tokens[b] == tokens_cap[b] => call
+ * nasr_engine_collect until it returns fewer).  With tokens_out == NULL the tokens are discarded and counted. */
 int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int B,
                      const int16_t *const *pcm, const int32_t *n_samples,
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens,

@@ -16,12 +16,13 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q8_0 = 0, 1, 2, 8
 FLAG_PCM_DEVICE, FLAG_NO_SYNC = 1, 2
 FLAG_AUDIO_S16 = 4
+RESET_FRESH, RESET_REFERENCE = 0, 1
 TAP_MEL, TAP_SUBSAMPLED, TAP_LAYER_OUT, TAP_ENCODER_OUT, TAP_K_CACHE, TAP_V_CACHE, TAP_CONV_CACHE, TAP_DEC_STATE = range(8)
 
 EXPORTS = [
-    "nasr_last_error", "nasr_abi_version", "nasr_engine_create", "nasr_engine_destroy",
-    "nasr_stream_create", "nasr_stream_reset", "nasr_stream_destroy", "nasr_stream_set_prompt",
-    "nasr_stream_get_stats", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
+    "nasr_last_error", "nasr_abi_version", "nasr_tensor_to_f32", "nasr_engine_create", "nasr_engine_destroy",
+    "nasr_stream_create", "nasr_stream_reset", "nasr_stream_reset_ex", "nasr_stream_destroy", "nasr_stream_set_prompt",
+    "nasr_stream_get_stats", "nasr_stream_get_progress", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize",
@@ -65,11 +66,15 @@ def lib():
         L.nasr_engine_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(HParams), C.POINTER(WeightDesc), C.c_int, C.c_int]
         L.nasr_engine_destroy.argtypes = [vp]
         L.nasr_engine_destroy.restype = None
+        L.nasr_tensor_to_f32.argtypes = [C.POINTER(WeightDesc), C.POINTER(C.c_float), C.c_int64]
+        L.nasr_tensor_to_f32.restype = C.c_int64
         L.nasr_stream_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         for n in ("reset", "destroy"):
             getattr(L, f"nasr_stream_{n}").argtypes = [vp]
         L.nasr_stream_set_prompt.argtypes = [vp, C.c_int]
+        L.nasr_stream_reset_ex.argtypes = [vp, C.c_int]
         L.nasr_stream_get_stats.argtypes = [vp, C.POINTER(StreamStats)]
+        L.nasr_stream_get_progress.argtypes = [vp, C.POINTER(StreamStats)]
         L.nasr_diar_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(WeightDesc), C.c_int, C.c_int, C.c_int]
         L.nasr_diar_destroy.argtypes = [vp]
         L.nasr_diar_destroy.restype = None
@@ -130,8 +135,9 @@ class Stream:
         self.h = h
         self.R, self.T = right_context, 1 + right_context
 
-    def reset(self):
-        _chk(lib().nasr_stream_reset(self.h))
+    def reset(self, reference=False):
+        """reference=True: nemo_stream_reset as the reference codes it (stale conv cache / preprocessor carry survive)"""
+        _chk(lib().nasr_stream_reset_ex(self.h, RESET_REFERENCE if reference else RESET_FRESH))
 
     def set_prompt(self, prompt_index: int):
         _chk(lib().nasr_stream_set_prompt(self.h, prompt_index))
@@ -144,6 +150,12 @@ class Stream:
     def stats(self) -> StreamStats:
         s = StreamStats()
         _chk(lib().nasr_stream_get_stats(self.h, C.byref(s)))
+        return s
+
+    def progress(self) -> StreamStats:
+        """host-mirror counters only: no device synchronisation"""
+        s = StreamStats()
+        _chk(lib().nasr_stream_get_progress(self.h, C.byref(s)))
         return s
 
     def token_frames(self, first=0, count=None) -> list:
@@ -181,6 +193,16 @@ def weight_descs(weights: dict):
             d.ne[j] = 1
         d.data = raw.ctypes.data
     return keep, descs
+
+
+def tensor_to_f32(type_id: int, raw: np.ndarray, shape) -> np.ndarray:
+    """what the engine computes with for one GGUF tensor (host-side dequantisation, no GPU)"""
+    keep, descs = weight_descs({"t": (type_id, raw, tuple(shape))})
+    out = np.zeros(int(np.prod(shape)), np.float32)
+    n = lib().nasr_tensor_to_f32(C.byref(descs[0]), out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+    if n < 0:
+        raise NasrError(lib().nasr_last_error().decode())
+    return out[:n].reshape(shape)
 
 
 class Diar:
@@ -302,6 +324,16 @@ class Engine:
         n = (C.c_int32 * B)()
         return bufs, ptrs, caps, n
 
+    def _gather(self, streams, bufs, tptrs, caps, n, cap):
+        """tokens of the call just made; a full buffer means more may be queued on the stream: collect until drained"""
+        B = len(streams)
+        out = [bufs[b][:n[b]].tolist() for b in range(B)]
+        while any(n[b] >= cap for b in range(B)):
+            _chk(lib().nasr_engine_collect(self.h, self._handles(streams), B, tptrs, caps, n))
+            for b in range(B):
+                out[b] += bufs[b][:n[b]].tolist()
+        return out
+
     def step(self, streams, pcms, flags=0, tok_cap=None):
         """pcms: list of int16 ndarrays (host) or list of (device_ptr, n) when FLAG_PCM_DEVICE."""
         B = len(streams)
@@ -317,7 +349,7 @@ class Engine:
         cap = tok_cap or (total // 1280 + 16) * 10
         bufs, tptrs, caps, n = self._tok_bufs(B, cap)
         _chk(lib().nasr_engine_step(self.h, self._handles(streams), B, ptrs, ns, tptrs, caps, n, flags))
-        return [bufs[b][:min(n[b], cap)].tolist() for b in range(B)]
+        return self._gather(streams, bufs, tptrs, caps, n, cap) if not flags & FLAG_NO_SYNC else [[] for _ in range(B)]
 
     def step_mel(self, streams, mels, flags=0):
         B = len(streams)
@@ -327,19 +359,19 @@ class Engine:
         cap = (max(a.shape[0] for a in arrs) // 8 + 16) * 10
         bufs, tptrs, caps, n = self._tok_bufs(B, cap)
         _chk(lib().nasr_engine_step_mel(self.h, self._handles(streams), B, ptrs, ns, tptrs, caps, n, flags))
-        return [bufs[b][:min(n[b], cap)].tolist() for b in range(B)]
+        return self._gather(streams, bufs, tptrs, caps, n, cap) if not flags & FLAG_NO_SYNC else [[] for _ in range(B)]
 
     def finalize(self, streams):
         B = len(streams)
         bufs, tptrs, caps, n = self._tok_bufs(B, 256)
         _chk(lib().nasr_engine_finalize(self.h, self._handles(streams), B, tptrs, caps, n))
-        return [bufs[b][:n[b]].tolist() for b in range(B)]
+        return self._gather(streams, bufs, tptrs, caps, n, 256)
 
     def collect(self, streams, cap=4096):
         B = len(streams)
         bufs, tptrs, caps, n = self._tok_bufs(B, cap)
         _chk(lib().nasr_engine_collect(self.h, self._handles(streams), B, tptrs, caps, n))
-        return [bufs[b][:min(n[b], cap)].tolist() for b in range(B)]
+        return self._gather(streams, bufs, tptrs, caps, n, cap)
 
     # ---- measurement ------------------------------------------------------------------
     def profile(self, on=True):

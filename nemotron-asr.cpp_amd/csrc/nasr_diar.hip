@@ -245,9 +245,9 @@ void set_audio(const nasr_diar *d, uint32_t flags, DiarMelParams &mp) {
 
 static int nasr_diar_load_spk(nasr_diar *d);
 
-extern "C" void nasr_diar_destroy(nasr_diar *d) {
+// takes no lock: the callers hold the shared API lock already (re-locking a std::shared_mutex the thread holds is undefined)
+static void diar_destroy_impl(nasr_diar *d) {
     if (!d) return;
-    Guard g;
     hipSetDevice(d->device);
     if (d->st) hipStreamSynchronize(d->st);
     for (void *p : d->allocs) hipFree(p);
@@ -260,6 +260,12 @@ extern "C" void nasr_diar_destroy(nasr_diar *d) {
     if (d->pin_audio) hipHostFree(d->pin_audio);
     if (d->st) hipStreamDestroy(d->st);
     delete d;
+}
+
+extern "C" void nasr_diar_destroy(nasr_diar *d) {
+    if (!d) return;
+    Guard g;
+    diar_destroy_impl(d);
 }
 
 extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
@@ -295,13 +301,13 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const
     if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) { delete d; return failf("hipStreamCreate failed"); }
     init_diar_kernel_attributes();
     d->pin_cap = (size_t)(d->max_windows + d->max_segments * SPK_EMB + 4096) * 16;
-    if (hipHostMalloc((void **)&d->pin, d->pin_cap, hipHostMallocDefault) != hipSuccess) { nasr_diar_destroy(d); return failf("hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&d->pin, d->pin_cap, hipHostMallocDefault) != hipSuccess) { diar_destroy_impl(d); return failf("hipHostMalloc failed"); }
     int rc = 0;
     if (d->has_vad) rc |= load_vad(d);
     if (!rc && d->has_spk) rc |= nasr_diar_load_spk(d);
-    if (rc) { api_unlock_shared(); nasr_diar_destroy(d); api_lock_shared(); return -1; }
+    if (rc) { diar_destroy_impl(d); return -1; }
     d->host.clear();
-    if (hipStreamSynchronize(d->st) != hipSuccess) { api_unlock_shared(); nasr_diar_destroy(d); api_lock_shared(); return failf("diar init sync failed"); }
+    if (hipStreamSynchronize(d->st) != hipSuccess) { diar_destroy_impl(d); return failf("diar init sync failed"); }
     *out = d;
     return 0;
 }

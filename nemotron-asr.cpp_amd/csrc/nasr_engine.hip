@@ -291,6 +291,21 @@ static int to_f32(const nasr_weight_desc &d, std::vector<float> &out) {
     return fail("%s: unsupported tensor type %d", d.name, d.type);
 }
 
+// the upload-time conversion as a host utility (no device involved): lets a caller, and the CPU test suite, check what the
+// engine will compute with for a given GGUF tensor
+extern "C" int64_t nasr_tensor_to_f32(const nasr_weight_desc *t, float *out, int64_t cap) {
+    if (!t || !t->data || !out) return fail("null argument");
+    if (t->n_dims < 1 || t->n_dims > 4) return fail("bad n_dims %d", t->n_dims);
+    for (int i = 0; i < t->n_dims; i++)
+        if (t->ne[i] <= 0) return fail("bad extent");
+    const int64_t n = desc_numel(*t);
+    if (n > cap) return fail("output buffer too small (%lld > %lld)", (long long)n, (long long)cap);
+    std::vector<float> v;
+    if (to_f32(*t, v)) return -1;
+    memcpy(out, v.data(), (size_t)n * 4);
+    return n;
+}
+
 struct Loader {
     nasr_engine *e;
     std::map<std::string, const nasr_weight_desc *> by_name;
@@ -736,17 +751,23 @@ static int stage_desc(nasr_engine *e, const std::vector<Tp> &host, const Tp **de
 static int pipe_drain(nasr_engine *e);     // completes a pipelined step that is still in flight (defined with the graph steps)
 
 // ---- streams ------------------------------------------------------------------------------------
-static int stream_zero_state(nasr_stream *s) {
+// keep_reference_state: what the reference's nemo_stream_context::reset() leaves behind (src/nemo-stream.cpp:95-115):
+// encoder_graph.reset() only flips a flag (:31-34) and nothing re-zeroes the cache tensors, and the per-stream
+// preprocessor is not touched -- so the conv cache, the K/V rows (hidden by cache_valid_len = 0: every cached key gets
+// -1e9 and weight exactly 0) and the preprocessor's carry (un-framed samples, last_sample) survive.
+static int stream_zero_state(nasr_stream *s, bool keep_reference_state = false) {
     nasr_engine *e = s->e;
     const size_t slot = (size_t)s->slot, ks1 = (size_t)e->hp.kernel_size - 1;
-    for (int l = 0; l < e->hp.n_layers; l++) {
-        HIPCHK(hipMemsetAsync((char *)e->kv_pool[l] + slot * 2 * KVC * D * e->esz, 0, (size_t)2 * KVC * D * e->esz, e->st));
-        HIPCHK(hipMemsetAsync(e->cc_pool[l] + slot * 2 * ks1 * D, 0, 2 * ks1 * D * 4, e->st));
+    if (!keep_reference_state) {
+        for (int l = 0; l < e->hp.n_layers; l++) {
+            HIPCHK(hipMemsetAsync((char *)e->kv_pool[l] + slot * 2 * KVC * D * e->esz, 0, (size_t)2 * KVC * D * e->esz, e->st));
+            HIPCHK(hipMemsetAsync(e->cc_pool[l] + slot * 2 * ks1 * D, 0, 2 * ks1 * D * 4, e->st));
+        }
+        HIPCHK(hipMemsetAsync(e->abuf + slot * 2 * ABUF_CAP, 0, (size_t)2 * ABUF_CAP * 4, e->st));
+        HIPCHK(hipMemsetAsync(e->last_sample + slot, 0, 4, e->st));
     }
     HIPCHK(hipMemsetAsync(e->dec_h + slot * 4 * HID, 0, 4 * HID * 4, e->st));
     HIPCHK(hipMemsetAsync(e->dec_c + slot * 4 * HID, 0, 4 * HID * 4, e->st));
-    HIPCHK(hipMemsetAsync(e->abuf + slot * 2 * ABUF_CAP, 0, (size_t)2 * ABUF_CAP * 4, e->st));
-    HIPCHK(hipMemsetAsync(e->last_sample + slot, 0, 4, e->st));
     HIPCHK(hipMemsetAsync(e->mel_ring + slot * MEL_RING * NMEL, 0, (size_t)MEL_RING * NMEL * 4, e->st));
     DecCtrl c;
     memset(&c, 0, sizeof(c));
@@ -756,13 +777,15 @@ static int stream_zero_state(nasr_stream *s) {
     const DecCtrl *dsrc;
     if (stage_desc(e, cv, &dsrc)) return -1;
     HIPCHK(hipMemcpyAsync(e->ctrl + slot, dsrc, sizeof(DecCtrl), hipMemcpyDeviceToDevice, e->st));
-    s->abuf_cnt = NFFT / 2;                    // 256 zero samples pre-seeded, src/preprocessor.cpp:220-221
-    s->abuf_par = 0;
+    if (!keep_reference_state) {
+        s->abuf_cnt = NFFT / 2;                // 256 zero samples pre-seeded, src/preprocessor.cpp:220-221
+        s->abuf_par = 0;
+        s->kv_head = 0;
+        s->cc_par = 0;
+    }
     s->mel_start = 0;
-    s->mel_count = PRE_CACHE;                  // 9 literal-zero frames, src/nemo-stream.cpp:73-74
-    s->valid_len = 0;                          // :81
-    s->kv_head = 0;
-    s->cc_par = 0;
+    s->mel_count = PRE_CACHE;                  // 9 literal-zero frames, src/nemo-stream.cpp:73-74 (reset: :100-102)
+    s->valid_len = 0;                          // :81 (reset: :112)
     s->chunks = 0;
     s->tok_read = 0;
     s->samples_in = 0;
@@ -792,16 +815,18 @@ extern "C" int nasr_stream_create(nasr_engine *e, int right_context, int prompt_
     return 0;
 }
 
-extern "C" int nasr_stream_reset(nasr_stream *s) {
+extern "C" int nasr_stream_reset_ex(nasr_stream *s, int mode) {
     ApiGuard api_guard;
     if (!s) return fail("null stream");
+    if (mode != NASR_RESET_FRESH && mode != NASR_RESET_REFERENCE) return fail("unknown reset mode %d", mode);
     HIPCHK(hipSetDevice(s->e->device));
     if (pipe_drain(s->e)) return -1;
     s->tok_queue.clear();
-    // NOTE: the reference's reset leaves stale conv-cache/K/V contents in place
-    // (src/nemo-stream.cpp:95-115); here a reset stream == a fresh stream.
-    return stream_zero_state(s);
+    return stream_zero_state(s, mode == NASR_RESET_REFERENCE);
 }
+
+// a reset stream == a fresh stream; the reference's own reset is NASR_RESET_REFERENCE (see stream_zero_state)
+extern "C" int nasr_stream_reset(nasr_stream *s) { return nasr_stream_reset_ex(s, NASR_RESET_FRESH); }
 
 extern "C" int nasr_stream_destroy(nasr_stream *s) {
     ApiGuard api_guard;
@@ -1259,15 +1284,21 @@ static int consume_collect(nasr_engine *e, const int *host, nasr_stream *const *
     return 0;
 }
 
-// hands the queued tokens of the B streams to the caller (at most tokens_cap[b]; the count is the true count)
+// hands the queued tokens of the B streams to the caller: at most tokens_cap[b] of them, n_tokens[b] = the number written.
+// What does not fit STAYS queued and comes out of the next step / collect / finalize call (nothing is ever dropped); a
+// caller that passes no buffer at all (null tokens_out) discards its tokens by contract and gets the count it discarded.
 static void deliver(nasr_stream *const *streams, int B, int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     for (int b = 0; b < B; b++) {
         std::vector<int32_t> &q = streams[b]->tok_queue;
-        const int cap = tokens_out && tokens_out[b] && tokens_cap ? tokens_cap[b] : 0;
-        const int n_copy = std::min((int)q.size(), cap);
+        if (!tokens_out || !tokens_out[b] || !tokens_cap) {
+            if (n_tokens) n_tokens[b] = (int32_t)q.size();
+            q.clear();
+            continue;
+        }
+        const int n_copy = std::min((int)q.size(), std::max(tokens_cap[b], 0));
         for (int i = 0; i < n_copy; i++) tokens_out[b][i] = q[(size_t)i];
-        if (n_tokens) n_tokens[b] = (int32_t)q.size();
-        q.clear();
+        if (n_tokens) n_tokens[b] = n_copy;
+        q.erase(q.begin(), q.begin() + n_copy);
     }
 }
 
@@ -1933,6 +1964,20 @@ extern "C" int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first,
     HIPCHK(hipMemcpy(ring.data(), e->tok_frame + (size_t)s->slot * TOK_CAP, TOK_CAP * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < count; i++) frames_out[i] = ring[(size_t)((first + i) & (TOK_CAP - 1))];
     return count;
+}
+
+// host mirror only: no pipeline drain, no stream synchronisation, no copy (the per-call path of a server)
+extern "C" int nasr_stream_get_progress(const nasr_stream *s, nasr_stream_stats *out) {
+    if (!s || !out) return fail("null argument");
+    memset(out, 0, sizeof(*out));
+    out->samples_in = s->samples_in;
+    out->chunks = s->chunks;
+    out->decode_iterations = -1;               // device counters: nasr_stream_get_stats
+    out->tokens = -1;
+    out->cache_valid_len = s->valid_len;
+    out->mel_frames_buffered = s->mel_count;
+    out->reserved = (int32_t)s->tok_queue.size();   // tokens decoded but not yet handed to the caller
+    return 0;
 }
 
 extern "C" int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out) {

@@ -22,20 +22,39 @@ def _wstr(f, s):
     f.write(b)
 
 
-def default_hparams(n_layers=24, num_prompts=0):
+def default_hparams(n_layers=24, num_prompts=0, kernel_size=9, vocab_size=1025):
+    """the `nemo.*` keys in the order the reference converter writes them (scripts/convert_to_gguf.py:356-371)"""
     return {"nemo.n_mels": 128, "nemo.d_model": 1024, "nemo.n_heads": 8, "nemo.d_head": 128, "nemo.d_ff": 4096,
-            "nemo.n_layers": n_layers, "nemo.vocab_size": 1025, "nemo.decoder_dim": 640, "nemo.joint_dim": 640,
-            "nemo.subsampling_factor": 8, "nemo.att_left_context": 70, "nemo.num_prompts": num_prompts}
+            "nemo.n_layers": n_layers, "nemo.kernel_size": kernel_size, "nemo.vocab_size": vocab_size, "nemo.decoder_dim": 640,
+            "nemo.joint_dim": 640, "nemo.subsampling_factor": 8, "nemo.att_left_context": 70, "nemo.num_prompts": num_prompts}
 
 
 def synthetic_vocab(n=1024):
-    """SentencePiece-like pieces: a third start a word (U+2581 prefix)."""
-    return [("▁" if i % 3 == 0 else "") + f"t{i}" for i in range(n)]
+    """SentencePiece-like pieces: a third start a word (U+2581 prefix); every piece fits a legacy 8-byte record."""
+    return [("▁" if i % 3 == 0 else "") + "t" + np.base_repr(i, 36).lower() for i in range(n)]
+
+
+LEGACY_WORD = 8
+
+
+def pack_vocab_legacy(vocab):
+    """fixed 8-byte NUL-terminated records, or None when a token does not fit -- the converter then omits the KV
+    (scripts/convert_to_gguf.py:288-306; reader: src/nemo-ggml.cpp:156-165)"""
+    enc = [t.encode() for t in vocab]
+    if any(len(e) + 1 > LEGACY_WORD for e in enc):
+        return None
+    return b"".join(e.ljust(LEGACY_WORD, b"\0") for e in enc)
 
 
 def write_gguf(path, weights: dict, hparams: dict, vocab: list, prompt_dict: dict | None = None,
                legacy_vocab_blob=False, name="synthetic-nemotron"):
-    """weights: name -> float32 ndarray, or (ggml_type, raw uint8/float16 ndarray, shape)."""
+    """weights: name -> float32 ndarray, or (ggml_type, raw uint8/float16 ndarray, shape).
+    Byte-for-byte the file the reference converter writes for the same content (tests/test_gguf_reference_fixtures.py).
+    legacy_vocab_blob: also write `tokenizer.vocab` when every token fits (the converter always does)."""
+    blob = pack_vocab_legacy(vocab) if legacy_vocab_blob else None
+    legacy_vocab_blob = blob is not None
+    if prompt_dict:
+        prompt_dict = {k: prompt_dict[k] for k in sorted(prompt_dict)}     # :381-383
     infos, off = [], 0
     for nm, v in weights.items():
         if isinstance(v, tuple):
@@ -59,7 +78,6 @@ def write_gguf(path, weights: dict, hparams: dict, vocab: list, prompt_dict: dic
         for s in vocab:
             _wstr(f, s)
         if legacy_vocab_blob:   # fixed 8-byte NUL-padded records (src/nemo-ggml.cpp:156-165)
-            blob = b"".join(s.encode()[:8].ljust(8, b"\0") for s in vocab)
             _wstr(f, "tokenizer.vocab"); f.write(struct.pack("<i", T_STRING)); _wstr(f, blob)
         if prompt_dict:
             langs = list(prompt_dict)

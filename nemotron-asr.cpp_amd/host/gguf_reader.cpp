@@ -1,6 +1,7 @@
 // gguf_reader.cpp -- see gguf_reader.h
 #include "gguf_reader.h"
 
+#include <cstdint>
 #include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -108,16 +109,25 @@ bool GgufFile::open(const std::string &path, std::string &err) {
         t.n_dims = (int32_t)c.get<uint32_t>();
         if (!c.ok || t.n_dims < 0 || t.n_dims > 4) { err = "bad tensor info"; return false; }
         int64_t numel = 1;
-        for (int d = 0; d < t.n_dims; d++) { t.ne[d] = c.get<int64_t>(); numel *= t.ne[d]; }
+        for (int d = 0; d < t.n_dims; d++) {
+            t.ne[d] = c.get<int64_t>();
+            // every extent positive, product checked against overflow (a corrupt header must not wrap numel)
+            if (!c.ok || t.ne[d] <= 0 || numel > (int64_t)(INT64_MAX / 64) / t.ne[d]) { err = "bad tensor shape: " + t.name; return false; }
+            numel *= t.ne[d];
+        }
         t.type = c.get<int32_t>();
         t.offset = c.get<uint64_t>();
         t.nbytes = ggml_type_nbytes(t.type, numel);
         if (!c.ok || t.nbytes == 0) { err = "unsupported tensor type/shape: " + t.name; return false; }
     }
+    if (alignment == 0 || (alignment & (alignment - 1)) != 0) { err = "general.alignment must be a power of two"; return false; }
     data_start_ = ((uint64_t)(c.p - map_) + alignment - 1) / alignment * alignment;
+    if (data_start_ > map_size_) { err = "tensor data section starts past the end of the file"; return false; }
+    const uint64_t data_size = map_size_ - data_start_;
     for (size_t i = 0; i < tensors_.size(); i++) {
         auto &t = tensors_[i];
-        if (data_start_ + t.offset + t.nbytes > map_size_) { err = "tensor data out of file bounds: " + t.name; return false; }
+        // written so that a huge offset cannot wrap the sum
+        if (t.offset > data_size || t.nbytes > data_size - t.offset) { err = "tensor data out of file bounds: " + t.name; return false; }
         t.data = map_ + data_start_ + t.offset;
         by_name_[t.name] = i;
     }

@@ -227,10 +227,19 @@ bool nemo_stream_process_batch(nemo_stream_context *const *sctx, int B, const in
         nemo_stream_context *s = sctx[b];
         s->total_audio_seconds += (double)ns[b] / s->config.sample_rate;
         s->total_compute_seconds += dt / B;
-        std::string text = absorb(s, buf[b].data(), cnt[b] < cap[b] ? cnt[b] : cap[b]);
+        std::string text = absorb(s, buf[b].data(), cnt[b]);
+        // a full buffer: more tokens may be queued on the stream (nothing is dropped below the ABI) -- fetch them now
+        while (cnt[b] >= cap[b]) {
+            if (nasr_engine_collect(s->nctx->engine, &st[b], 1, &ptr[b], &cap[b], &cnt[b]) < 0) {
+                fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+                return false;
+            }
+            text += absorb(s, buf[b].data(), cnt[b]);
+        }
         if (out) out[b] = text;
+        // host-mirror counter: no device synchronisation on the per-call path (a pipelined step stays in flight)
         nasr_stream_stats stt;
-        if (nasr_stream_get_stats(s->stream, &stt) == 0) s->total_chunks_processed = stt.chunks;
+        if (nasr_stream_get_progress(s->stream, &stt) == 0) s->total_chunks_processed = stt.chunks;
     }
     return true;
 }
@@ -250,7 +259,16 @@ std::string nemo_stream_finalize(nemo_stream_context *sctx) {
         fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
         return "";
     }
-    return absorb(sctx, tok, cnt < cap ? cnt : cap);       // only the text produced by the tail flush (:1292)
+    // the text produced by the tail flush (:1292) -- with pipelined steps also the step that was still in flight
+    std::string text = absorb(sctx, tok, cnt);
+    while (cnt >= cap) {
+        if (nasr_engine_collect(sctx->nctx->engine, &sctx->stream, 1, &tp, &cap, &cnt) < 0) {
+            fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+            break;
+        }
+        text += absorb(sctx, tok, cnt);
+    }
+    return text;
 }
 
 std::string nemo_stream_get_transcript(nemo_stream_context *sctx) { return sctx ? sctx->transcript : ""; }
@@ -262,7 +280,8 @@ const std::vector<int> &nemo_stream_get_tokens(nemo_stream_context *sctx) {
 
 void nemo_stream_reset(nemo_stream_context *sctx) {
     if (!sctx) return;
-    nasr_stream_reset(sctx->stream);
+    // the reference's reset as coded (src/nemo-stream.cpp:95-115): the conv cache and the preprocessor carry survive
+    nasr_stream_reset_ex(sctx->stream, NASR_RESET_REFERENCE);
     sctx->tokens.clear();
     sctx->transcript.clear();
     sctx->total_audio_seconds = sctx->total_compute_seconds = 0;

@@ -281,9 +281,18 @@ QUANT_PATTERN = r"encoder\.layers\.\d+\.(feed_forward\d+|self_attn|conv)\.[^.]+\
 TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q8_0 = 0, 1, 2, 8
 
 
+def _blocks32(x: np.ndarray) -> np.ndarray:
+    """flattened, zero padded to a multiple of 32 (the converter pads a ragged tail, scripts/convert_to_gguf.py:129-132)"""
+    v = np.ascontiguousarray(x, np.float32).reshape(-1)
+    if v.size % 32:
+        v = np.concatenate([v, np.zeros(32 - v.size % 32, np.float32)])
+    return v.reshape(-1, 32)
+
+
 def pack_q8_0(x: np.ndarray) -> np.ndarray:
-    """34-byte blocks: f16 scale (amax/127) + 32 int8."""
-    b = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    """34-byte blocks: f16 scale (amax/127) + 32 int8 = round-half-even(x / f16 scale), no clip
+    (byte-identical to the reference converter's quantize_q8_0: tests/test_gguf_reference_fixtures.py)."""
+    b = _blocks32(x)
     sc = (np.abs(b).max(axis=1) / 127.0).astype(np.float16)
     s32 = sc.astype(np.float32)[:, None]
     q = np.where(s32 != 0, np.round(b / np.where(s32 != 0, s32, 1.0)), 0).astype(np.int8)
@@ -298,8 +307,9 @@ def unpack_q8_0(raw: np.ndarray, shape) -> np.ndarray:
 
 
 def pack_q4_0(x: np.ndarray) -> np.ndarray:
-    """18-byte blocks: f16 scale (amax/7) + 16 bytes, low nibble = elements 0..15, high = 16..31."""
-    b = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    """18-byte blocks: f16 scale (amax/7) + 16 bytes, low nibble = elements 0..15, high = 16..31; values
+    round-half-even(x / f16 scale) clipped to [-8, 7] (byte-identical to the reference converter's quantize_q4_0)."""
+    b = _blocks32(x)
     sc = (np.abs(b).max(axis=1) / 7.0).astype(np.float16)
     s32 = sc.astype(np.float32)[:, None]
     q = np.clip(np.where(s32 != 0, np.round(b / np.where(s32 != 0, s32, 1.0)), 0), -8, 7).astype(np.int8)
@@ -318,12 +328,14 @@ def unpack_q4_0(raw: np.ndarray, shape) -> np.ndarray:
 
 
 def quantize_weights(W: dict, kind: str):
-    """Returns (engine_weights, dequantised_f32_weights): tensors matching QUANT_PATTERN (except the
-    depthwise conv, convert_to_gguf.py:237-243) are stored as `kind` in {"f16","q8_0","q4_0"}."""
+    """Returns (engine_weights, dequantised_f32_weights): the tensors the reference converter would store as `kind` in
+    {"f16","q8_0","q4_0"} -- QUANT_PATTERN, never the depthwise conv (convert_to_gguf.py:237-243), at least 256 elements
+    and at least 2 dimensions (:413-419: conv.batch_norm.weight matches the pattern but is 1-D and stays F32), i.e. the
+    11 matrices of a layer: FFN 2 x 2, attention q/k/v/pos/out, pointwise conv 1/2."""
     import re
     eng, deq = {}, {}
     for name, a in W.items():
-        if re.search(QUANT_PATTERN, name) and "depthwise_conv" not in name and a.size % 32 == 0:
+        if re.search(QUANT_PATTERN, name) and "depthwise_conv" not in name and a.size >= 256 and a.ndim >= 2 and a.size % 32 == 0:
             if kind == "f16":
                 h = a.astype(np.float16)
                 eng[name], deq[name] = (TYPE_F16, h, a.shape), h.astype(np.float32)

@@ -56,6 +56,10 @@ def lib():
         L.orc_model_create.restype = C.c_void_p
         L.orc_model_create.argtypes = [C.c_int] * 4
         L.orc_model_set_tensor.argtypes = [C.c_void_p, C.c_char_p, _fp, C.c_int64]
+        L.orc_model_set_tensor_q8_0.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+        L.orc_stream_reset_reference.argtypes = [C.c_void_p]
+        L.orc_stream_enable_decision_log.argtypes = [C.c_void_p, C.c_int]
+        L.orc_stream_decision_log.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip, _fp, C.c_int]
         L.orc_model_finalize.argtypes = [C.c_void_p]
         L.orc_model_free.argtypes = [C.c_void_p]
         L.orc_preproc_create.restype = C.c_void_p
@@ -89,19 +93,33 @@ def lib():
     return _lib
 
 
+EMU_BF16, EMU_Q8_ACT = 1, 2
+
+
 class OracleModel:
+    """weights: name -> float32 ndarray.  q8_blocks (with emulate_q8_act=True): name -> raw Q8_0 bytes of the encoder-layer
+    matrices whose dequantised values are in `weights`: those are then multiplied with ggml-CPU semantics (activation rows
+    quantised per 32, int8 dot products) instead of f32."""
+
     def __init__(self, weights: dict, n_layers: int, kernel_size: int = 9, num_prompts: int = 0,
-                 emulate_bf16: bool = False):
+                 emulate_bf16: bool = False, emulate_q8_act: bool = False, q8_blocks: dict = None):
         L = lib()
         self.n_layers, self.kernel_size = n_layers, kernel_size
         self._keep = {}
-        self.h = L.orc_model_create(n_layers, kernel_size, num_prompts, int(emulate_bf16))
+        self.h = L.orc_model_create(n_layers, kernel_size, num_prompts,
+                                    (EMU_BF16 if emulate_bf16 else 0) | (EMU_Q8_ACT if emulate_q8_act else 0))
         for name, arr in weights.items():
             a = np.ascontiguousarray(arr, dtype=np.float32)
             self._keep[name] = a
             rc = L.orc_model_set_tensor(self.h, name.encode(), _f(a), a.size)
             if rc != 0:
                 raise ValueError(f"oracle rejected tensor {name} {a.shape}")
+        for name, raw in (q8_blocks or {}).items():
+            r = np.ascontiguousarray(raw).view(np.uint8)
+            self._keep["q8:" + name] = r
+            numel = r.size // 34 * 32
+            if L.orc_model_set_tensor_q8_0(self.h, name.encode(), r.ctypes.data, numel) != 0:
+                raise ValueError(f"oracle rejected Q8_0 blocks of {name}")
         if L.orc_model_finalize(self.h) != 0:
             raise ValueError("oracle model incomplete")
 
@@ -164,8 +182,22 @@ class OracleStream:
             lib().orc_stream_free(self.h)
             self.h = None
 
-    def reset(self):
-        lib().orc_stream_reset(self.h)
+    def reset(self, reference=False):
+        """reference=True: nemo_stream_reset as the reference codes it (caches and preprocessor carry survive)"""
+        (lib().orc_stream_reset_reference if reference else lib().orc_stream_reset)(self.h)
+
+    def enable_decision_log(self, on=True):
+        lib().orc_stream_enable_decision_log(self.h, int(on))
+
+    def decision_log(self):
+        """one record per LSTM+joint evaluation: dict of arrays frame, ntok_before, best, second, margin"""
+        n = lib().orc_stream_decision_log(self.h, None, None, None, None, None, 0)
+        a = {k: np.zeros(max(n, 1), np.int32) for k in ("frame", "ntok_before", "best", "second")}
+        mg = np.zeros(max(n, 1), np.float32)
+        lib().orc_stream_decision_log(self.h, *[a[k].ctypes.data_as(_ip) for k in ("frame", "ntok_before", "best", "second")], _f(mg), n)
+        out = {k: v[:n] for k, v in a.items()}
+        out["margin"] = mg[:n]
+        return out
 
     def enable_taps(self):
         sub = np.zeros((self.T, 1024), np.float32)
@@ -241,6 +273,35 @@ class OracleStream:
         h = np.zeros(1280, np.float32); c = np.zeros(1280, np.float32); p = C.c_int(0)
         lib().orc_stream_get_decoder_state(self.h, _f(h), _f(c), C.byref(p))
         return h, c, p.value
+
+
+def first_divergence(log: dict, ref_tokens, ref_frames, got_tokens, got_frames):
+    """Where a reduced-precision engine's greedy path leaves the oracle's.  Returns None when the two token streams
+    (ids and emission frames) are identical, else a dict: index of the first differing token, the oracle decision (one
+    LSTM+joint evaluation) at which the engine chose differently, and that decision's top-2 logit margin in the oracle.
+    The engine only reports emissions; the decision is recovered from them: with i tokens in common, the engine emitted
+    earlier than the oracle (=> the oracle's BLANK decision at that frame with i tokens out), later or never (=> the oracle's
+    emission decision of token i), or another token at the same frame (=> that same emission decision)."""
+    n = min(len(ref_tokens), len(got_tokens))
+    i = 0
+    while i < n and ref_tokens[i] == got_tokens[i] and ref_frames[i] == got_frames[i]:
+        i += 1
+    if i == len(ref_tokens) and i == len(got_tokens):
+        return None
+    if i < len(got_tokens) and (i >= len(ref_tokens) or got_frames[i] < ref_frames[i]):
+        frame, want_blank = got_frames[i], True       # the engine emitted where the oracle said blank
+    else:
+        frame, want_blank = ref_frames[i], False      # the engine said blank / something else where the oracle emitted token i
+    sel = np.nonzero((log["frame"] == frame) & (log["ntok_before"] == i))[0]
+    if sel.size != 1:
+        return dict(index=i, frame=int(frame), decision=-1, margin=float("nan"), oracle_best=-1, oracle_second=-1)
+    k = int(sel[0])
+    assert (log["best"][k] == BLANK_ID) == want_blank
+    return dict(index=i, frame=int(frame), decision=k, margin=float(log["margin"][k]), oracle_best=int(log["best"][k]),
+                oracle_second=int(log["second"][k]), engine_choice=(int(got_tokens[i]) if i < len(got_tokens) and got_frames[i] == frame else BLANK_ID))
+
+
+BLANK_ID = 1024
 
 
 def pos_emb(position: int) -> np.ndarray:

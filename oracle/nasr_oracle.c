@@ -90,6 +90,81 @@ static void gemm_nt(const float *x, int M, int K, const float *w, int N,
     }
 }
 
+/* ---- ggml-CPU semantics of a mul_mat with a Q8_0 weight (emulation, see nasr_oracle.h "Q8_0 activations") ----------
+ * ggml is an un-vendored, empty submodule of the reference (pin unrecoverable), so this follows ggml's PUBLISHED scalar
+ * algorithm, not code in /root/reference: for src0 = Q8_0 weights and src1 = f32 activations, ggml_compute_forward_mul_mat
+ * converts every activation row to the weight type's vec_dot_type (Q8_0) with quantize_row_q8_0 and calls
+ * ggml_vec_dot_q8_0_q8_0 per (row, column):
+ *   quantize_row_q8_0:  per block of 32: amax = max |x|, d = amax / 127, id = d ? 1/d : 0, q_i = roundf(x_i * id)
+ *                       (round half away from zero), block scale stored as fp16(d)
+ *   vec_dot_q8_0_q8_0:  sumf += (float)(sum_i qw_i * qa_i) * (fp16->f32(dw) * fp16->f32(da)), blocks in ascending order
+ * (the SIMD paths accumulate the same products in 8 float lanes; differences at the 1e-7 relative level).
+ * Block layout = scripts/convert_to_gguf.py:118-154 of the reference: 34 bytes = fp16 d + 32 int8. */
+static float f16_bits_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ffu, f;
+    if (exp == 0) {
+        if (man == 0) f = sign;
+        else {
+            exp = 127 - 15 + 1;
+            while (!(man & 0x400u)) { man <<= 1; exp--; }
+            man &= 0x3ffu;
+            f = sign | (exp << 23) | (man << 13);
+        }
+    } else if (exp == 31) f = sign | 0x7f800000u | (man << 13);
+    else f = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float r;
+    memcpy(&r, &f, 4);
+    return r;
+}
+static uint16_t f32_to_f16_bits(float x) { /* round to nearest even, like GGML_FP32_TO_FP16 (F16C / _cvtss_sh) */
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (u > 0x7f800000u ? 0x200u : 0));
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);         /* >= 65520 rounds to inf */
+    if (u < 0x33000001u) return (uint16_t)sign;                      /* < 2^-25 (+ ties to even) -> 0 */
+    int e = (int)(u >> 23) - 127;
+    uint32_t man = (u & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                       /* subnormal halves lose more bits */
+    uint32_t half_man = man >> shift, rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half_man & 1u))) half_man++;
+    uint32_t out = e < -14 ? half_man : (((uint32_t)(e + 15) << 10) + (half_man - 0x400u));
+    return (uint16_t)(sign | out);
+}
+
+static void gemm_q8_0(const float *x, int M, int K, const uint8_t *wq, int N, const float *bias, float *out) {
+    const int nb = K / 32;
+    int8_t *aq = (int8_t *)xmalloc((size_t)M * K);
+    float *ad = (float *)xmalloc(sizeof(float) * (size_t)M * nb);
+    for (int m = 0; m < M; m++)
+        for (int b = 0; b < nb; b++) {
+            const float *xb = x + (size_t)m * K + b * 32;
+            float amax = 0.0f;
+            for (int i = 0; i < 32; i++) { float v = fabsf(xb[i]); if (v > amax) amax = v; }
+            const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+            ad[(size_t)m * nb + b] = f16_bits_to_f32(f32_to_f16_bits(d));
+            for (int i = 0; i < 32; i++) aq[(size_t)m * K + b * 32 + i] = (int8_t)roundf(xb[i] * id);
+        }
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; n++) {
+        const uint8_t *wr = wq + (size_t)n * nb * 34;
+        for (int m = 0; m < M; m++) {
+            float sumf = 0.0f;
+            for (int b = 0; b < nb; b++) {
+                uint16_t hd;
+                memcpy(&hd, wr + (size_t)b * 34, 2);
+                const int8_t *qw = (const int8_t *)(wr + (size_t)b * 34 + 2), *qa = aq + (size_t)m * K + b * 32;
+                int sumi = 0;
+                for (int i = 0; i < 32; i++) sumi += (int)qw[i] * (int)qa[i];
+                sumf += (float)sumi * (f16_bits_to_f32(hd) * ad[(size_t)m * nb + b]);
+            }
+            out[(size_t)m * N + n] = bias ? (bias[n] + sumf) : sumf;
+        }
+    }
+    free(aq); free(ad);
+}
+
 /* LayerNorm, biased variance, eps literal 1e-5 (src/nemo-stream.cpp:580-591,
  * src/reference/ops.cpp:72-108) */
 static void layer_norm_rows(const float *x, int M, int D, const float *w, const float *b,
@@ -124,8 +199,12 @@ typedef struct {
     const float *wpos_f32; /* un-rounded linear_pos (P is computed in f32, then rounded) */
 } orc_layer;
 
+typedef struct { const float *key; const uint8_t *blocks; } q8_entry;
+
 struct orc_model {
     int n_layers, kernel_size, num_prompts, emulate_bf16;
+    int emulate_q8_act;            /* ggml-CPU Q8_0 mul_mat semantics for tensors registered with orc_model_set_tensor_q8_0 */
+    q8_entry *q8; int n_q8, cap_q8;
     const float *fb, *window;
     const float *conv0_w, *conv0_b, *conv2_w, *conv2_b, *conv3_w, *conv3_b;
     const float *conv5_w, *conv5_b, *conv6_w, *conv6_b, *sub_out_w, *sub_out_b;
@@ -138,12 +217,27 @@ struct orc_model {
     int n_owned, cap_owned;
 };
 
-orc_model *orc_model_create(int n_layers, int kernel_size, int num_prompts, int emulate_bf16) {
+static const uint8_t *q8_of(const orc_model *m, const float *w) {
+    if (!m->emulate_q8_act) return NULL;
+    for (int i = 0; i < m->n_q8; i++)
+        if (m->q8[i].key == w) return m->q8[i].blocks;
+    return NULL;
+}
+
+/* the linear layers of the encoder: f32 GEMM, or the Q8_0 x Q8_0 product when the weight was registered as blocks */
+static void gemm_w(const orc_model *m, const float *x, int M, int K, const float *w, int N, const float *bias, float *out) {
+    const uint8_t *q = q8_of(m, w);
+    if (q) gemm_q8_0(x, M, K, q, N, bias, out);
+    else gemm_nt(x, M, K, w, N, bias, out);
+}
+
+orc_model *orc_model_create(int n_layers, int kernel_size, int num_prompts, int emulate) {
     orc_model *m = (orc_model *)xcalloc(1, sizeof(*m));
     m->n_layers = n_layers;
     m->kernel_size = kernel_size;
     m->num_prompts = num_prompts;
-    m->emulate_bf16 = emulate_bf16;
+    m->emulate_bf16 = (emulate & ORC_EMU_BF16) ? 1 : 0;
+    m->emulate_q8_act = (emulate & ORC_EMU_Q8_ACT) ? 1 : 0;
     m->layers = (orc_layer *)xcalloc((size_t)n_layers, sizeof(orc_layer));
     return m;
 }
@@ -153,6 +247,7 @@ void orc_model_free(orc_model *m) {
     for (int i = 0; i < m->n_owned; i++) free(m->owned[i]);
     free(m->owned);
     free(m->layers);
+    free(m->q8);
     free(m);
 }
 
@@ -274,6 +369,33 @@ int orc_model_set_tensor(orc_model *m, const char *name, const float *data, int6
         }
         const float **slot = (const float **)((char *)m + s->off);
         *slot = (m->emulate_bf16 && s->round == 1) ? own_rounded(m, data, numel) : data;
+        return 0;
+    }
+    return -1;
+}
+
+/* registers the Q8_0 blocks of an encoder-layer matrix that orc_model_set_tensor() already received (dequantised values) */
+int orc_model_set_tensor_q8_0(orc_model *m, const char *name, const uint8_t *blocks, int64_t numel) {
+    static const char *lp = "encoder.layers.";
+    if (strncmp(name, lp, strlen(lp)) != 0 || numel % 32) return -1;
+    char *end = NULL;
+    long l = strtol(name + strlen(lp), &end, 10);
+    if (!end || *end != '.' || l < 0) return -1;
+    if (l >= m->n_layers) return 0;
+    for (size_t i = 0; i < sizeof(k_layer_slots) / sizeof(k_layer_slots[0]); i++) {
+        const layer_slot *sl = &k_layer_slots[i];
+        if (strcmp(end + 1, sl->suffix) != 0) continue;
+        if (sl->numel != numel) return -1;
+        const float *key = *(const float **)((char *)&m->layers[l] + sl->off);
+        if (!key) return -1;
+        if (sl->round == 2) key = m->layers[l].wpos_f32;     /* linear_pos is used through wpos_f32 */
+        if (m->n_q8 == m->cap_q8) {
+            m->cap_q8 = m->cap_q8 ? 2 * m->cap_q8 : 64;
+            m->q8 = (q8_entry *)realloc(m->q8, (size_t)m->cap_q8 * sizeof(q8_entry));
+        }
+        m->q8[m->n_q8].key = key;
+        m->q8[m->n_q8].blocks = blocks;
+        m->n_q8++;
         return 0;
     }
     return -1;
@@ -519,6 +641,10 @@ struct orc_stream {
     int frames_total;       /* encoder frames decoded so far: timed_token.frame_idx (src/nemo-ggml.h:383-395) */
     int *tok_frames; int n_tok_frames, cap_tok_frames;
     float *tap_sub, *tap_layers;
+    /* decision log (orc_stream_enable_decision_log): one record per LSTM+joint evaluation */
+    int log_on, n_log, cap_log;
+    int *log_frame, *log_ntok, *log_best, *log_second;
+    float *log_margin;
 };
 
 static void stream_build_posproj(orc_stream *s) {
@@ -529,7 +655,7 @@ static void stream_build_posproj(orc_stream *s) {
     for (int r = 0; r < s->n_rel; r++) orc_pos_emb((ORC_LEFT_CTX + s->T - 1) - r, emb + (size_t)r * ORC_D_MODEL);
     for (int l = 0; l < m->n_layers; l++) {
         float *P = s->posproj + (size_t)l * s->n_rel * ORC_D_MODEL;
-        gemm_nt(emb, s->n_rel, ORC_D_MODEL, m->layers[l].wpos_f32, ORC_D_MODEL, NULL, P); /* :516 */
+        gemm_w(m, emb, s->n_rel, ORC_D_MODEL, m->layers[l].wpos_f32, ORC_D_MODEL, NULL, P); /* :516 */
         if (m->emulate_bf16) round_bf16_inplace(P, (int64_t)s->n_rel * ORC_D_MODEL);
     }
     free(emb);
@@ -554,7 +680,41 @@ void orc_stream_reset(orc_stream *s) {
     s->decode_iterations = 0;
     s->frames_total = 0;
     s->n_tok_frames = 0;
+    s->n_log = 0;
     if (s->pp) orc_preproc_reset(s->pp);
+}
+
+/* nemo_stream_context::reset() AS CODED (src/nemo-stream.cpp:95-115): decoder state, mel buffer (9 zero frames), token /
+ * timing counters and cache_valid_len are reset; encoder_graph.reset() only flips a flag (:31-34) that nothing reads
+ * afterwards, so the K/V and conv cache tensors keep their contents, and the per-stream preprocessor (audio_buf carry,
+ * last_sample) is not touched.  Stale K/V rows are invisible (valid_len = 0 masks all 70 cached keys); the stale conv
+ * cache is seen by the first kernel_size-1 frames. */
+void orc_stream_reset_reference(orc_stream *s) {
+    s->cache_valid_len = 0;
+    memset(s->h, 0, sizeof(s->h));
+    memset(s->c, 0, sizeof(s->c));
+    s->prev_token = ORC_BLANK;
+    s->n_mel = ORC_PRE_CACHE;
+    memset(s->mel_buf, 0, sizeof(float) * (size_t)ORC_PRE_CACHE * ORC_N_MELS);
+    s->total_chunks = 0;
+    s->decode_iterations = 0;
+    s->frames_total = 0;
+    s->n_tok_frames = 0;
+    s->n_log = 0;
+}
+
+void orc_stream_enable_decision_log(orc_stream *s, int on) { s->log_on = on; s->n_log = 0; }
+/* record i = the i-th LSTM+joint evaluation since create/reset: absolute encoder frame, tokens emitted before it, arg-max,
+ * runner-up and the top-2 logit margin (best - second).  Returns the number of records. */
+int orc_stream_decision_log(const orc_stream *s, int *frame, int *ntok_before, int *best, int *second, float *margin, int cap) {
+    for (int i = 0; i < s->n_log && i < cap; i++) {
+        if (frame) frame[i] = s->log_frame[i];
+        if (ntok_before) ntok_before[i] = s->log_ntok[i];
+        if (best) best[i] = s->log_best[i];
+        if (second) second[i] = s->log_second[i];
+        if (margin) margin[i] = s->log_margin[i];
+    }
+    return s->n_log;
 }
 
 orc_stream *orc_stream_create(const orc_model *m, int right_context, int prompt_index) {
@@ -583,6 +743,7 @@ orc_stream *orc_stream_create(const orc_model *m, int right_context, int prompt_
 void orc_stream_free(orc_stream *s) {
     if (!s) return;
     free(s->kcache); free(s->vcache); free(s->convcache); free(s->posproj); free(s->mel_buf); free(s->tok_frames);
+    free(s->log_frame); free(s->log_ntok); free(s->log_best); free(s->log_second); free(s->log_margin);
     orc_preproc_free(s->pp);
     free(s);
 }
@@ -623,10 +784,10 @@ static void ffn_block(const orc_model *m, float *x, int T, const float *nw, cons
                       const float *w1, const float *w2, float *a, float *h, float *o) {
     layer_norm_rows(x, T, ORC_D_MODEL, nw, nb, a);
     if (m->emulate_bf16) round_bf16_inplace(a, (int64_t)T * ORC_D_MODEL);
-    gemm_nt(a, T, ORC_D_MODEL, w1, ORC_D_FF, NULL, h);
+    gemm_w(m, a, T, ORC_D_MODEL, w1, ORC_D_FF, NULL, h);
     for (size_t i = 0; i < (size_t)T * ORC_D_FF; i++) h[i] = siluf_(h[i]);
     if (m->emulate_bf16) round_bf16_inplace(h, (int64_t)T * ORC_D_FF);
-    gemm_nt(h, T, ORC_D_FF, w2, ORC_D_MODEL, NULL, o);
+    gemm_w(m, h, T, ORC_D_FF, w2, ORC_D_MODEL, NULL, o);
     for (size_t i = 0; i < (size_t)T * ORC_D_MODEL; i++) x[i] += 0.5f * o[i];
 }
 
@@ -640,11 +801,11 @@ static void mha_block(const orc_model *m, const orc_layer *L, float *x, int T, i
     float *ctx = (float *)xmalloc(sizeof(float) * (size_t)T * D);
     layer_norm_rows(x, T, D, L->norm_att_w, L->norm_att_b, a);
     if (m->emulate_bf16) round_bf16_inplace(a, (int64_t)T * D);
-    gemm_nt(a, T, D, L->wq, D, NULL, q);                      /* :485 */
+    gemm_w(m, a, T, D, L->wq, D, NULL, q);                    /* :485 */
     memcpy(kall, kc, sizeof(float) * (size_t)C * D);          /* :493-498 concat */
     memcpy(vall, vc, sizeof(float) * (size_t)C * D);
-    gemm_nt(a, T, D, L->wk, D, NULL, kall + (size_t)C * D);   /* :486 */
-    gemm_nt(a, T, D, L->wv, D, NULL, vall + (size_t)C * D);   /* :487 */
+    gemm_w(m, a, T, D, L->wk, D, NULL, kall + (size_t)C * D); /* :486 */
+    gemm_w(m, a, T, D, L->wv, D, NULL, vall + (size_t)C * D); /* :487 */
     if (m->emulate_bf16) {
         round_bf16_inplace(kall + (size_t)C * D, (int64_t)T * D);
         round_bf16_inplace(vall + (size_t)C * D, (int64_t)T * D);
@@ -684,7 +845,7 @@ static void mha_block(const orc_model *m, const orc_layer *L, float *x, int T, i
             }
         }
     if (m->emulate_bf16) round_bf16_inplace(ctx, (int64_t)T * D);
-    gemm_nt(ctx, T, D, L->wout, D, NULL, o);                 /* :570 */
+    gemm_w(m, ctx, T, D, L->wout, D, NULL, o);               /* :570 */
     for (size_t i = 0; i < (size_t)T * D; i++) x[i] += o[i]; /* :643 */
     /* new cache = last 70 rows of [cache; new] (:505-512) */
     memcpy(kc, kall + (size_t)(KV - C) * D, sizeof(float) * (size_t)C * D);
@@ -701,7 +862,7 @@ static void conv_block(const orc_model *m, const orc_layer *L, float *x, int T, 
     float *c = (float *)xmalloc(sizeof(float) * (size_t)T * D);
     layer_norm_rows(x, T, D, L->norm_conv_w, L->norm_conv_b, a);
     if (m->emulate_bf16) round_bf16_inplace(a, (int64_t)T * D);
-    gemm_nt(a, T, D, L->pw1, 2 * D, NULL, y);                /* :654 */
+    gemm_w(m, a, T, D, L->pw1, 2 * D, NULL, y);              /* :654 */
     memcpy(z, cc, sizeof(float) * (size_t)ks1 * D);          /* :351-356 */
     for (int t = 0; t < T; t++)                              /* GLU :657-664 */
         for (int ch = 0; ch < D; ch++)
@@ -716,7 +877,7 @@ static void conv_block(const orc_model *m, const orc_layer *L, float *x, int T, 
     layer_norm_rows(c, T, D, L->conv_ln_w, L->conv_ln_b, c); /* :671-673 */
     for (size_t i = 0; i < (size_t)T * D; i++) c[i] = siluf_(c[i]); /* :674 */
     if (m->emulate_bf16) round_bf16_inplace(c, (int64_t)T * D);
-    gemm_nt(c, T, D, L->pw2, D, NULL, o);                    /* :677 */
+    gemm_w(m, c, T, D, L->pw2, D, NULL, o);                  /* :677 */
     for (size_t i = 0; i < (size_t)T * D; i++) x[i] += o[i]; /* :679 */
     free(y); free(z); free(c);
 }
@@ -740,10 +901,10 @@ void orc_layer_chunk0(const orc_model *m, int layer, const float *x, int T, floa
     float *kc = (float *)xcalloc((size_t)ORC_LEFT_CTX * D, sizeof(float));
     float *vc = (float *)xcalloc((size_t)ORC_LEFT_CTX * D, sizeof(float));
     float *cc = (float *)xcalloc((size_t)ks1 * D, sizeof(float));
-    float *emb = (float *)xmalloc(sizeof(float) * (size_t)n_rel * D);
+    float *emb = (float *)xcalloc((size_t)n_rel * D, sizeof(float));
     float *P = (float *)xmalloc(sizeof(float) * (size_t)n_rel * D);
     for (int r = 0; r < n_rel; r++) orc_pos_emb((ORC_LEFT_CTX + T - 1) - r, emb + (size_t)r * D);
-    gemm_nt(emb, n_rel, D, m->layers[layer].wpos_f32, D, NULL, P);
+    gemm_w(m, emb, n_rel, D, m->layers[layer].wpos_f32, D, NULL, P);
     if (m->emulate_bf16) round_bf16_inplace(P, (int64_t)n_rel * D);
     memcpy(out, x, sizeof(float) * (size_t)T * D);
     cached_layer(m, layer, out, T, KV, kc, vc, cc, P, 0);
@@ -847,6 +1008,25 @@ int orc_stream_decode(orc_stream *s, const float *enc, int n_frames, int *tokens
             float bs = logits[0];
             for (int v = 1; v < ORC_VOCAB; v++)
                 if (logits[v] > bs) { bs = logits[v]; best = v; } /* first max, :899-906 */
+            if (s->log_on) {
+                if (s->n_log == s->cap_log) {
+                    s->cap_log = s->cap_log ? 2 * s->cap_log : 1024;
+                    s->log_frame = (int *)realloc(s->log_frame, sizeof(int) * (size_t)s->cap_log);
+                    s->log_ntok = (int *)realloc(s->log_ntok, sizeof(int) * (size_t)s->cap_log);
+                    s->log_best = (int *)realloc(s->log_best, sizeof(int) * (size_t)s->cap_log);
+                    s->log_second = (int *)realloc(s->log_second, sizeof(int) * (size_t)s->cap_log);
+                    s->log_margin = (float *)realloc(s->log_margin, sizeof(float) * (size_t)s->cap_log);
+                }
+                int second = best == 0 ? 1 : 0;
+                for (int v = 0; v < ORC_VOCAB; v++)
+                    if (v != best && logits[v] > logits[second]) second = v;
+                s->log_frame[s->n_log] = s->frames_total + t;
+                s->log_ntok[s->n_log] = s->n_tok_frames;
+                s->log_best[s->n_log] = best;
+                s->log_second[s->n_log] = second;
+                s->log_margin[s->n_log] = bs - logits[second];
+                s->n_log++;
+            }
             if (best == ORC_BLANK) break;                          /* state untouched :908-911 */
             if (n_tok < cap) tokens_out[n_tok] = best;
             n_tok++;

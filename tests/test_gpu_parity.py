@@ -268,7 +268,7 @@ def test_quantised_gguf_flavours(W, kind):
     """F16 / Q8_0 / Q4_0 tensors at the seam (scripts/convert_to_gguf.py:118-204) are dequantised at
     upload: the engine fed the packed bytes == the oracle fed the dequantised f32 values."""
     engW, deqW = synth.quantize_weights(W, kind)
-    assert sum(isinstance(v, tuple) for v in engW.values()) == N_LAYERS * 12   # FFN 2x2, attention 5, conv pw1/pw2/batch_norm.weight
+    assert sum(isinstance(v, tuple) for v in engW.values()) == N_LAYERS * 11   # FFN 2x2, attention q/k/v/pos/out, conv pw1/pw2
     om = ob.OracleModel(deqW, N_LAYERS)
     eng = capi.Engine(engW, n_layers=N_LAYERS, dtype=capi.DTYPE_F32, max_streams=1)
     pcm = synth.make_pcm(2, 3.0)
