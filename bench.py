@@ -3,17 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B --right-context R --dtype bf16]
 
-A "step" is one pass of the hot path over one batch: every stream of the batch is pushed
-1280*(1+R) new PCM samples (80 ms * (1+R) of audio), which runs PCM->log-mel, one cached
-encoder chunk (24 layers) and the RNN-T greedy decode for all B streams in one launch
-sequence.  Default workload = BASELINE.json configs[1]: nemotron-0.6B, bf16, batch = 1 stream,
-80 ms lookahead (R = 0), full-size seeded synthetic weights and PCM (no checkpoints/audio exist
-on the box).  PCM is resident in HBM before the timed region starts (NASR_FLAG_PCM_DEVICE).
+A "step" is one pass of the hot path over one batch: every stream of the batch is pushed 1280*(1+R) new PCM samples
+(80 ms * (1+R) of audio), which runs PCM->log-mel, one cached encoder chunk (24 layers) and the RNN-T greedy decode for
+all B streams in one launch sequence.  Headline workload = BASELINE.json configs[1]: nemotron-0.6B, bf16, batch = 1
+stream, 80 ms lookahead (R = 0), full-size seeded synthetic weights and PCM (no checkpoints / audio exist on the box).
+PCM is resident in HBM before the timed region starts (NASR_FLAG_PCM_DEVICE); the hand-over of host buffers (H2D inside
+the timed region) is reported beside it as `host_pcm`, never as `value`.
 
-Multi-GPU (N > 1, launched by torch.distributed.run): streams are independent, so rank r owns
-its own B streams on GPU r with replicated weights -- weak scaling, no data-path collective
-(SURVEY.md §8e).  torch.distributed (RCCL) is used only for the barrier and the max-over-ranks
-of the elapsed time.
+Timing: W untimed warm-up steps, then 5 regions of EXACTLY K steps each, every region bracketed by a barrier + device
+synchronisation on both sides, max over ranks per region; `value` is the median region (`runs` lists all five).
+
+Also in the line (rank 0):
+  * `configs`: the other single-GPU configurations BASELINE.json names -- configs[2] (Q8_0 tensors, 64 streams, 1.12 s
+    lookahead; with --gpus N this is configs[3]: 64 streams per GPU) and configs[4] (the same + the diarization
+    side-car), each with its own roofline;
+  * `roofline` (dominant kernel; duration from HIP events on the engine's stream), `cpu_baseline` (the oracle, bounded
+    sample) and `token_agreement` (engine tokens vs the F32 oracle on the same audio, with the oracle's top-2 margin at
+    the first divergence).
+
+Multi-GPU: `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks of this script itself
+(`python -m torch.distributed.run --nproc-per-node N`, one rank per GPU) BEFORE anything touches the GPU and exits with
+their status.  Streams are independent units: rank r owns its own streams on GPU r with replicated weights -- weak
+scaling, no data-path collective; torch.distributed (RCCL) only lines the ranks up (barrier) and takes
+the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +35,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -35,37 +49,13 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 (spec)
-# measured-achievable on this pool (tests/micro/peaks.py): 1 GiB stream copy 5.0 TB/s, hipBLASLt bf16 8192^3 1261 TFLOP/s
-HBM_MEASURED_GBS = 5020.0
+# measured-achievable (MI355X_MICROARCH.md: float4 copy 6.29 TB/s; tests/micro/peaks.py on this pool: hipBLASLt bf16 8192^3 1261 TFLOP/s)
+HBM_MEASURED_GBS = 6290.0
 MFMA_MEASURED_TFLOPS = 1261.0
+REPEATS = 5
 
 
-# HIP-event category (engine) -> rocprofv3 kernel symbol, for the committed PMC traffic summary
-_SYMBOL = {"k_fused_ln_gemm": "void nasr::k_fused_skinny<0>(nasr::FusedParams)",
-           "k_fused_plain_gemm": "void nasr::k_fused_skinny<1>(nasr::FusedParams)",
-           "k_fused_attn_gemm": "void nasr::k_fused_skinny<2>(nasr::FusedParams)",
-           "k_fused_dwconv_gemm": "void nasr::k_fused_skinny<3>(nasr::FusedParams)"}
-
-
-def pmc_traffic(category, B, R, dtype, layers):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes committed under
-    profiles/ (FETCH_SIZE x2 correction + WRITE_SIZE, MI355X_MICROARCH.md).  PMC counters cannot be
-    collected from inside this process; the number is reported only for the configuration it was
-    measured on (batch 1, R 0, bf16, 24 layers) and is null otherwise."""
-    if (B, R, dtype, layers, category) == (64, 13, "bf16", 24, "k_gemm_tiled"):       # BASELINE configs[2]/[3] shape
-        f64 = ROOT / "profiles" / "r1f_pmc_batch64_R13.json"
-        if not f64.exists():
-            return None
-        d = json.loads(f64.read_text())["derived"]["k_gemm_tiled2"]
-        return int(d["fabric_read_bytes"] + d["write_bytes"])
-    f = ROOT / "profiles" / "r1_pmc_traffic_batch1_R0.json"
-    if (B, R, dtype, layers) != (1, 0, "bf16", 24) or not f.exists() or category not in _SYMBOL:
-        return None
-    k = json.loads(f.read_text())["kernels"].get(_SYMBOL[category])
-    return k.get("hbm_bytes_per_launch_corrected") if k else None
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -88,144 +78,318 @@ def parse():
                     help="audio seconds of the CPU-baseline sample (~10-20 s of CPU work on 16 host threads)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-buffered", action="store_true", help="skip the buffered-audio (file transcription) figure")
+    ap.add_argument("--no-extra-configs", action="store_true", help="headline only: skip the configs[2] / configs[4] entries")
+    ap.add_argument("--extra-steps", type=int, default=200, help="timed steps per region of the extra configurations")
     ap.add_argument("--diarize", action="store_true",
-                    help="BASELINE config 5: also time the diarization side-car on each step's audio (MarbleNet VAD on every "
-                         "10 ms window + TitaNet-L embeddings of 1.5 s sub-segments at a 0.75 s shift, random-init weights)")
-    return ap.parse_args()
+                    help="BASELINE config 5 on the HEADLINE workload too: also time the diarization side-car on each step's audio")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks started by --gpus N (0: pick a free one)")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help=argparse.SUPPRESS)   # launch-path test only (tests/test_bench_launch.py): no GPU, gloo, a sleeping stand-in
+    return ap.parse_args(argv)
+
+
+# ---- multi-rank launcher -------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """--gpus N without a torchrun environment: start N ranks of this script.  Runs before load_package(), torch.cuda or
+    any HIP call in this process (a process that has initialised the GPU must neither fork ranks nor exec); the parent
+    only waits and hands on the exit status."""
+    port = args.master_port
+    if not port:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- a stand-in engine for the launch-path test (never the product path) -------------------------------------------
+class _StubEngine:
+    """sleeps instead of computing: exercises argument handling, the rank launcher, barriers and the JSON line on a box
+    without a GPU.  Selected only by the hidden --stub-engine flag; the line it prints says so."""
+
+    def __init__(self, B):
+        self.B = B
+
+    def step(self):
+        time.sleep(0.0005)
+
+    def synchronize(self):
+        pass
+
+
+def pmc_traffic(kernel_symbol_part, tag):
+    """HBM bytes per launch of a kernel from the rocprofv3 --pmc passes committed under profiles/ for THIS build
+    (profiles/r2_pmc_traffic_<tag>.json, written by tests/prof_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside this process; null when no
+    summary for the configuration / kernel is committed."""
+    f = ROOT / "profiles" / f"r2_pmc_traffic_{tag}.json"
+    if not f.exists():
+        return None
+    try:
+        ks = json.loads(f.read_text())["kernels"]
+    except (ValueError, KeyError):
+        return None
+    for name, rec in ks.items():
+        if kernel_symbol_part in name:
+            return rec.get("hbm_bytes_per_launch_corrected")
+    return None
+
+
+_SYMBOL = {"k_fused_ln_gemm": "k_fused_skinny<0>", "k_fused_plain_gemm": "k_fused_skinny<1>", "k_fused_attn_gemm": "k_fused_skinny<2>",
+           "k_fused_dwconv_gemm": "k_fused_skinny<3>", "k_gemm_tiled": "k_gemm_", "k_gemm_skinny": "k_gemm_skinny", "k_gemm_mid": "k_gemm_mid"}
+
+
+class Run:
+    """one engine + B streams + their PCM in HBM, stepped through the C ABI"""
+
+    def __init__(self, capi, synth, engW, layers, dtype, B, R, device, stream_ids, chunks_per_step=1, pipeline=True, audio_s=60.0):
+        self.capi, self.synth = capi, synth
+        self.B, self.R, self.T = B, R, 1 + R
+        self.n_step = synth.shift_samples(R) * chunks_per_step
+        self.eng = capi.Engine(engW, n_layers=layers, dtype=dtype, max_streams=B, device=device)
+        self.eng.set_option("pipeline", 1 if pipeline else 0)
+        self.streams = [self.eng.stream(R) for _ in range(B)]
+        self.n_avail = max(2, int(audio_s * synth.SAMPLE_RATE) // self.n_step)       # steps of audio per stream before it wraps
+        n_total = self.n_avail * self.n_step
+        self.pcm_host = [synth.make_pcm(sid, n_total / synth.SAMPLE_RATE + 0.01)[:n_total] for sid in stream_ids]
+        self.pcm_dev = [self.eng.upload(p) for p in self.pcm_host]
+        self.L = capi.lib()
+        self.handles = (C.c_void_p * B)(*[s.h for s in self.streams])
+        self.tok_cap = 16 * self.T * chunks_per_step
+        self.tok_bufs = [np.zeros(self.tok_cap, np.int32) for _ in range(B)]
+        self.tptrs = (C.c_void_p * B)(*[b.ctypes.data for b in self.tok_bufs])
+        self.caps = (C.c_int32 * B)(*([self.tok_cap] * B))
+        self.ntok = (C.c_int32 * B)()
+        self.ns = (C.c_int32 * B)(*([self.n_step] * B))
+        self.dev_ptrs = [(C.c_void_p * B)(*[self.pcm_dev[s] + 2 * k * self.n_step for s in range(B)]) for k in range(self.n_avail)]
+        self.host_ptrs = [(C.c_void_p * B)(*[self.pcm_host[s].ctypes.data + 2 * k * self.n_step for s in range(B)]) for k in range(self.n_avail)]
+        self.k = 0                       # steps pushed so far (audio position = k mod n_avail)
+        self.tokens = 0
+        self.tok_log0 = []               # token ids of stream 0, in order (token_agreement)
+        self.audio_per_step = B * self.n_step / synth.SAMPLE_RATE
+
+    def step(self, host=False):
+        i = self.k % self.n_avail
+        ptrs = self.host_ptrs[i] if host else self.dev_ptrs[i]
+        rc = self.L.nasr_engine_step(self.eng.h, self.handles, self.B, ptrs, self.ns, self.tptrs, self.caps, self.ntok,
+                                     0 if host else self.capi.FLAG_PCM_DEVICE)
+        if rc < 0:
+            raise RuntimeError(self.L.nasr_last_error().decode())
+        self.k += 1
+        self.tokens += sum(self.ntok[b] for b in range(self.B))
+        if self.ntok[0]:
+            self.tok_log0 += self.tok_bufs[0][:self.ntok[0]].tolist()
+
+    def drain(self):
+        out = self.eng.collect(self.streams)
+        self.tokens += sum(len(t) for t in out)
+        self.tok_log0 += out[0]
+
+    def close(self):
+        for s in self.streams:
+            s.destroy()
+        self.eng.close()
+
+
+def timed_regions(run, steps, barrier, max_over_ranks, host=False, repeats=REPEATS):
+    """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronise; -> list of elapsed seconds (max over ranks)"""
+    out = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.step(host)
+        barrier()
+        out.append(max_over_ranks(time.perf_counter() - t0))
+    return out
+
+
+def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag):
+    """per-kernel-class HIP-event pass (eager launches, events around every launch on the engine's stream) -> (roofline, kernels)"""
+    eng = run.eng
+    eng.profile(True)
+    for _ in range(n_steps):
+        run.step()
+    kernels = eng.profile_read()
+    eng.profile(False)
+    dom = max((k for k in kernels if "gemm" in k["name"]), key=lambda k: k["total_ms"], default=None)
+    if not dom or dom["total_ms"] <= 0:
+        return None, kernels
+    # Events bracket every launch of the (eager) profile pass, so each bracket also holds ~2 us of launch latency that the
+    # timed region (graph replay) does not pay.  The kernel's duration inside the timed region = its share of the bracketed
+    # time x the timed step; this is what rocprofv3 reports for the same command (profiles/).  The raw bracket average is
+    # kept beside it.  Pipelined steps: the decode graph is off the timed critical path.
+    ev_total = sum(k["total_ms"] for k in kernels if sync_steps or k["name"] != "k_dec_iter")
+    share = dom["total_ms"] / ev_total
+    per_step = dom["launches"] / n_steps
+    avg_s = share * step_s / per_step
+    avg_ev_us = 1e3 * dom["total_ms"] / dom["launches"]
+    flops, nbytes = dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"]
+    tf, gbs = flops / avg_s / 1e12, nbytes / avg_s / 1e9
+    mfma_bound = flops / (MFMA_PEAK_TFLOPS * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9)
+    traffic = pmc_traffic(_SYMBOL.get(dom["name"], dom["name"]), pmc_tag)
+    common = dict(kernel=dom["name"], avg_launch_us=round(avg_s * 1e6, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
+                  launches_per_step=per_step, share_of_step=round(share, 4), alg_bytes_per_launch=round(nbytes),
+                  alg_flops_per_launch=round(flops), traffic=traffic, workload=label)
+    if mfma_bound:
+        roof = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_TFLOPS, 4),
+                    peak_measured=MFMA_MEASURED_TFLOPS, frac_of_measured=round(tf / MFMA_MEASURED_TFLOPS, 4),
+                    hbm_frac=round(gbs / HBM_PEAK_GBS, 4), **common)
+    else:
+        roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                    peak_measured=HBM_MEASURED_GBS, frac_of_measured=round(gbs / HBM_MEASURED_GBS, 4),
+                    mfma_frac=round(tf / MFMA_PEAK_TFLOPS, 6), **common)
+    return roof, kernels
+
+
+def summarize(regions, steps, audio_per_step, world):
+    med = statistics.median(regions)
+    return dict(value=round(world * audio_per_step * steps / med, 2), ms_per_step=round(1e3 * med / steps, 4),
+                runs_ms_per_step=[round(1e3 * r / steps, 4) for r in regions])
+
+
+def reference_cli_baseline(pcm, R):
+    """BASELINE.md §3 hook: when the user supplies the reference's own CLI built against their ggml checkout
+    ($NEMOTRON_REF_BIN, e.g. /path/to/nemotron-asr.cpp built with `make GGML_DIR=$GGML_DIR`) and a real checkpoint
+    ($NEMOTRON_GGUF), time `<bin> <gguf> <pcm> 80 <R> --cpu` on the headline stream's audio and report its own
+    'Real-time factor' line (src/transcribe_stream.cpp:263-267) inverted to RTFx.  Neither exists on the pool's boxes."""
+    exe, gguf = os.environ.get("NEMOTRON_REF_BIN"), os.environ.get("NEMOTRON_GGUF")
+    if not exe or not gguf or not Path(exe).exists() or not Path(gguf).exists():
+        return None
+    import re
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pcm") as f:
+        pcm.tofile(f.name)
+        r = subprocess.run([exe, gguf, f.name, "80", str(R), "--cpu"], capture_output=True, text=True, timeout=3600)
+    m = re.search(r"Real-time factor[^0-9]*([0-9.]+)", r.stderr + r.stdout)
+    if r.returncode != 0 or not m or float(m.group(1)) <= 0:
+        return dict(error=(r.stderr or r.stdout)[-300:])
+    return dict(value=round(1.0 / float(m.group(1)), 3), unit="audio-s/s", kind="reference", cores="ggml default thread count",
+                sample=f"{pcm.size / 16000:.1f} s of the headline stream through {exe} --cpu (real checkpoint {gguf}: other weights than the GPU run)")
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))                     # nothing above touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or drop the torchrun environment and let --gpus start the ranks)")
     dist = None
     torch = None
     if world > 1 or os.environ.get("NASR_BENCH_FORCE_DIST"):      # the knob exercises the RCCL plumbing on a 1-GPU box
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.stub_engine:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ge.load_package()
     from nemotron_asr_amd import capi, sharding, synth
 
     B, R = args.batch, args.right_context
     T = 1 + R
-    n_step = synth.shift_samples(R) * args.chunks_per_step
-    total_steps = args.warmup + args.steps
-    audio_per_step = B * n_step / synth.SAMPLE_RATE
+    red_dev = "cpu" if args.stub_engine else "cuda"
+
+    def max_over_ranks(x):
+        return sharding.max_over_ranks(dist, x, device=red_dev)
+
+    if args.stub_engine:
+        # ---- launch-path test: same control flow (ranks, barriers, max over ranks, one JSON line), no engine ----------
+        stub = _StubEngine(B)
+
+        class _R:
+            audio_per_step = B * synth.shift_samples(R) / synth.SAMPLE_RATE
+
+            def step(self, host=False):
+                stub.step()
+        run = _R()
+
+        def barrier():
+            sharding.barrier(dist, None)
+        for _ in range(args.warmup):
+            run.step()
+        regions = timed_regions(run, args.steps, barrier, max_over_ranks, repeats=REPEATS)
+        if rank == 0:
+            s = summarize(regions, args.steps, run.audio_per_step, world)
+            print(json.dumps({"metric": "RTFx (audio-sec/sec), nemotron-0.6B streaming forward path", "value": s["value"], "unit": "audio-s/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": s["ms_per_step"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                              "stub": True, "config": {"workload": "STUB ENGINE (sleeps): launch-path test, not a measurement",
+                                                       "ranks_seen": world, "stream_ids_rank0": sharding.stream_ids(rank, world, B)}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     t0 = time.time()
     W = synth.make_weights(n_layers=args.layers)
     t_weights = time.time() - t0
     dtype = capi.DTYPE_BF16 if args.dtype == "bf16" else capi.DTYPE_F32
-    engW = W
+    engW, Wcpu = W, W
     if args.weights != "f32":
-        engW, W = synth.quantize_weights(W, args.weights)     # engine gets the packed blocks, the CPU baseline their values
-    eng = capi.Engine(engW, n_layers=args.layers, dtype=dtype, max_streams=B, device=local_rank)
-    del engW
-    eng.set_option("pipeline", 0 if args.sync_steps else 1)
-    streams = [eng.stream(R) for _ in range(B)]
-    # PCM for every step, resident in HBM before timing starts.  Extra steps for the profile pass.
+        engW, Wcpu = synth.quantize_weights(W, args.weights)     # engine gets the packed blocks, the CPU baseline their values
     prof_steps = 0 if args.no_profile_pass else min(args.steps, 50)
-    n_total = (total_steps + prof_steps) * n_step
-    secs = n_total / synth.SAMPLE_RATE
-    pcm_host = [synth.make_pcm(sid, secs)[:n_total] for sid in sharding.stream_ids(rank, world, B)]
-    pcm_dev = [eng.upload(p) for p in pcm_host]
+    need_s = (args.warmup + REPEATS * args.steps * 2 + prof_steps + 4) * synth.shift_samples(R) * args.chunks_per_step / synth.SAMPLE_RATE
+    audio_s = min(max(need_s, args.cpu_seconds + 2.0), 120.0)
+    run = Run(capi, synth, engW, args.layers, dtype, B, R, local_rank, sharding.stream_ids(rank, world, B), args.chunks_per_step,
+              pipeline=not args.sync_steps, audio_s=audio_s)
+    del engW
 
-    L = capi.lib()
-    handles = (C.c_void_p * B)(*[s.h for s in streams])
-    tok_cap = 16 * T * args.chunks_per_step
-    tok_bufs = [np.zeros(tok_cap, np.int32) for _ in range(B)]
-    tptrs = (C.c_void_p * B)(*[b.ctypes.data for b in tok_bufs])
-    caps = (C.c_int32 * B)(*([tok_cap] * B))
-    ntok = (C.c_int32 * B)()
-    ns = (C.c_int32 * B)(*([n_step] * B))
-    step_ptrs = [(C.c_void_p * B)(*[pcm_dev[s] + 2 * k * n_step for s in range(B)]) for k in range(total_steps + prof_steps)]
+    def barrier_for(r):
+        def barrier():
+            sharding.barrier(dist, r.eng.synchronize)
+            if dist is not None:
+                torch.cuda.synchronize()        # torch's own stream (RCCL barrier); the engine's stream is synchronised above
+        return barrier
 
-    tokens_total = 0
+    barrier = barrier_for(run)
+    for _ in range(args.warmup):
+        run.step()
+    run.drain()                                # pipelined steps: the last warm-up step's tokens are not the timed region's
+    run.tokens = 0
+    regions = timed_regions(run, args.steps, barrier, max_over_ranks)
+    run.drain()
+    tokens_timed, chunks_timed = run.tokens, run.streams[0].progress().chunks
+    head = summarize(regions, args.steps, run.audio_per_step, world)
+    host_regions = timed_regions(run, args.steps, barrier, max_over_ranks, host=True, repeats=3)
+    run.drain()
+    host_pcm = summarize(host_regions, args.steps, run.audio_per_step, world)
+    host_pcm["note"] = "same steps with the PCM handed over as HOST buffers: one gathered H2D copy per step inside the timed region"
+    step_s = statistics.median(regions) / args.steps
 
-    def run_step(k):
-        nonlocal tokens_total
-        rc = L.nasr_engine_step(eng.h, handles, B, step_ptrs[k], ns, tptrs, caps, ntok, capi.FLAG_PCM_DEVICE)
-        if rc < 0:
-            raise RuntimeError(L.nasr_last_error().decode())
-        tokens_total += sum(ntok[b] for b in range(B))
-
-    def barrier():
-        sharding.barrier(dist, eng.synchronize)
-        if dist is not None:
-            torch.cuda.synchronize()            # torch's own stream (RCCL barrier); the engine's stream is synchronised above
-
-    for k in range(args.warmup):
-        run_step(k)
-    eng.collect(streams)                       # pipelined steps: the last warm-up step's tokens are not the timed region's
-    tokens_total = 0
-    barrier()
-    t_start = time.perf_counter()
-    for k in range(args.warmup, total_steps):
-        run_step(k)
-    barrier()
-    elapsed = time.perf_counter() - t_start                # barrier() = engine synchronize: the last decode graph has finished
-    elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
-    tokens_total += sum(len(t) for t in eng.collect(streams))       # tokens of the last pipelined step (host queue)
-    tokens_timed = tokens_total
-    chunks_timed = streams[0].stats().chunks
-
-    value = sharding.aggregate_rtfx(world, audio_per_step * args.steps, elapsed)
-
-    # ---- per-kernel HIP-event pass (same steps, events around every launch) ------------------
-    roofline = None
-    kernels = []
+    roofline, kernels = None, []
+    label = f"batch={B} R={R} {args.dtype}" + (f" from {args.weights}" if args.weights != "f32" else "")
     if prof_steps and rank == 0:
-        eng.profile(True)
-        for k in range(total_steps, total_steps + prof_steps):
-            run_step(k)
-        kernels = eng.profile_read()
-        eng.profile(False)
-        dom = max((k for k in kernels if "gemm" in k["name"]), key=lambda k: k["total_ms"], default=None)
-        if dom and dom["total_ms"] > 0:
-            # Events bracket every launch of the (eager) profile pass, so each bracket also holds ~2 us of launch
-            # latency that the timed region (graph replay) does not pay.  The kernel's duration inside the timed
-            # region = its share of the bracketed time x the timed step; this is what rocprofv3 reports for the
-            # same command (profiles/).  The raw bracket average is kept beside it.
-            # pipelined steps: the decode graph is off the timed critical path, the step time is shared by the rest
-            ev_total = sum(k["total_ms"] for k in kernels if args.sync_steps or k["name"] != "k_dec_iter")
-            share = dom["total_ms"] / ev_total
-            per_step = dom["launches"] / prof_steps
-            avg_ms = share * (1e3 * elapsed / args.steps) / per_step
-            avg_ev_us = 1e3 * dom["total_ms"] / dom["launches"]
-            if dom["name"] == "k_gemm_tiled":
-                ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-                roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS,
-                                unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
-                                traffic=pmc_traffic(dom["name"], B * args.chunks_per_step, R, args.dtype, args.layers),
-                                peak_measured=MFMA_MEASURED_TFLOPS, frac_of_measured=round(ach / MFMA_MEASURED_TFLOPS, 4),
-                                hbm_frac=round(dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                avg_launch_us=round(avg_ms * 1e3, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
-                                launches_per_step=per_step, share_of_step=round(share, 4))
-            else:
-                traffic = pmc_traffic(dom["name"], B * args.chunks_per_step, R, args.dtype, args.layers)
-                ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-                roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                                peak_measured=HBM_MEASURED_GBS, frac_of_measured=round(ach / HBM_MEASURED_GBS, 4),
-                                mfma_frac=round(dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 6),
-                                avg_launch_us=round(avg_ms * 1e3, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
-                                launches_per_step=per_step, share_of_step=round(share, 4),
-                                alg_bytes_per_launch=round(dom["bytes"] / dom["launches"]))
+        roofline, kernels = profile_pass(run, prof_steps, step_s, args.sync_steps, label, f"b{B}_R{R}")
+        run.drain()
+    steps_pushed = run.k
 
     # ---- the same stream fed buffered audio (file transcription): 256 chunks per push share one launch sequence ----
     buffered = None
     if rank == 0 and world == 1 and (B, args.chunks_per_step) == (1, 1) and not args.no_buffered:
+        eng, L = run.eng, run.L
         G, n_push = 256, 5
         nb = synth.shift_samples(R) * G
         pb = synth.make_pcm(1000, (n_push + 1) * nb / synth.SAMPLE_RATE + 0.01)[:(n_push + 1) * nb]
         db = eng.upload(pb)
-        sb = streams[0]                         # the timed region is over: reuse its slot
-        sb.reset()
-        hb = (C.c_void_p * 1)(sb.h)
+        eng2_stream = run.streams[0]
+        tok_log_keep, frames_keep = list(run.tok_log0), eng2_stream.token_frames()
+        eng2_stream.reset()                      # the timed region is over: reuse its slot
+        hb = (C.c_void_p * 1)(eng2_stream.h)
         tb = np.zeros(16 * T * G, np.int32)
         tpb = (C.c_void_p * 1)(tb.ctypes.data)
         cb = (C.c_int32 * 1)(tb.size)
@@ -245,21 +409,22 @@ def main():
                         value=round(n_push * nb / synth.SAMPLE_RATE / tsum, 1), unit="audio-s/s",
                         note="same engine, same stream semantics (80 ms lookahead, chunk-by-chunk caches), the 256 chunks of "
                              "a push go through every layer as one launch sequence; not the headline value")
+    else:
+        tok_log_keep, frames_keep = list(run.tok_log0), (run.streams[0].token_frames() if rank == 0 else [])
 
-    # ---- diarization side-car on the same audio (BASELINE config 5) ---------------------------------------------------
-    diar = None
-    if args.diarize and rank == 0:
+    # ---- diarization side-car beside the headline workload (only on request; configs[4] is measured below) --------------
+    def diarization_entry(r, n_ov):
         dW = synth.make_diar_weights()
-        deng = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * B), device=local_rank)
+        deng = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * r.B), device=local_rank)
         hist = 10080 - 160                                   # samples of history a new 10 ms hop needs
         # the side-car reads the SAME s16 PCM the ASR streams were fed, already resident in HBM
-        vad_ptrs = [pcm_dev[b] for b in range(B)]
-        vad_n = [hist + n_step] * B
-        n_seg = max(1, int(round(B * (n_step / synth.SAMPLE_RATE) / 0.75)))                          # sub-segment shift 0.75 s
-        seg_ptrs = [pcm_dev[i % B] + 2 * 12000 * (i // B) for i in range(n_seg)]
+        vad_ptrs = [r.pcm_dev[b] for b in range(r.B)]
+        vad_n = [hist + r.n_step] * r.B
+        n_seg = max(1, int(round(r.B * (r.n_step / synth.SAMPLE_RATE) / 0.75)))                          # sub-segment shift 0.75 s
+        seg_ptrs = [r.pcm_dev[i % r.B] + 2 * 12000 * (i // r.B) for i in range(n_seg)]
         deng.vad_device_s16(vad_ptrs, vad_n); deng.embed_device_s16(seg_ptrs)
         reps = 10
-        eng.synchronize()
+        r.eng.synchronize()
         tq = time.perf_counter()
         for _ in range(reps):
             pv = deng.vad_device_s16(vad_ptrs, vad_n)
@@ -271,7 +436,6 @@ def main():
         # the same work overlapped: the side-car runs on its own HIP stream from a second host thread while the ASR
         # step of the same audio runs on the engine's stream (ctypes releases the GIL during both calls)
         import threading
-        n_ov = min(args.steps, 20)
         gate_go, gate_done = threading.Barrier(2), threading.Barrier(2)
 
         def side_car():
@@ -281,85 +445,156 @@ def main():
                 deng.embed_device_s16(seg_ptrs)
                 gate_done.wait()
 
-        th = threading.Thread(target=side_car)
-        th.start()
-        for s in streams:
-            s.reset()
-        run_step(0)
-        eng.synchronize()
-        tq = time.perf_counter()
-        for k in range(n_ov):
-            gate_go.wait()
-            run_step(1 + k)
-            gate_done.wait()
-        t_ov = (time.perf_counter() - tq) / n_ov
-        th.join()
-        step_s = elapsed / args.steps
-        diar = dict(overlapped_ms_per_step=round(1e3 * t_ov, 3), overlapped_rtfx=round(audio_per_step / t_ov, 1),
-                    vad_windows_per_step=int(sum(x.size for x in pv)), vad_ms_per_step=round(1e3 * t_vad, 3),
-                    embeddings_per_step=n_seg, embed_ms_per_step=round(1e3 * t_spk, 3),
-                    asr_plus_diarization_rtfx=round(audio_per_step / (step_s + t_vad + t_spk), 1),
-                    note="side-car on the streams' own s16 PCM, device-resident; *_ms_per_step: run alone after the ASR step, "
-                         "overlapped_*: on its own HIP stream from a second host thread beside the ASR step")
+        ovs = []
+        for _ in range(REPEATS):
+            th = threading.Thread(target=side_car)
+            th.start()
+            r.eng.synchronize()
+            tq = time.perf_counter()
+            for _ in range(n_ov):
+                gate_go.wait()
+                r.step()
+                gate_done.wait()
+            r.eng.synchronize()
+            ovs.append((time.perf_counter() - tq) / n_ov)
+            th.join()
+        r.drain()
+        t_ov = statistics.median(ovs)
+        d = dict(value=round(r.audio_per_step / t_ov, 1), ms_per_step=round(1e3 * t_ov, 3), runs_ms_per_step=[round(1e3 * x, 3) for x in ovs],
+                 steps_per_region=n_ov, vad_windows_per_step=int(sum(x.size for x in pv)), vad_ms_per_step=round(1e3 * t_vad, 3),
+                 embeddings_per_step=n_seg, embed_ms_per_step=round(1e3 * t_spk, 3),
+                 note="side-car (MarbleNet VAD on every 10 ms window + TitaNet-L embeddings of 1.5 s sub-segments at a 0.75 s shift, random-init "
+                      "weights) on the streams' own s16 PCM, device-resident, on its own HIP stream from a second host thread beside the ASR step; "
+                      "vad/embed_ms_per_step: each call run alone")
         deng.close()
+        return d
 
-    # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample ------------
-    cpu = None
+    diar = None
+    if args.diarize and rank == 0:
+        diar = diarization_entry(run, min(args.steps, 50))
+
+    # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample; token agreement -------------
+    cpu, agreement, cpu_ref = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import difflib
         from oracle import binding as ob
-        om = ob.OracleModel(W, args.layers)
+        om = ob.OracleModel(Wcpu, args.layers)
         ost = ob.OracleStream(om, R)
-        n_cpu_steps = max(2, int(args.cpu_seconds * synth.SAMPLE_RATE / n_step))
-        p = synth.make_pcm(sharding.stream_ids(rank, world, B)[0], args.cpu_seconds + 3 * n_step / synth.SAMPLE_RATE + 1.0)
-        ost.process(p[:2 * n_step])            # warm-up: fills the first chunk
+        ost.enable_decision_log()
+        n_step = run.n_step
+        p = run.pcm_host[0]
+        n_cpu_steps = max(2, min(int(args.cpu_seconds * synth.SAMPLE_RATE / n_step), p.size // n_step - 2))
+        ref_tokens = ost.process(p[:2 * n_step])            # warm-up: fills the first chunk
         c0 = ost.total_chunks
         tc = time.perf_counter()
         for k in range(2, 2 + n_cpu_steps):
-            ost.process(p[k * n_step:(k + 1) * n_step])
+            ref_tokens += ost.process(p[k * n_step:(k + 1) * n_step])
         tcpu = time.perf_counter() - tc
         cpu = dict(value=round(n_cpu_steps * n_step / synth.SAMPLE_RATE / tcpu, 3), unit="audio-s/s",
                    cores=ob.lib().orc_num_threads(), kind="port",
                    sample=f"{n_cpu_steps} steps ({n_cpu_steps * n_step / synth.SAMPLE_RATE:.2f} s of audio) of stream 0, "
                           f"same weights/PCM, f32 CPU restatement (oracle/nasr_oracle.c, OpenMP), "
                           f"{ost.total_chunks - c0} chunks in {tcpu:.2f} s")
+        # engine tokens of stream 0 (warm-up + timed + host-PCM + profile steps, one continuous stream) vs the F32 oracle on the
+        # same audio, cut at the frames both have decoded
+        if args.chunks_per_step == 1:
+            ref_frames = ost.token_frames()
+            # the first push completes no chunk, every later one exactly one; audio is contiguous until the stream's PCM wraps
+            n_frames = (min(steps_pushed, run.n_avail, 2 + n_cpu_steps) - 1) * T
+            ge_t = [(t, f) for t, f in zip(tok_log_keep, frames_keep) if f < n_frames]
+            rf_t = [(t, f) for t, f in zip(ref_tokens, ref_frames) if f < n_frames]
+            gt, gf = [t for t, _ in ge_t], [f for _, f in ge_t]
+            rt, rf = [t for t, _ in rf_t], [f for _, f in rf_t]
+            div = ob.first_divergence(ost.decision_log(), rt, rf, gt, gf)
+            agreement = dict(frames_compared=n_frames, oracle_tokens=len(rt), engine_tokens=len(gt),
+                             common_prefix=div["index"] if div else len(rt),
+                             aligned_ratio=round(difflib.SequenceMatcher(None, rt, gt, autojunk=False).ratio(), 4),
+                             first_divergence=div,
+                             note="engine (this dtype) vs the F32 oracle on the same audio of stream 0; greedy RNN-T leaves the oracle's path at the "
+                                  "first decision a rounding flips: first_divergence.margin is the oracle's top-2 logit margin there")
+        del om
+        cpu_ref = reference_cli_baseline(p[:int(args.cpu_seconds * synth.SAMPLE_RATE)], R)
+
+    # ---- the other configurations BASELINE.json names ------------------------------------------------------------------
+    configs = {}
+    headline_is_default = (B, R, args.dtype, args.layers, args.chunks_per_step, args.weights) == (1, 0, "bf16", 24, 1, "f32")
+    if headline_is_default and not args.no_extra_configs:
+        run.close()
+        run = None
+        xB, xR = 64, 13
+        q8W, _ = synth.quantize_weights(W, "q8_0")
+        xrun = Run(capi, synth, q8W, args.layers, capi.DTYPE_BF16, xB, xR, local_rank, sharding.stream_ids(rank, world, xB), 1,
+                   pipeline=not args.sync_steps, audio_s=60.0)
+        del q8W
+        xbar = barrier_for(xrun)
+        for _ in range(5):
+            xrun.step()
+        xrun.drain()
+        xrun.tokens = 0
+        xr = timed_regions(xrun, args.extra_steps, xbar, max_over_ranks)
+        xrun.drain()
+        e = summarize(xr, args.extra_steps, xrun.audio_per_step, world)
+        xh = timed_regions(xrun, args.extra_steps, xbar, max_over_ranks, host=True, repeats=3)
+        xrun.drain()
+        e["host_pcm"] = summarize(xh, args.extra_steps, xrun.audio_per_step, world)
+        e.update(unit="audio-s/s", steps_per_region=args.extra_steps, regions=REPEATS, tokens_emitted=xrun.tokens,
+                 workload=f"nemotron-speech-streaming-0.6B ({args.layers} layers) bf16 from Q8_0 tensors, batch={xB} streams/GPU, 1.12 s lookahead (R=13), "
+                          f"{world}xMI355X [BASELINE.json configs[{2 if world == 1 else 3}]]")
+        if rank == 0 and prof_steps:
+            e["roofline"], xk = profile_pass(xrun, 20, statistics.median(xr) / args.extra_steps, args.sync_steps, "batch=64 R=13 bf16 from q8_0", "b64_R13")
+            e["kernels"] = [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in xk]
+            xrun.drain()
+        configs["b64_R13_q8_0"] = e
+        if rank == 0 and world == 1:
+            d = diarization_entry(xrun, 40)
+            d.update(unit="audio-s/s", workload=f"the ASR engine of b64_R13_q8_0 + MarbleNet VAD + TitaNet-L embeddings fused on-GPU, batch={xB} streams, "
+                                                 f"1xMI355X [BASELINE.json configs[4]]")
+            configs["b64_R13_diarize"] = d
+        xrun.close()
 
     if rank == 0:
         out = {
             "metric": "RTFx (audio-sec/sec), nemotron-0.6B streaming forward path",
-            "value": round(value, 2),
+            "value": head["value"],
             "unit": "audio-s/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            "timing": f"median of {REPEATS} regions of {args.steps} steps, each bracketed by barrier + device synchronise, max over ranks",
+            "runs_ms_per_step": head["runs_ms_per_step"],
             "config": {
                 "workload": f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}"
                             + (f" from {args.weights.upper()} tensors" if args.weights != "f32" else "") + f", batch={B} stream(s)/GPU, "
                             f"{80 * T} ms lookahead (R={R}), {world}xMI355X"
                             + (f", {args.chunks_per_step} chunks pushed per step" if args.chunks_per_step > 1 else "")
-                            + (" [BASELINE.json configs[1]]" if (B, R, args.dtype, args.layers, args.chunks_per_step) == (1, 0, "bf16", 24, 1) else ""),
-                "streams_per_gpu": B, "right_context": R, "audio_s_per_step_per_gpu": audio_per_step,
+                            + (" [BASELINE.json configs[1]]" if headline_is_default else ""),
+                "streams_per_gpu": B, "right_context": R, "audio_s_per_step_per_gpu": B * synth.shift_samples(R) * args.chunks_per_step / synth.SAMPLE_RATE,
                 "parallelism": f"stream-sharded x{world}, no collectives",
                 "pcm": "device-resident", "tokens_emitted": tokens_timed, "chunks": chunks_timed,
                 "steps": "synchronous" if args.sync_steps else "pipelined: decode graph of step s on a second HIP stream beside the encoder graph of step s+1",
             },
+            "host_pcm": host_pcm,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_reference_cli": cpu_ref,
+            "token_agreement": agreement,
+            "configs": configs or None,
             "buffered_audio": buffered,
             "diarization": diar,
             "kernels": [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in kernels],
             "setup_s": {"weights": round(t_weights, 1)},
         }
         print(json.dumps(out), flush=True)
-    for s in streams:
-        s.destroy()
-    eng.close()
+    if run is not None:
+        run.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

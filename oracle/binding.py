@@ -341,6 +341,8 @@ def ref():
         R.ref_preproc_process.argtypes = [C.c_void_p, C.POINTER(C.c_int16), C.c_int, _fp, C.c_int]
         R.ref_subsampling.argtypes = [pp, _fp, C.c_int, _fp]
         R.ref_pos_emb.argtypes = [C.c_int, _fp]
+        if hasattr(R, "ref_rel_shift"):
+            R.ref_rel_shift.argtypes = [_fp, C.c_int, C.c_int, _fp]
         R.ref_conformer_layer.argtypes = [pp, _fp, C.c_int, _fp]
         R.ref_ffn.argtypes = [_fp, _fp, _fp, C.c_int, _fp]
         R.ref_layer_norm.argtypes = [_fp, _fp, _fp, C.c_int, _fp]
@@ -413,6 +415,16 @@ def ref_conformer_layer(weights, layer, x) -> np.ndarray:
 def ref_pos_emb(seq_len) -> np.ndarray:
     out = np.zeros((2 * seq_len - 1, 1024), np.float32)
     ref().ref_pos_emb(seq_len, _f(out))
+    return out
+
+
+def ref_rel_shift(x: np.ndarray) -> np.ndarray:
+    """x [heads][qlen][2 qlen - 1] -> [heads][qlen][qlen] through the compiled reference rel_shift"""
+    x = np.ascontiguousarray(x, np.float32)
+    H, q, pl = x.shape
+    assert pl == 2 * q - 1
+    out = np.zeros((H, q, q), np.float32)
+    ref().ref_rel_shift(_f(x), H, q, _f(out))
     return out
 
 

@@ -16,6 +16,12 @@
 #include <vector>
 
 #include "preprocessor.h"                 // $(REF)/src
+// RelPositionMultiHeadAttention::rel_shift is a private member of the (unmodified) reference class; the shim's own
+// translation unit sees it as public so that the golden generator can call the compiled function itself (access
+// specifiers do not change the class layout; the reference's .cpp files are compiled as they are).
+#define private public
+#include "include/conformer_modules.h"
+#undef private
 #include "include/conformer_encoder.h"    // $(REF)/src/reference
 #include "include/conformer_modules.h"
 #include "include/conv_subsampling.h"
@@ -63,6 +69,17 @@ void ref_pos_emb(int seq_len, float *out /*[2*seq_len-1][1024]*/) {
     nemo::TensorF p;
     pe.get_pos_emb((size_t)seq_len, p);
     std::memcpy(out, p.ptr(), sizeof(float) * p.numel());
+}
+
+// ---- a-6: RelPositionMultiHeadAttention::rel_shift (src/reference/conformer_modules.cpp:188-240) ------
+// x [heads][qlen][2*qlen-1] -> out [heads][qlen][qlen]; the input pattern of tests/test_compute.cpp:1028-1052
+void ref_rel_shift(const float *x, int heads, int qlen, float *out) {
+    nemo::RelPositionMultiHeadAttention a;
+    const size_t pl = 2 * (size_t)qlen - 1;
+    nemo::TensorF in({1, (size_t)heads, (size_t)qlen, pl}), o;
+    std::memcpy(in.ptr(), x, sizeof(float) * (size_t)heads * qlen * pl);
+    a.rel_shift(in, o);
+    std::memcpy(out, o.ptr(), sizeof(float) * o.numel());
 }
 
 // ---- a-3..a-9: ConformerLayer::forward (src/reference/conformer_encoder.cpp:29-69) ---

@@ -38,6 +38,12 @@ def main():
         out[f"layer_T{T}"] = ob.ref_conformer_layer(W, 0, gi.layer_input(T))
     # a-7: positional table
     out["pos_emb_5"] = ob.ref_pos_emb(5)
+    # a-6: rel_shift on the reference's own closed-form test input, in[h][i][p] = 100 h + 10 i + p, heads 2, qlen 4
+    # (tests/test_compute.cpp:1028-1052), plus qlen 14 (the R = 13 chunk length)
+    for q in (4, 14):
+        out[f"rel_shift_q{q}"] = ob.ref_rel_shift(gi.rel_shift_input(2, q))
+    # a-7 again at the chunk widths the streaming slice is cut from (src/nemo-stream.cpp:168-177): KV = 71 and 84
+    out["pos_emb_84"] = ob.ref_pos_emb(84)
     # a-12/13: decoder+joint logits for the reference's own test sequence
     # (tests/test_compute.cpp:2407: {1024, 0, 100, 500})
     enc = gi.enc_frames(64)

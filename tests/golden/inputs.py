@@ -40,3 +40,9 @@ def layer_input(T):
 
 def enc_frames(n):
     return _normal(0xE7C0DE, (n, 1024))
+
+
+def rel_shift_input(heads, qlen):
+    """the reference's own rel-shift test pattern (tests/test_compute.cpp:1028-1038): in[h][i][p] = 100 h + 10 i + p"""
+    h, i, p = np.meshgrid(np.arange(heads), np.arange(qlen), np.arange(2 * qlen - 1), indexing="ij")
+    return (100.0 * h + 10.0 * i + p).astype(np.float32)

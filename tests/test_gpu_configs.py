@@ -1,0 +1,342 @@
+"""GPU parity at the workloads BASELINE.json names (configs[2] / configs[3]: 64 streams x 1.12 s lookahead, Q8_0 tensors ->
+bf16 engine, M = 896 rows per GEMM) and the token-agreement analysis of the reduced-precision engine against the f32
+oracle (= the reference's arithmetic), plus the reference-exact reset and the never-drop token hand-over.
+
+Tolerances: bf16 engine vs the bf16-emulating oracle (same rounding points, other summation order) 3e-2 on LayerNorm-scale
+activations for 2 layers; 24 layers: stated in the test.  Token agreement: greedy RNN-T diverges at the first near-tie a
+rounding flips, so the check is on WHERE it diverges: the oracle's top-2 logit margin at the first differing decision of
+every stream must be below EPS_MARGIN (the logit noise the bf16 path is allowed), not on an agreement rate."""
+import ctypes as C
+import difflib
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from nemotron_asr_amd import capi, synth
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+# logit noise budget of the bf16 path at 24 layers: encoder rows differ from f32 by ~1e-2 (max ~5e-2) on |x| <= 4, the
+# joint (f32) maps that to ~2e-2 (max ~1e-1) on logits of scale 3-5; a first divergence at a larger oracle margin is a bug
+EPS_MARGIN = 0.25
+
+
+def _report(name, payload):
+    d = os.environ.get("NASR_REPORT_DIR")
+    if d:
+        Path(d).mkdir(parents=True, exist_ok=True)
+        (Path(d) / f"{name}.json").write_text(json.dumps(payload, indent=1))
+
+
+@pytest.fixture(scope="module")
+def W2():
+    return synth.make_weights(n_layers=2)
+
+
+@pytest.fixture(scope="module")
+def W24():
+    return synth.make_weights(n_layers=24)
+
+
+@pytest.fixture(scope="module")
+def Q24(W24):
+    """(engine tensors with Q8_0 blocks, dequantised f32 values, raw blocks by name)"""
+    engW, deq = synth.quantize_weights(W24, "q8_0")
+    return engW, deq, {k: v[1] for k, v in engW.items() if isinstance(v, tuple)}
+
+
+def _pieces(R, n_push, seed0, B):
+    n = synth.shift_samples(R)
+    return n, [synth.make_pcm(seed0 + b, n_push * n / 16000 + 0.01)[:n_push * n] for b in range(B)]
+
+
+def test_config3_q8_0_64_streams_R13_two_layers(W2):
+    """BASELINE configs[2] at its exact launch shape: 64 streams x R = 13 (M = 896 rows: 7 m-chunks of the 128 x 128 tile
+    kernel, XCD remap, split-K + reduction), Q8_0 tensors dequantised and packed to bf16 at upload, PCM in.  EVERY stream's
+    last-layer output of every step and its K / V / conv caches against the bf16-emulating oracle on the dequantised values."""
+    L, B, R, T = 2, 64, 13, 14
+    engW, deqW = synth.quantize_weights(W2, "q8_0")
+    om = ob.OracleModel(deqW, L, emulate_bf16=True)
+    eng = capi.Engine(engW, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    eng.set_debug(True)
+    n, pcms = _pieces(R, 6, 400, B)
+    sts = [eng.stream(R) for _ in range(B)]
+    osts = [ob.OracleStream(om, R) for _ in range(B)]
+    taps = [o.enable_taps() for o in osts]
+    worst, steps, toks_g, toks_o = 0.0, 0, [[] for _ in range(B)], [[] for _ in range(B)]
+    for k in range(6):
+        out = eng.step(sts, [p[k * n:(k + 1) * n] for p in pcms])
+        stepped = False
+        for b in range(B):
+            toks_g[b] += out[b]
+            c0 = osts[b].total_chunks
+            toks_o[b] += osts[b].process(pcms[b][k * n:(k + 1) * n])
+            assert sts[b].progress().chunks == osts[b].total_chunks
+            if osts[b].total_chunks > c0:
+                stepped = True
+                got = sts[b].tap(capi.TAP_LAYER_OUT, L - 1).reshape(T, 1024)
+                worst = max(worst, float(np.abs(got - taps[b][1][L - 1]).max()))
+        steps += stepped
+    assert steps >= 4 and worst < 3e-2, (steps, worst)
+    kv_worst = 0.0
+    for b in range(B):
+        for l in range(L):
+            for which, tap in ((0, capi.TAP_K_CACHE), (1, capi.TAP_V_CACHE)):
+                kv_worst = max(kv_worst, float(np.abs(sts[b].tap(tap, l, cap=70 * 1024).reshape(70, 1024) - osts[b].get_cache(which, l)).max()))
+            kv_worst = max(kv_worst, float(np.abs(sts[b].tap(capi.TAP_CONV_CACHE, l, cap=8 * 1024).reshape(8, 1024) - osts[b].get_cache(2, l)).max()))
+    assert kv_worst < 1.2e-1, kv_worst          # K rows are not LayerNorm-scaled (|k| up to ~4: one bf16 ulp = 0.03)
+    # tokens: same leading tokens on every stream that emitted (exactness is asserted on f32)
+    n_tok = 0
+    for b in range(B):
+        m = min(4, len(toks_o[b]), len(toks_g[b]))
+        assert toks_g[b][:m] == toks_o[b][:m], b
+        n_tok += len(toks_o[b])
+    assert n_tok > 20
+    eng.close()
+
+
+def test_config3_full_size_one_step_and_q8_semantics(Q24):
+    """The same launch shape at BASELINE's model size (24 layers): one 64-stream x R = 13 step from Q8_0 tensors, four spot
+    streams against the 24-layer bf16-emulating oracle.  bf16 re-rounding over 24 layers is a random walk (~100 roundings
+    of 0.004-0.008 on |x| <= 4): typical difference 0.01-0.02, worst element below 0.1 (stated, measured 0.05-0.07).
+    Then the question config 3 asks -- how close is this to the ggml CPU path ON Q8_0? -- as numbers: the oracle in
+    ORC_EMU_Q8_ACT mode (activation rows quantised per 32, int8 dot products: ggml's published Q8_0 mul_mat) against the
+    f32 product of the same dequantised weights, and the engine against both."""
+    engW, deq, blocks = Q24
+    L, B, R, T = 24, 64, 13, 14
+    eng = capi.Engine(engW, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    eng.set_debug(True)
+    n, pcms = _pieces(R, 2, 500, B)
+    sts = [eng.stream(R) for _ in range(B)]
+    for k in range(2):
+        eng.step(sts, [p[k * n:(k + 1) * n] for p in pcms])
+    assert all(s.progress().chunks == 1 for s in sts)
+    spots = (0, 21, 42, 63)
+    got = {b: sts[b].tap(capi.TAP_LAYER_OUT, L - 1).reshape(T, 1024).copy() for b in spots}
+    eng.close()
+    res = {}
+    for mode, kw in (("bf16", dict(emulate_bf16=True)), ("f32", {}), ("q8_act", dict(emulate_q8_act=True, q8_blocks=blocks))):
+        om = ob.OracleModel(deq, L, **kw)
+        outs = {}
+        for b in spots if mode == "bf16" else spots[:2]:
+            ost = ob.OracleStream(om, R)
+            tap = ost.enable_taps()
+            ost.process(pcms[b])
+            assert ost.total_chunks == 1
+            outs[b] = tap[1][L - 1].copy()
+        res[mode] = outs
+        del om
+    d_bf16 = max(float(np.abs(got[b] - res["bf16"][b]).max()) for b in spots)
+    m_bf16 = max(float(np.abs(got[b] - res["bf16"][b]).mean()) for b in spots)
+    assert d_bf16 < 1e-1 and m_bf16 < 1.5e-2, (d_bf16, m_bf16)
+    def dist(a, b):
+        return dict(max=max(float(np.abs(a[k] - b[k]).max()) for k in spots[:2]), mean=max(float(np.abs(a[k] - b[k]).mean()) for k in spots[:2]))
+
+    rep = dict(engine_vs_bf16_oracle=dict(max=d_bf16, mean=m_bf16), q8_act_oracle_vs_f32_oracle=dist(res["f32"], res["q8_act"]),
+               engine_vs_q8_act_oracle=dist(got, res["q8_act"]), engine_vs_f32_oracle=dist(got, res["f32"]))
+    _report("config3_full_size", rep)
+    # the engine (bf16 operands) must be no further from ggml's Q8_0 semantics than 3x what those semantics are from f32
+    assert rep["engine_vs_q8_act_oracle"]["mean"] < 3 * max(rep["q8_act_oracle_vs_f32_oracle"]["mean"], 5e-3), rep
+
+
+def _run_engine_tokens(eng, R, pcms, n):
+    B = len(pcms)
+    sts = [eng.stream(R) for _ in range(B)]
+    toks = [[] for _ in range(B)]
+    for o in range(0, pcms[0].size, n):
+        for b, t in enumerate(eng.step(sts, [p[o:o + n] for p in pcms])):
+            toks[b] += t
+    for b, t in enumerate(eng.finalize(sts)):
+        toks[b] += t
+    frames = [s.token_frames() for s in sts]
+    for s in sts:
+        s.destroy()
+    return toks, frames
+
+
+def _agreement(om, R, pcms, n, toks, frames):
+    rows = []
+    for b, pcm in enumerate(pcms):
+        ost = ob.OracleStream(om, R)
+        ost.enable_decision_log()
+        ref = []
+        for o in range(0, pcm.size, n):
+            ref += ost.process(pcm[o:o + n])
+        ref += ost.finalize()
+        rf = ost.token_frames()
+        div = ob.first_divergence(ost.decision_log(), ref, rf, toks[b], frames[b])
+        prefix = div["index"] if div else len(ref)
+        rows.append(dict(stream=b, ref_tokens=len(ref), engine_tokens=len(toks[b]), common_prefix=prefix,
+                         aligned_ratio=round(difflib.SequenceMatcher(None, ref, toks[b], autojunk=False).ratio(), 4),
+                         first_divergence=div))
+    return rows
+
+
+def test_bf16_token_agreement_vs_f32_oracle(W24):
+    """24 layers, R = 13: 8 streams x 30 s through the bf16 engine (graph path, M = 112 rows) against the F32 oracle.
+    Reported: tokens, common prefix, aligned agreement; asserted: every stream's first divergence happens at a decision
+    whose top-2 margin in the oracle is below EPS_MARGIN, and the aligned agreement over all streams is above 0.5."""
+    L, R, B = 24, 13, 8
+    n, pcms = _pieces(R, 27, 700, B)                     # 27 x 1.12 s = 30.2 s per stream
+    eng = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    toks, frames = _run_engine_tokens(eng, R, pcms, n)
+    eng.close()
+    om = ob.OracleModel(W24, L)
+    rows = _agreement(om, R, pcms, n, toks, frames)
+    del om
+    tot_ref = sum(r["ref_tokens"] for r in rows)
+    rate = sum(r["aligned_ratio"] * r["ref_tokens"] for r in rows) / max(tot_ref, 1)
+    _report("bf16_token_agreement", dict(rows=rows, aligned_rate=rate, eps_margin=EPS_MARGIN))
+    assert tot_ref > 50, tot_ref
+    for r in rows:
+        d = r["first_divergence"]
+        assert d is None or (d["decision"] >= 0 and d["margin"] < EPS_MARGIN), r
+    assert rate > 0.5, rows
+
+
+def test_q8_0_token_agreement_vs_ggml_q8_semantics(Q24):
+    """BASELINE config 3's parity question: the engine fed Q8_0 tensors (dequantised to bf16) against ggml-CPU Q8_0
+    semantics (oracle ORC_EMU_Q8_ACT, parity unpinned: ggml is absent from the reference tree).  4 streams x 11 s, R = 13.
+    Same bar as above: first divergences only at oracle margins below EPS_MARGIN."""
+    engW, deq, blocks = Q24
+    L, R, B = 24, 13, 4
+    n, pcms = _pieces(R, 10, 900, B)
+    eng = capi.Engine(engW, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    toks, frames = _run_engine_tokens(eng, R, pcms, n)
+    eng.close()
+    om = ob.OracleModel(deq, L, emulate_q8_act=True, q8_blocks=blocks)
+    rows = _agreement(om, R, pcms, n, toks, frames)
+    del om
+    tot_ref = sum(r["ref_tokens"] for r in rows)
+    rate = sum(r["aligned_ratio"] * r["ref_tokens"] for r in rows) / max(tot_ref, 1)
+    _report("q8_0_token_agreement", dict(rows=rows, aligned_rate=rate, eps_margin=EPS_MARGIN))
+    assert tot_ref > 10
+    for r in rows:
+        d = r["first_divergence"]
+        assert d is None or (d["decision"] >= 0 and d["margin"] < EPS_MARGIN), r
+
+
+def test_reset_reference_mode_keeps_what_the_reference_keeps(W2):
+    """nemo_stream_reset as coded (src/nemo-stream.cpp:95-115): conv cache and preprocessor carry survive, K/V contents
+    survive but are masked.  Engine (f32) == oracle twin token for token and on the encoder output; and the quirk is
+    visible: the first chunk after a reference reset differs from the first chunk after a fresh reset, by the stale conv
+    cache (R = 0: exactly the first kernel_size - 1 = 8 frames read stale rows in layer 0)."""
+    L = 2
+    om = ob.OracleModel(W2, L)
+    eng = capi.Engine(W2, n_layers=L, dtype=capi.DTYPE_F32, max_streams=2)
+    eng.set_debug(True)
+    first, second = synth.make_pcm(7, 1.53), synth.make_pcm(8, 2.0)      # 1.53 s: leaves un-framed samples in the preprocessor
+    for R in (0, 13):
+        st, ost = eng.stream(R), ob.OracleStream(om, R)
+        tap = ost.enable_taps()
+        assert eng.step([st], [first])[0] + eng.finalize([st])[0] == ost.process(first) + ost.finalize()
+        st.reset(reference=True)
+        ost.reset(reference=True)
+        assert st.progress().chunks == 0 and st.progress().cache_valid_len == 0 and st.progress().mel_frames_buffered == 9
+        n = synth.shift_samples(R)
+        tg, to, enc_ref, sub_ref = [], [], [], []
+        for o in range(0, second.size, n):
+            c0 = ost.total_chunks
+            tg += eng.step([st], [second[o:o + n]])[0]
+            to += ost.process(second[o:o + n])
+            assert st.stats().chunks == ost.total_chunks
+            if ost.total_chunks > c0:
+                e = st.tap(capi.TAP_LAYER_OUT, L - 1).reshape(-1, 1024)
+                assert np.abs(e - tap[1][L - 1]).max() < 2e-3
+                enc_ref.append(e.copy())
+                sub_ref.append(st.tap(capi.TAP_SUBSAMPLED).reshape(-1, 1024).copy())
+        tg += eng.finalize([st])[0]
+        to += ost.finalize()
+        assert tg == to and st.token_frames() == ost.token_frames()
+        # the same audio after a FRESH reset: other mel frames (no preprocessor carry) and no stale conv rows
+        st.reset()
+        enc_fresh, sub_fresh = [], []
+        for o in range(0, second.size, n):
+            c0 = st.progress().chunks
+            eng.step([st], [second[o:o + n]])
+            if st.progress().chunks > c0:
+                enc_fresh.append(st.tap(capi.TAP_LAYER_OUT, L - 1).reshape(-1, 1024).copy())
+                sub_fresh.append(st.tap(capi.TAP_SUBSAMPLED).reshape(-1, 1024).copy())
+        assert len(enc_fresh) >= 1 and np.abs(enc_fresh[0] - enc_ref[0][:enc_fresh[0].shape[0]]).max() > 1e-3
+        st.destroy()
+    # isolate the conv-cache effect (mel pushed directly: no preprocessor involved), layer 0, R = 0
+    rng = np.random.default_rng(5)
+    mel_a = (rng.standard_normal((9 * 8, 128)) * 2 - 4).astype(np.float32)
+    mel_b = (rng.standard_normal((12 * 8, 128)) * 2 - 4).astype(np.float32)
+    outs = {}
+    for mode in (False, True):
+        st = eng.stream(0)
+        for c in range(9):
+            eng.step_mel([st], [mel_a[c * 8:(c + 1) * 8]])
+        st.reset(reference=mode)
+        rows = []
+        for c in range(12):
+            eng.step_mel([st], [mel_b[c * 8:(c + 1) * 8]])
+            rows.append(st.tap(capi.TAP_LAYER_OUT, 0).reshape(-1, 1024)[0].copy())
+        outs[mode] = np.stack(rows)
+        st.destroy()
+    diff = np.abs(outs[True] - outs[False]).max(axis=1)
+    assert (diff[:8] > 1e-4).all(), diff            # frames 0..7 read at least one stale conv-cache row
+    # from frame 8 on the conv window holds new rows only, and layer 0's K/V rows never depended on the conv module:
+    # layer 0 is bit-identical again (deeper layers keep the difference in their K/V rows for 70 frames)
+    assert diff[8:].max() == 0.0, diff
+    eng.close()
+
+
+def test_tokens_that_do_not_fit_stay_queued(W2):
+    """The hand-over never drops a token: with a 3-entry buffer the step returns 3, the rest comes out of collect /
+    finalize in order; the concatenation equals the oracle's tokens."""
+    L = 2
+    eng = capi.Engine(W2, n_layers=L, dtype=capi.DTYPE_F32, max_streams=1)
+    st = eng.stream(0)
+    pcm = synth.make_pcm(11, 6.0)
+    ost = ob.OracleStream(ob.OracleModel(W2, L), 0)
+    ref = ost.process(pcm) + ost.finalize()
+    assert len(ref) > 12
+    lib = capi.lib()
+    h = (C.c_void_p * 1)(st.h)
+    buf = np.zeros(3, np.int32)
+    tp = (C.c_void_p * 1)(buf.ctypes.data)
+    cap = (C.c_int32 * 1)(3)
+    nt = (C.c_int32 * 1)()
+    pp = (C.c_void_p * 1)(pcm.ctypes.data)
+    ns = (C.c_int32 * 1)(pcm.size)
+    assert lib.nasr_engine_step(eng.h, h, 1, pp, ns, tp, cap, nt, 0) == 0
+    got = buf[:nt[0]].tolist()
+    assert nt[0] == 3 and st.progress().reserved > 0          # queued on the stream, visible without a device sync
+    while True:
+        assert lib.nasr_engine_collect(eng.h, h, 1, tp, cap, nt) == 0
+        got += buf[:nt[0]].tolist()
+        if nt[0] < 3:
+            break
+    got += eng.finalize([st])[0]
+    assert got == ref
+    eng.close()
+
+
+def test_progress_does_not_drain_the_pipeline(W2):
+    """nasr_stream_get_progress is host state only: with pipelined steps the decode of the last step stays in flight (its
+    tokens arrive with the next call), where nasr_stream_get_stats completes it."""
+    eng = capi.Engine(W2, n_layers=2, dtype=capi.DTYPE_F32, max_streams=1)
+    eng.set_option("pipeline", 1)
+    st = eng.stream(0)
+    pcm = synth.make_pcm(3, 4.0)
+    sync = []
+    for o in range(0, pcm.size, 1280):
+        sync += eng.step([st], [pcm[o:o + 1280]])[0]
+    n_before = len(sync)
+    chunks = st.progress().chunks
+    assert chunks > 40 and st.progress().decode_iterations == -1
+    assert st.stats().chunks == chunks                           # drains: the last step's tokens are now queued
+    tail = eng.collect([st])[0] + eng.finalize([st])[0]
+    ost = ob.OracleStream(ob.OracleModel(W2, 2), 0)
+    ref = []
+    for o in range(0, pcm.size, 1280):
+        ref += ost.process(pcm[o:o + 1280])
+    ref += ost.finalize()
+    assert sync + tail == ref and n_before <= len(ref)
+    eng.close()

@@ -54,6 +54,37 @@ def test_speaker_embeddings_match_oracle(dtype, tol):
     eng.close()
 
 
+def test_config5_batch_64_streams():
+    """BASELINE config 5 at its batch: ONE nasr_diar_vad call over 64 buffers of 1.12 s of new audio (+ 0.62 s of history:
+    112 windows each, 7 168 windows) and ONE nasr_diar_embed call over 96 sub-segments (64 streams x 1.12 s at a 0.75 s
+    shift), s16 PCM, the dtype the benchmark uses (TitaNet pointwise convs on the bf16 MFMA) -- a sample of windows and
+    segments against the oracle."""
+    W = synth.make_diar_weights()
+    om = db.DiarModel(W)
+    B, n = 64, 10080 - 160 + 17920
+    pcms = [synth.make_pcm(600 + b, 2.6)[:max(n, 36000)] for b in range(B)]
+    eng = capi.Diar(W, dtype=capi.DTYPE_BF16, max_windows=8192, max_segments=96)
+    probs = eng.vad([p[:n] for p in pcms])
+    assert [p.size for p in probs] == [112] * B
+    allp = np.concatenate(probs)
+    assert np.isfinite(allp).all() and 0.0 < allp.min() and allp.max() < 1.0
+    worst = 0.0
+    for b in (0, 17, 40, 63):
+        a = pcms[b][:n].astype(np.float32) / 32768.0
+        for w in (0, 1, 55, 110, 111):
+            worst = max(worst, abs(float(probs[b][w]) - om.vad_window(a[w * 160:w * 160 + 10080])))
+    assert worst < 2e-5, worst
+    segs = [pcms[i % B][12000 * (i // B):12000 * (i // B) + 24000].astype(np.float32) / 32768.0 for i in range(96)]
+    emb = eng.embed(segs)
+    assert emb.shape == (96, 192) and np.isfinite(emb).all()
+    for i in (0, 31, 64, 95):
+        r = om.spk_embed(segs[i])
+        assert np.abs(emb[i] - r).max() < 6e-2 * np.abs(r).max(), i
+        assert float(emb[i] @ r / (np.linalg.norm(emb[i]) * np.linalg.norm(r))) > 0.999, i
+    assert np.abs(eng.embed(segs[40:41])[0] - emb[40]).max() < 1e-2 * np.abs(emb[40]).max()      # batch of 96 == alone (bf16 tiles differ)
+    eng.close()
+
+
 def test_s16_device_resident_audio_equals_float_host_audio(Wv):
     """NASR_FLAG_AUDIO_S16 | NASR_FLAG_PCM_DEVICE: the side-car reads s16 PCM that is already in HBM (the ASR streams' own
     buffers) -- same probabilities / embeddings as float host audio (x / 32768 is exact in f32)."""

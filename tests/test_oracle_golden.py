@@ -61,6 +61,35 @@ def test_pos_emb(golden):
     assert np.abs(mine - golden["pos_emb_5"]).max() < 1e-5    # reference threshold 1e-5 (:1359)
 
 
+@pytest.mark.parametrize("q", [4, 14])
+def test_rel_shift_closed_form(golden, q):
+    """a-6.  The reference's own closed-form check (tests/test_compute.cpp:1041-1052): out[h][i][j] = in[h][i][j + q-1-i],
+    on vectors produced by the COMPILED reference rel_shift (src/reference/conformer_modules.cpp:188-240).  The engine and
+    the oracle never materialise the shift: they index the relative-position scores at row j + T - 1 - i."""
+    x = gi.rel_shift_input(2, q)
+    ref = golden[f"rel_shift_q{q}"]
+    assert ref.shape == (2, q, q)
+    i, j = np.meshgrid(np.arange(q), np.arange(q), indexing="ij")
+    folded = x[:, i, j + q - 1 - i]                   # the indexing used by k_attention / mha_block with T = q, no cache
+    assert np.array_equal(folded, ref)
+    assert ref[0, 0].tolist()[:4] == [q - 1.0, q + 0.0, q + 1.0, q + 2.0][:4]       # query 0 starts at relative position 0
+    assert ref[1, q - 1, 0] == 100.0 + 10.0 * (q - 1)                              # last query, oldest key: most positive rel
+
+
+def test_streaming_pos_slice_rows(golden):
+    """a-7.  The streaming graph slices 2 KV - 1 rows centred in the sinusoid table (src/nemo-stream.cpp:168-177): slice
+    row s holds position KV - 1 - s, which is what RelPositionalEncoding::get_pos_emb(KV) returns (golden from the compiled
+    reference, KV = 84 = 70 + 14).  After the rel-shift only rows j + T - 1 - i are read: the oracle / engine precompute
+    exactly those KV + T - 1 rows, row r <-> position (70 + T - 1) - r."""
+    T, KV = 14, 84
+    table = golden["pos_emb_84"]
+    assert table.shape == (2 * KV - 1, 1024)
+    rows = np.stack([ob.pos_emb((70 + T - 1) - r) for r in range(KV + T - 1)])
+    assert np.abs(rows - table[:KV + T - 1]).max() < 1e-5          # reference threshold (:1359)
+    i, j = np.meshgrid(np.arange(T), np.arange(KV), indexing="ij")
+    assert (j + T - 1 - i).max() == KV + T - 2 and (j + T - 1 - i).min() == 0     # every row used, none beyond
+
+
 def test_decoder_joint(golden, model):
     enc = gi.enc_frames(64)
     h = np.zeros(1280, np.float32)
