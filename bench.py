@@ -210,7 +210,7 @@ def timed_regions(run, steps, barrier, max_over_ranks, host=False, repeats=REPEA
     return out
 
 
-def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag):
+def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag, bound=None):
     """per-kernel-class HIP-event pass (eager launches, events around every launch on the engine's stream) -> (roofline, kernels)"""
     eng = run.eng
     eng.profile(True)
@@ -232,7 +232,9 @@ def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag):
     avg_ev_us = 1e3 * dom["total_ms"] / dom["launches"]
     flops, nbytes = dom["flops"] / dom["launches"], dom["bytes"] / dom["launches"]
     tf, gbs = flops / avg_s / 1e12, nbytes / avg_s / 1e9
-    mfma_bound = flops / (MFMA_PEAK_TFLOPS * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9)
+    # batch 1 / R = 0 streams every weight once with M = 1 (HBM-bound); 64 streams x R = 13 has M = 896 rows
+    # per GEMM (MFMA-bound).  In between the larger of the two lower bounds decides.
+    mfma_bound = bound == "mfma" if bound else flops / (MFMA_PEAK_TFLOPS * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9)
     traffic = pmc_traffic(_SYMBOL.get(dom["name"], dom["name"]), pmc_tag)
     common = dict(kernel=dom["name"], avg_launch_us=round(avg_s * 1e6, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
                   launches_per_step=per_step, share_of_step=round(share, 4), alg_bytes_per_launch=round(nbytes),
@@ -541,7 +543,7 @@ def main():
                  workload=f"nemotron-speech-streaming-0.6B ({args.layers} layers) bf16 from Q8_0 tensors, batch={xB} streams/GPU, 1.12 s lookahead (R=13), "
                           f"{world}xMI355X [BASELINE.json configs[{2 if world == 1 else 3}]]")
         if rank == 0 and prof_steps:
-            e["roofline"], xk = profile_pass(xrun, 20, statistics.median(xr) / args.extra_steps, args.sync_steps, "batch=64 R=13 bf16 from q8_0", "b64_R13")
+            e["roofline"], xk = profile_pass(xrun, 20, statistics.median(xr) / args.extra_steps, args.sync_steps, "batch=64 R=13 bf16 from q8_0", "b64_R13", bound="mfma")
             e["kernels"] = [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in xk]
             xrun.drain()
         configs["b64_R13_q8_0"] = e

@@ -20,9 +20,10 @@ from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
 
-# logit noise budget of the bf16 path at 24 layers: encoder rows differ from f32 by ~1e-2 (max ~5e-2) on |x| <= 4, the
-# joint (f32) maps that to ~2e-2 (max ~1e-1) on logits of scale 3-5; a first divergence at a larger oracle margin is a bug
-EPS_MARGIN = 0.25
+# logit noise budget of the bf16 path at 24 layers: encoder rows differ from f32 by ~1e-2 (max 5-7e-2) on |x| <= 4 and the
+# (f32) joint maps that to ~1e-2 on the logits.  Measured first-divergence margins (round 2, 12 streams): 0.001-0.016.
+# A first divergence at an oracle margin above EPS_MARGIN = 3x the largest of those would be a bug, not a rounding flip.
+EPS_MARGIN = 0.05
 
 
 def _report(name, payload):
@@ -67,6 +68,8 @@ def test_config3_q8_0_64_streams_R13_two_layers(W2):
     sts = [eng.stream(R) for _ in range(B)]
     osts = [ob.OracleStream(om, R) for _ in range(B)]
     taps = [o.enable_taps() for o in osts]
+    for o in osts:
+        o.enable_decision_log()
     worst, steps, toks_g, toks_o = 0.0, 0, [[] for _ in range(B)], [[] for _ in range(B)]
     for k in range(6):
         out = eng.step(sts, [p[k * n:(k + 1) * n] for p in pcms])
@@ -89,13 +92,15 @@ def test_config3_q8_0_64_streams_R13_two_layers(W2):
                 kv_worst = max(kv_worst, float(np.abs(sts[b].tap(tap, l, cap=70 * 1024).reshape(70, 1024) - osts[b].get_cache(which, l)).max()))
             kv_worst = max(kv_worst, float(np.abs(sts[b].tap(capi.TAP_CONV_CACHE, l, cap=8 * 1024).reshape(8, 1024) - osts[b].get_cache(2, l)).max()))
     assert kv_worst < 1.2e-1, kv_worst          # K rows are not LayerNorm-scaled (|k| up to ~4: one bf16 ulp = 0.03)
-    # tokens: same leading tokens on every stream that emitted (exactness is asserted on f32)
-    n_tok = 0
+    # tokens: where a stream leaves the oracle's greedy path, the oracle's top-2 margin there is within the rounding noise
+    # (token-for-token exactness is asserted on the f32 engine; 64 streams x 5 steps always contain a few near-ties)
+    n_tok, n_same = 0, 0
     for b in range(B):
-        m = min(4, len(toks_o[b]), len(toks_g[b]))
-        assert toks_g[b][:m] == toks_o[b][:m], b
+        div = ob.first_divergence(osts[b].decision_log(), toks_o[b], osts[b].token_frames(), toks_g[b], sts[b].token_frames())
+        assert div is None or (div["decision"] >= 0 and div["margin"] < EPS_MARGIN), (b, div)
+        n_same += div is None
         n_tok += len(toks_o[b])
-    assert n_tok > 20
+    assert n_tok > 20 and n_same >= B // 2, (n_tok, n_same)
     eng.close()
 
 
