@@ -73,6 +73,9 @@ def parse(argv=None):
     ap.add_argument("--sync-steps", action="store_true",
                     help="every step returns its own tokens before the next one starts (engine option pipeline = 0); default: "
                          "pipelined steps, the decode graph of step s runs on a second HIP stream beside the encoder graph of step s + 1")
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=[1, 2],
+                    help="1: decode of step s beside the encoder of step s + 1; 2 (default): in addition layers L/2..L of step s beside "
+                         "layers 0..L/2 of step s + 1 (engine option pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=60.0,
                     help="audio seconds of the CPU-baseline sample (~10-20 s of CPU work on 16 host threads)")
@@ -148,12 +151,12 @@ _SYMBOL = {"k_fused_ln_gemm": "k_fused_skinny<0>", "k_fused_plain_gemm": "k_fuse
 class Run:
     """one engine + B streams + their PCM in HBM, stepped through the C ABI"""
 
-    def __init__(self, capi, synth, engW, layers, dtype, B, R, device, stream_ids, chunks_per_step=1, pipeline=True, audio_s=60.0):
+    def __init__(self, capi, synth, engW, layers, dtype, B, R, device, stream_ids, chunks_per_step=1, pipeline=2, audio_s=60.0):
         self.capi, self.synth = capi, synth
         self.B, self.R, self.T = B, R, 1 + R
         self.n_step = synth.shift_samples(R) * chunks_per_step
         self.eng = capi.Engine(engW, n_layers=layers, dtype=dtype, max_streams=B, device=device)
-        self.eng.set_option("pipeline", 1 if pipeline else 0)
+        self.eng.set_option("pipeline", pipeline)
         self.streams = [self.eng.stream(R) for _ in range(B)]
         self.n_avail = max(2, int(audio_s * synth.SAMPLE_RATE) // self.n_step)       # steps of audio per stream before it wraps
         n_total = self.n_avail * self.n_step
@@ -210,21 +213,35 @@ def timed_regions(run, steps, barrier, max_over_ranks, host=False, repeats=REPEA
     return out
 
 
-def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag, bound=None):
-    """per-kernel-class HIP-event pass (eager launches, events around every launch on the engine's stream) -> (roofline, kernels)"""
+def profile_pass(run, n_steps, label, pmc_tag, restore_pipeline, bound=None):
+    """Roofline of the dominant kernel, the kernel ALONE on the chip: a region of synchronous graph-replayed steps gives the
+    step time of the un-overlapped launch chain, a per-kernel-class HIP-event pass (eager launches, events around every
+    launch on the engine's stream) gives each kernel's share of it.  (In the pipelined timed region two or three launch
+    chains share the chip and a kernel's own duration is longer while the chip does more: `step_roofline` in the line is the
+    figure for that regime.)  -> (roofline, kernels, synchronous step seconds)"""
     eng = run.eng
+    eng.set_option("pipeline", 0)
+    for _ in range(3):
+        run.step()                                   # builds the synchronous step graph
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        run.step()
+    eng.synchronize()
+    step_s = (time.perf_counter() - t0) / n_steps
+    sync_steps = True
     eng.profile(True)
     for _ in range(n_steps):
         run.step()
     kernels = eng.profile_read()
     eng.profile(False)
+    eng.set_option("pipeline", restore_pipeline)
     dom = max((k for k in kernels if "gemm" in k["name"]), key=lambda k: k["total_ms"], default=None)
     if not dom or dom["total_ms"] <= 0:
-        return None, kernels
-    # Events bracket every launch of the (eager) profile pass, so each bracket also holds ~2 us of launch latency that the
-    # timed region (graph replay) does not pay.  The kernel's duration inside the timed region = its share of the bracketed
-    # time x the timed step; this is what rocprofv3 reports for the same command (profiles/).  The raw bracket average is
-    # kept beside it.  Pipelined steps: the decode graph is off the timed critical path.
+        return None, kernels, step_s
+    # Events bracket every launch of the (eager) profile pass, so each bracket also holds ~2 us of launch latency that a
+    # graph replay does not pay.  The kernel's duration = its share of the bracketed time x the synchronous graph-replayed
+    # step; this is what rocprofv3 reports for `bench.py --sync-steps` (profiles/).  The raw bracket average is kept beside it.
     ev_total = sum(k["total_ms"] for k in kernels if sync_steps or k["name"] != "k_dec_iter")
     share = dom["total_ms"] / ev_total
     per_step = dom["launches"] / n_steps
@@ -238,7 +255,8 @@ def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag, bound=None):
     traffic = pmc_traffic(_SYMBOL.get(dom["name"], dom["name"]), pmc_tag)
     common = dict(kernel=dom["name"], avg_launch_us=round(avg_s * 1e6, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
                   launches_per_step=per_step, share_of_step=round(share, 4), alg_bytes_per_launch=round(nbytes),
-                  alg_flops_per_launch=round(flops), traffic=traffic, workload=label)
+                  alg_flops_per_launch=round(flops), traffic=traffic, workload=label,
+                  regime=f"kernel alone on the chip: synchronous graph-replayed steps, {round(step_s * 1e3, 4)} ms per step")
     if mfma_bound:
         roof = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_TFLOPS, 4),
                     peak_measured=MFMA_MEASURED_TFLOPS, frac_of_measured=round(tf / MFMA_MEASURED_TFLOPS, 4),
@@ -247,7 +265,23 @@ def profile_pass(run, n_steps, step_s, sync_steps, label, pmc_tag, bound=None):
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                     peak_measured=HBM_MEASURED_GBS, frac_of_measured=round(gbs / HBM_MEASURED_GBS, 4),
                     mfma_frac=round(tf / MFMA_PEAK_TFLOPS, 6), **common)
-    return roof, kernels
+    return roof, kernels, step_s
+
+
+def step_roofline(layers, B, R, step_s, weight_bytes_per_param=2.0):
+    """Whole-step roofline fractions: algorithmic FLOPs of a step (2 x MACs of the conformer GEMMs, attention,
+    subsampling; decode excluded) and algorithmic bytes (every encoder weight once per step in the GGUF flavour's size + K/V
+    window and conv cache per stream) over the measured step time, against the dense bf16 MFMA and the HBM peak."""
+    T, KV = 1 + R, 70 + 1 + R
+    mac_frame = layers * (24117248 + 3 * 1024 * KV + 9216)
+    sub_chunk = {0: 29.4e6, 1: 40e6, 6: 95e6, 13: 168e6}[R]
+    flops = 2.0 * B * (T * mac_frame + sub_chunk)
+    wbytes = layers * 24117248 * weight_bytes_per_param + 13.4e6 * 4
+    state = B * layers * (2 * 70 * 1024 * 2 + 2 * T * 1024 * 2 + 2 * 8 * 1024 * 4)
+    nbytes = wbytes + state
+    return dict(flops_per_step=round(flops), bytes_per_step=round(nbytes), tflops=round(flops / step_s / 1e12, 1),
+                gbs=round(nbytes / step_s / 1e9, 1), mfma_frac=round(flops / step_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                hbm_frac=round(nbytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
 
 
 def summarize(regions, steps, audio_per_step, world):
@@ -348,7 +382,7 @@ def main():
     need_s = (args.warmup + REPEATS * args.steps * 2 + prof_steps + 4) * synth.shift_samples(R) * args.chunks_per_step / synth.SAMPLE_RATE
     audio_s = min(max(need_s, args.cpu_seconds + 2.0), 120.0)
     run = Run(capi, synth, engW, args.layers, dtype, B, R, local_rank, sharding.stream_ids(rank, world, B), args.chunks_per_step,
-              pipeline=not args.sync_steps, audio_s=audio_s)
+              pipeline=0 if args.sync_steps else args.pipeline_depth, audio_s=audio_s)
     del engW
 
     def barrier_for(r):
@@ -375,8 +409,9 @@ def main():
 
     roofline, kernels = None, []
     label = f"batch={B} R={R} {args.dtype}" + (f" from {args.weights}" if args.weights != "f32" else "")
+    sync_step_s = None
     if prof_steps and rank == 0:
-        roofline, kernels = profile_pass(run, prof_steps, step_s, args.sync_steps, label, f"b{B}_R{R}")
+        roofline, kernels, sync_step_s = profile_pass(run, prof_steps, label, f"b{B}_R{R}", 0 if args.sync_steps else args.pipeline_depth)
         run.drain()
     steps_pushed = run.k
 
@@ -526,7 +561,7 @@ def main():
         xB, xR = 64, 13
         q8W, _ = synth.quantize_weights(W, "q8_0")
         xrun = Run(capi, synth, q8W, args.layers, capi.DTYPE_BF16, xB, xR, local_rank, sharding.stream_ids(rank, world, xB), 1,
-                   pipeline=not args.sync_steps, audio_s=60.0)
+                   pipeline=0 if args.sync_steps else args.pipeline_depth, audio_s=60.0)
         del q8W
         xbar = barrier_for(xrun)
         for _ in range(5):
@@ -542,8 +577,10 @@ def main():
         e.update(unit="audio-s/s", steps_per_region=args.extra_steps, regions=REPEATS, tokens_emitted=xrun.tokens,
                  workload=f"nemotron-speech-streaming-0.6B ({args.layers} layers) bf16 from Q8_0 tensors, batch={xB} streams/GPU, 1.12 s lookahead (R=13), "
                           f"{world}xMI355X [BASELINE.json configs[{2 if world == 1 else 3}]]")
+        e["step_roofline"] = step_roofline(args.layers, xB, xR, statistics.median(xr) / args.extra_steps, 34.0 / 32.0)
         if rank == 0 and prof_steps:
-            e["roofline"], xk = profile_pass(xrun, 20, statistics.median(xr) / args.extra_steps, args.sync_steps, "batch=64 R=13 bf16 from q8_0", "b64_R13", bound="mfma")
+            e["roofline"], xk, xs = profile_pass(xrun, 20, "batch=64 R=13 bf16 from q8_0", "b64_R13", 0 if args.sync_steps else args.pipeline_depth, bound="mfma")
+            e["synchronous_ms_per_step"] = round(1e3 * xs, 4)
             e["kernels"] = [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in xk]
             xrun.drain()
         configs["b64_R13_q8_0"] = e
@@ -579,9 +616,14 @@ def main():
                 "streams_per_gpu": B, "right_context": R, "audio_s_per_step_per_gpu": B * synth.shift_samples(R) * args.chunks_per_step / synth.SAMPLE_RATE,
                 "parallelism": f"stream-sharded x{world}, no collectives",
                 "pcm": "device-resident", "tokens_emitted": tokens_timed, "chunks": chunks_timed,
-                "steps": "synchronous" if args.sync_steps else "pipelined: decode graph of step s on a second HIP stream beside the encoder graph of step s+1",
+                "steps": "synchronous" if args.sync_steps else
+                         ("pipelined, depth 1: decode graph of step s on a second HIP stream beside the encoder graph of step s+1" if args.pipeline_depth == 1 else
+                          "pipelined, depth 2: layers 0..L/2 of step s+2, layers L/2..L of step s+1 and the decode of step s side by side on three HIP streams "
+                          "(same kernels, same per-stream order, bit-identical results; tokens two calls later)"),
             },
             "host_pcm": host_pcm,
+            "synchronous_ms_per_step": round(1e3 * sync_step_s, 4) if sync_step_s else None,
+            "step_roofline": step_roofline(args.layers, B * args.chunks_per_step, R, step_s, {"f32": 2.0, "f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.weights]),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_reference_cli": cpu_ref,

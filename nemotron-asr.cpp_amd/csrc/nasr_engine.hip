@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <shared_mutex>
 #include <string>
@@ -96,7 +97,7 @@ struct nasr_stream {
     int valid_len, kv_head, cc_par;  // cache_valid_len, K/V ring head, conv-cache parity
     int chunks, tok_read;
     int64_t samples_in;
-    int last_T, last_row;            // rows of the last chunk (for taps)
+    int last_T, last_row, last_ws;   // rows of the last chunk and the workspace set they are in (for taps)
     bool alive;
     std::vector<int32_t> tok_queue;  // tokens gathered from the device, not yet handed to the caller
 };
@@ -133,27 +134,33 @@ struct nasr_engine {
     char *gh = nullptr;                                                               // pinned host block
     int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active
     int64_t graph_replays = 0, eager_steps = 0, decode_fallbacks = 0, decode_fallback_rounds = 0;
-    // pipelined graph steps (option "pipeline"): the decode graph of step s runs on st2 beside the encoder graph of step
-    // s + 1; buffers the two graphs hand over exist twice (parity = step & 1)
-    bool opt_pipeline = false;
-    hipStream_t st2 = nullptr;
+    // pipelined graph steps (option "pipeline", 1 or 2): launch sequences of CONSECUTIVE steps run beside each other on
+    // their own HIP streams -- see the comment at pipe_step().  Everything a step in flight owns exists NSLOT times:
+    // workspace set, descriptor blocks, joint.enc buffer, token landing zone, graphs (their kernel arguments point into
+    // the slot).  Slot of a step = its sequence number mod NSLOT.
+    static const int NSLOT = 3;
+    struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; };
+    WS ws[NSLOT];                    // ws[0] = the set the synchronous paths use (mirrored in x, x2, ... below)
+    int opt_pipeline = 0;            // 0: synchronous steps; 1: decode beside the next encoder; 2: + the two encoder halves skewed
+    hipStream_t st2 = nullptr, st3 = nullptr;      // st2: decode graphs, st3: second encoder lane (layers L/2 .. L)
     struct Pipe {
-        char *g_desc = nullptr, *gh = nullptr;            // descriptor block of the encoder graph (device / pinned)
+        char *g_desc = nullptr, *gh = nullptr;            // descriptor block of the encoder graphs (device / pinned)
         int *gh_collect = nullptr, *collect_dev = nullptr;
         int *g_dmeta = nullptr, *gh_dmeta = nullptr;      // k_collect meta of the decode graph [2 B] (device / pinned)
         float *encproj = nullptr;                         // [w_rows][640]: encoder graph -> decode graph
-        hipEvent_t enc_done = nullptr, dec_done = nullptr;
-        std::map<int64_t, hipGraphExec_t> enc_graphs, dec_graphs;
-        bool pending = false;                             // a decode graph of this parity is in flight / not yet consumed
+        hipEvent_t seg0_done = nullptr, enc_done = nullptr;
+        std::map<int64_t, hipGraphExec_t> seg0_graphs, seg1_graphs, dec_graphs;     // key = (B, T, G, depth)
+        int stage = 0;                                    // 0 free, 1 first encoder segment launched, 2 whole encoder launched
+        int64_t seq = -1;                                 // sequence number of the step that occupies the slot
         std::vector<nasr_stream *> streams;
-        int T = 0, G = 0;
+        int T = 0, G = 0, depth = 0;
         int64_t key = 0;
-    } pipe[2];
-    int pipe_parity = 0;
+    } pipe[NSLOT];
+    int64_t pipe_seq = 0;            // steps launched through the pipeline so far
     bool pipe_ready = false;
     size_t desc_bytes = 0, col_bytes = 0;
     int64_t pipe_steps = 0;
-    void *a, *hbuf, *ctx, *cbuf, *sub_b;
+    void *a, *hbuf, *ctx, *cbuf, *sub_b;             // (with x, x2, part, q, glu, sub_a, hfuse: the CURRENT workspace set, see use_ws)
     float *predg;                    // [slot][640] cached joint.pred output of the LSTM candidate
     unsigned long long *key;
     int *n_active;                   // [3] = n_active, n_dirty, n_rows
@@ -163,6 +170,11 @@ struct nasr_engine {
     char *pin = nullptr; size_t pin_cap = 0, pin_off = 0;
     char *ddesc = nullptr; size_t ddesc_cap = 0, ddesc_off = 0;
     int16_t *pcm_stage = nullptr; size_t pcm_stage_cap = 0;
+    // host PCM hand-over: the streams' buffers are gathered into a pinned block and cross PCIe as ONE copy.  The copy is
+    // asynchronous and a pipelined call returns before it has run, so the pinned blocks rotate (a block is reused four
+    // calls later; at most three steps are in flight).
+    struct { int16_t *p = nullptr; size_t cap = 0; } pcm_pin[4];
+    unsigned pcm_pin_next = 0;
     float *mel_stage = nullptr; size_t mel_stage_cap = 0;
     // debug taps
     bool debug = false;
@@ -579,6 +591,32 @@ static int ensure_posproj(nasr_engine *e, int T) {
     return 0;
 }
 
+// one workspace set: the buffers a launch sequence passes from kernel to kernel, for w_rows rows
+static int alloc_ws(nasr_engine *e, nasr_engine::WS &w) {
+    const size_t M = (size_t)e->w_rows;
+    int rc = 0;
+    rc |= dalloc(e, &w.x, M * D);
+    rc |= dalloc(e, &w.x2, M * D);
+    rc |= dalloc(e, &w.part, 8 * M * D);
+    rc |= dalloc(e, &w.q, M * D);
+    rc |= dalloc(e, &w.glu, M * D);
+    rc |= dalloc(e, &w.hfuse, e->hp.num_prompts > 0 ? M * 2048 : 4);
+    { char *p; rc |= dalloc(e, &p, M * D * e->esz); w.a = p; }
+    { char *p; rc |= dalloc(e, &p, M * FF * e->esz); w.hbuf = p; }
+    { char *p; rc |= dalloc(e, &p, M * D * e->esz); w.ctx = p; }
+    { char *p; rc |= dalloc(e, &p, M * D * e->esz); w.cbuf = p; }
+    // subsampling ping-pong buffers, [chunks][H2][33][256] (conv0 is fused into the first depthwise conv and never
+    // stored).  Rows per encoder frame are largest for multi-chunk steps at R = 0: H2 = 2T + 3 = 5 per frame.
+    rc |= dalloc(e, &w.sub_a, M * 5 * 33 * SUBC);
+    { char *p; rc |= dalloc(e, &p, (M * 5 * 33 * SUBC) * 4); w.sub_b = p; }
+    return rc;
+}
+// the enqueue functions address the workspace through the engine's own fields: point them at a set
+static void use_ws(nasr_engine *e, const nasr_engine::WS &w) {
+    e->x = w.x; e->x2 = w.x2; e->part = w.part; e->q = w.q; e->glu = w.glu; e->sub_a = w.sub_a; e->hfuse = w.hfuse;
+    e->a = w.a; e->hbuf = w.hbuf; e->ctx = w.ctx; e->cbuf = w.cbuf; e->sub_b = w.sub_b;
+}
+
 // ---------------------------------------------------------------------------------------
 static void engine_destroy_impl(nasr_engine *e);
 extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
@@ -629,21 +667,10 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     rc |= dalloc(e, &e->dec_c, S * 4 * HID);
     rc |= dalloc(e, &e->ctrl, S);
     rc |= dalloc(e, &e->tok_ring, S * TOK_CAP);
-    rc |= dalloc(e, &e->x, M * D);
-    rc |= dalloc(e, &e->x2, M * D);
-    rc |= dalloc(e, &e->part, 8 * M * D);
-    rc |= dalloc(e, &e->q, M * D);
-    rc |= dalloc(e, &e->glu, M * D);
+    memset(e->ws, 0, sizeof(e->ws));
+    rc |= alloc_ws(e, e->ws[0]);
+    use_ws(e, e->ws[0]);
     rc |= dalloc(e, &e->encproj, M * JNT);
-    rc |= dalloc(e, &e->hfuse, hp->num_prompts > 0 ? M * 2048 : 4);
-    { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->a = p; }
-    { char *p; rc |= dalloc(e, &p, M * FF * e->esz); e->hbuf = p; }
-    { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->ctx = p; }
-    { char *p; rc |= dalloc(e, &p, M * D * e->esz); e->cbuf = p; }
-    // subsampling ping-pong buffers, [chunks][H2][33][256] (conv0 is fused into the first depthwise conv and never
-    // stored).  Rows per encoder frame are largest for multi-chunk steps at R = 0: H2 = 2T + 3 = 5 per frame.
-    rc |= dalloc(e, &e->sub_a, M * 5 * 33 * SUBC);
-    { char *p; rc |= dalloc(e, &p, (M * 5 * 33 * SUBC) * 4); e->sub_b = p; }
     rc |= dalloc(e, &e->predg, S * JNT);
     rc |= dalloc(e, &e->key, M);
     rc |= dalloc(e, &e->n_active, 4);
@@ -704,20 +731,24 @@ static void engine_destroy_impl(nasr_engine *e) {
     for (void *p : e->allocs) hipFree(p);
     for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
     if (e->st2) hipStreamSynchronize(e->st2);
-    for (int p = 0; p < 2; p++) {
+    if (e->st3) hipStreamSynchronize(e->st3);
+    for (int p = 0; p < nasr_engine::NSLOT; p++) {
         nasr_engine::Pipe &P = e->pipe[p];
-        for (auto &kv : P.enc_graphs) hipGraphExecDestroy(kv.second);
+        for (auto &kv : P.seg0_graphs) hipGraphExecDestroy(kv.second);
+        for (auto &kv : P.seg1_graphs) hipGraphExecDestroy(kv.second);
         for (auto &kv : P.dec_graphs) hipGraphExecDestroy(kv.second);
         if (P.gh_dmeta) hipHostFree(P.gh_dmeta);
-        if (p == 1 && P.gh) hipHostFree(P.gh);           // parity 0 shares the engine's own block
+        if (p > 0 && P.gh) hipHostFree(P.gh);            // slot 0 shares the engine's own block
+        if (P.seg0_done) hipEventDestroy(P.seg0_done);
         if (P.enc_done) hipEventDestroy(P.enc_done);
-        if (P.dec_done) hipEventDestroy(P.dec_done);
     }
     if (e->st2) hipStreamDestroy(e->st2);
+    if (e->st3) hipStreamDestroy(e->st3);
     if (e->gh) hipHostFree(e->gh);
     if (e->pin) hipHostFree(e->pin);
     if (e->ddesc) hipFree(e->ddesc);
     if (e->pcm_stage) hipFree(e->pcm_stage);
+    for (auto &pin : e->pcm_pin) if (pin.p) hipHostFree(pin.p);
     if (e->mel_stage) hipFree(e->mel_stage);
     if (e->tap_mel) hipFree(e->tap_mel);
     if (e->tap_sub) hipFree(e->tap_sub);
@@ -790,6 +821,7 @@ static int stream_zero_state(nasr_stream *s, bool keep_reference_state = false) 
     s->tok_read = 0;
     s->samples_in = 0;
     s->last_T = 0;
+    s->last_ws = 0;
     return 0;
 }
 
@@ -875,13 +907,14 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
 }
 
 // ---- small-M form of the 24 layers: 8 launches per layer (kernels_fused.hip) ------------------------
-static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G) {
+// layers [l0, l1): a segment boundary hands over x (X[0]: four flips per layer) and the split-K partials of FFN2
+static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G, int l0, int l1) {
     const int TS = G * T;                      // rows per stream in this launch (G chunks batched)
     const int M = B * TS, nL = e->hp.n_layers, ks = e->hp.kernel_size;
     hipStream_t st = e->st;
     float *X[2] = {e->x, e->x2};
     int cur = 0;
-    int prev_splits = 0;          // split-K partials pending from the previous layer's FFN2
+    int prev_splits = l0 > 0 ? 4 : 0;   // split-K partials pending from the previous layer's FFN2
 #ifdef NASR_STAMPS
     unsigned long long *stamp_buf = g_stamp_buf;           // diagnostic build: 8 launches x 24 layers x 32 stamps
     int stamp_slot = 0;
@@ -894,7 +927,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         launch_fused_skinny(f, st);
     };
     auto wbytes = [&](int N, int K) { return (double)N * K * 2 + (double)M * (K + N) * 4; };
-    for (int l = 0; l < nL; l++) {
+    for (int l = l0; l < l1; l++) {
         LayerW &L = e->L[l];
         FusedParams f;
         // K1: [norm_out of layer l-1] + LN_ff1 -> W1 -> SiLU
@@ -984,6 +1017,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         launch(f, "k_fused_plain_gemm", wbytes(D, FF), 2.0 * M * D * FF);
         prev_splits = 4;
     }
+    if (l1 < nL) return 0;                     // the next segment's first kernel picks x and the partials up
     // x = norm_out(x + 0.5 * FFN2) of the last layer (cur is back at X[0] = e->x: 4 flips per layer)
     PostParams q;
     memset(&q, 0, sizeof(q));
@@ -999,20 +1033,33 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
 // host state changes -- capturable into a hipGraph.  tap_slots != null only in debug mode.
 // G > 1: G consecutive chunks of every stream in one launch sequence (rows of a stream are (chunk, frame)-major;
 // vrows has one descriptor per (stream, chunk) for the subsampling stage).  Only the fused small-M path does this.
-static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, const int *tap_slots, int B, int T, int R, int G = 1) {
+// seg: -1 = the whole encoder; 0 = subsampling + layers [0, L/2); 1 = layers [L/2, L) + prompt fusion + joint.enc (the two
+// halves of a skewed pipelined step, engine option "pipeline" = 2: they are captured into separate graphs)
+static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, const int *tap_slots, int B, int T, int R, int G = 1, int seg = -1) {
     const int Bs = B * G;                      // subsampling batch: one entry per (stream, chunk)
     const int M = Bs * T;
     const int chunk_mel = PRE_CACHE + 8 * (1 + R);
     hipStream_t st = e->st;
     const int act = e->bf16 ? 1 : 0;
+    const int nLayers = e->hp.n_layers;
+    const int l0 = seg == 1 ? nLayers / 2 : 0, l1 = seg == 0 ? nLayers / 2 : nLayers;
+    const bool front = seg != 1, tail = seg != 0;
+    GemmParams g;
 
+    // debug taps are indexed by slot: [slot][TMAX][1024] (+ layers)
+    auto tap_copy = [&](float *tap_base, size_t per_slot, size_t layer_off) -> int {
+        for (int b = 0; b < B; b++)
+            HIPCHK(hipMemcpyAsync(tap_base + (size_t)tap_slots[b] * per_slot + layer_off, e->x + (size_t)b * T * D,
+                                  (size_t)T * D * 4, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
     // ---- a-2 subsampling ------------------------------------------------------------------
     const int H1 = chunk_mel / 2 + 1, W1 = 65, H2 = H1 / 2 + 1, W2 = 33, H3 = H2 / 2 + 1, W3 = 17;
+    if (front) {
     {
         ProfScope ps(e, "k_sub_conv0_dw", (double)Bs * (chunk_mel * NMEL * 4 + H2 * W2 * SUBC * (act ? 2 : 4)), 2.0 * Bs * H2 * W2 * SUBC * 90);
         launch_sub_conv0_dw(vrows, Bs, chunk_mel, e->mel_ring, e->w0t, e->b0, e->w2t, e->b2, e->sub_b, act, H1, W1, st);
     }
-    GemmParams g;
     memset(&g, 0, sizeof(g));
     g.A = e->sub_b; g.W = e->w3; g.M = Bs * H2 * W2; g.N = SUBC; g.K = SUBC; g.lda = SUBC; g.splits = 1;
     g.epi = EPI_BIAS_RELU_F32; g.out_f32 = e->sub_a; g.ldo = SUBC; g.bias = e->b3;
@@ -1031,15 +1078,8 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     g.rows_per_batch = T; g.batch_stride = H3 * SUBFLAT; g.row_offset = DROP_EXTRA;
     g.epi = EPI_BIAS_F32; g.out_f32 = e->x; g.ldo = D; g.bias = e->sub_out_b;
     run_gemm(e, g, false, "sub_out");
-
-    // debug taps are indexed by slot: [slot][TMAX][1024] (+ layers)
-    auto tap_copy = [&](float *tap_base, size_t per_slot, size_t layer_off) -> int {
-        for (int b = 0; b < B; b++)
-            HIPCHK(hipMemcpyAsync(tap_base + (size_t)tap_slots[b] * per_slot + layer_off, e->x + (size_t)b * T * D,
-                                  (size_t)T * D * 4, hipMemcpyDeviceToDevice, st));
-        return 0;
-    };
     if (e->debug && tap_copy(e->tap_sub, (size_t)TMAX * D, 0)) return -1;
+    }   // front
 
     // Up to 4 rows the 8-launch fused layer wins; above, its per-workgroup prologues (every workgroup redoes the
     // LayerNorm of all rows) cost more than the 6 extra launches of the unfused layer (measured at R = 0:
@@ -1049,16 +1089,18 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     const int TS = G * T;                      // rows per stream in this launch
     if (G > 1 && e->debug) return fail("internal: multi-chunk steps are not available in debug mode");
     if (fused) {
-        if (run_layers_fused(e, rows, B, T, G)) return -1;
+        if (run_layers_fused(e, rows, B, T, G, l0, l1)) return -1;
     } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
-        PostParams pp;
-        memset(&pp, 0, sizeof(pp));
-        pp.x = e->x; pp.M = M; pp.ln2_w = e->L[0].ln_ff1_w; pp.ln2_b = e->L[0].ln_ff1_b; pp.a_out = e->a; pp.act_bf16 = act;
-        { ProfScope ps(e, "k_post", (double)M * D * (4 + e->esz)); launch_post(pp, st); }
+        if (front) {
+            PostParams pp;
+            memset(&pp, 0, sizeof(pp));
+            pp.x = e->x; pp.M = M; pp.ln2_w = e->L[0].ln_ff1_w; pp.ln2_b = e->L[0].ln_ff1_b; pp.a_out = e->a; pp.act_bf16 = act;
+            { ProfScope ps(e, "k_post", (double)M * D * (4 + e->esz)); launch_post(pp, st); }
+        }
 
         const int nL = e->hp.n_layers, ks = e->hp.kernel_size;
-        for (int l = 0; l < nL; l++) {
+        for (int l = l0; l < l1; l++) {
             LayerW &L = e->L[l];
             auto ffn = [&](void *w1, void *w2, const float *nln_w, const float *nln_b, bool last) {
                 GemmParams a;
@@ -1141,6 +1183,7 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
             if (e->debug && tap_copy(e->tap_layers, (size_t)nL * TMAX * D, (size_t)l * TMAX * D)) return -1;
         }
     }
+    if (!tail) return 0;
     // ---- a-11 prompt fusion (multilingual only, src/nemo-ggml.cpp:1087-1105) ---------------------
     if (e->hp.num_prompts > 0) {
         memset(&g, 0, sizeof(g));
@@ -1190,6 +1233,7 @@ static void chunk_bookkeeping(nasr_stream *s, int row) {
     s->chunks++;
     s->last_T = T;
     s->last_row = row;
+    s->last_ws = 0;                            // pipelined steps overwrite this with their slot
 }
 
 static void fill_row_desc(RowDesc &rd, const nasr_stream *s, int n_dec) {
@@ -1340,7 +1384,8 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         ApiGuard api_guard;
         HIPCHK(hipSetDevice(e->device));
         if (pipe_drain(e)) return -1;
-        e->opt_pipeline = value != 0;
+        if (value < 0 || value > 2) return fail("pipeline must be 0, 1 or 2");
+        e->opt_pipeline = value;
     }
     else return fail("unknown option '%s'", key);
     return 0;
@@ -1410,15 +1455,24 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraph
     return 0;
 }
 
-// ---- pipelined graph steps (engine option "pipeline") ------------------------------------------------------------------
-// A step is two graphs: the encoder graph (descriptors, front end, subsampling, layers, joint.enc projection) on the
-// engine's stream and the decode graph (begin, iterations, token gather, D2H) on a second stream.  The decode graph of
-// step s is launched when the encoder graph of step s has finished and runs BESIDE the encoder graph of step s + 1, which
-// the host has already launched: at batch 1 the decode tail (12 dependent launches), the read-back and the host turn-around (together ~7 % of a
-// step) leave the critical path.  The price is one step of token latency at this synchronous interface: the call of step s
-// returns the tokens of step s - 1; finalize / collect / any other entry point first completes what is in flight.
-// Two independent launch chains share the chip almost for free (tests/micro/overlap_probe.py: the 24-layer chain slows by
-// 10 % beside a second chain that is busy ALL the time; the decode graph is busy 5 % of it).
+// ---- pipelined graph steps (engine option "pipeline" = 1 or 2) ----------------------------------------------------------
+// A step is a chain of dependent launches (209 at batch 1, ~350 at 64 streams x R = 13) and the chip idles at every link
+// (boundary, arrival of the previous kernel's output, pipeline fill, epilogue tail: DESIGN.md section 5).  What fills those
+// gaps is a second, independent chain -- and consecutive steps of the SAME streams provide one: layer l of step s + 1 needs
+// from step s only what its layer l left in the K/V ring and the conv cache.  So the step is cut into pieces that run on
+// their own HIP streams, each piece one step behind the piece before it:
+//   depth 1:  [encoder graph of step s]            on st   beside  [decode graph of step s-1] on st2
+//   depth 2:  [front end + layers 0..L/2 of step s] on st  beside  [layers L/2..L + joint.enc of step s-1] on st3
+//                                                           beside  [decode graph of step s-2] on st2
+// Stream order keeps every piece behind the same piece of the previous step (layer l of step s + 1 after layer l of step
+// s); an event keeps it behind the previous piece of its own step.  Measured with two independent engines on one GPU
+// (tests/micro/lanes_probe.py, round 2): two chains side by side move 1.69x (batch 1), 1.60x (64 streams x 80 ms) and
+// 1.28x (64 streams x 1.12 s) the audio of one; a third and fourth add nothing.
+// The price is token latency at this synchronous interface: the call of step s returns the tokens of step s - depth;
+// finalize / collect / any other entry point first completes what is in flight.  Results are bit-identical to synchronous
+// stepping (same kernels, same inputs, same order per stream).  Everything a step in flight owns exists NSLOT = 3 times.
+// The decode graph is launched only once its input is ready: parked behind an event wait for the ~1 ms the encoder takes
+// it made every boundary of the encoder chain slower (round 1: 1.21 vs 1.07 ms per step at batch 1).
 static int pipe_blind_iterations(int frames) {
     // off the critical path an idle iteration is free: give one frame its worst case (10 symbols + the closing blank)
     const int worst = frames * MAX_SYMBOLS + 1;
@@ -1429,17 +1483,19 @@ static int pipe_blind_iterations(int frames) {
 static int ensure_pipe(nasr_engine *e) {
     if (e->pipe_ready) return 0;
     HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking));
     const size_t S = (size_t)e->max_streams, M = (size_t)e->w_rows;
-    for (int p = 0; p < 2; p++) {
+    for (int p = 0; p < nasr_engine::NSLOT; p++) {
         nasr_engine::Pipe &P = e->pipe[p];
+        HIPCHK(hipEventCreateWithFlags(&P.seg0_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&P.enc_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&P.dec_done, hipEventDisableTiming));
         if (p == 0) {
             P.g_desc = e->g_desc; P.gh = e->gh; P.gh_collect = e->gh_collect; P.collect_dev = e->collect_dev; P.encproj = e->encproj;
         } else {
             HIPCHK(hipHostMalloc((void **)&P.gh, e->desc_bytes + e->col_bytes, hipHostMallocDefault));
             P.gh_collect = (int *)(P.gh + e->desc_bytes);
             if (dalloc(e, &P.g_desc, e->desc_bytes) || dalloc(e, &P.collect_dev, S * (1 + COLLECT_STRIDE) + 4) || dalloc(e, &P.encproj, M * JNT)) return -1;
+            if (alloc_ws(e, e->ws[p])) return -1;
         }
         HIPCHK(hipHostMalloc((void **)&P.gh_dmeta, 2 * S * sizeof(int), hipHostMallocDefault));
         if (dalloc(e, &P.g_dmeta, 2 * S)) return -1;
@@ -1448,66 +1504,84 @@ static int ensure_pipe(nasr_engine *e) {
     return 0;
 }
 
-static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, hipGraphExec_t *enc_out, hipGraphExec_t *dec_out) {
+// the graphs of one (B, T, G, depth) on one slot: first encoder segment (or the whole encoder at depth 1), second segment
+// (depth 2), decode.  Their kernel arguments point into the slot's workspace set, descriptor block and joint.enc buffer.
+static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, int depth, hipGraphExec_t *seg0_out,
+                             hipGraphExec_t *seg1_out, hipGraphExec_t *dec_out) {
     nasr_engine::Pipe &P = e->pipe[p];
     const GraphDescLayout L = graph_desc_layout(B, G);
     const RowDesc *g_rows = (const RowDesc *)(P.g_desc + L.rows), *g_vrows = (const RowDesc *)(P.g_desc + L.vrows);
     const PcmDesc *g_pcm = (const PcmDesc *)(P.g_desc + L.pcm);
-    hipGraph_t graph = nullptr;
-    // encoder graph on the engine's stream; its last kernel writes this parity's joint.enc buffer
-    HIPCHK(hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
     float *const encproj_saved = e->encproj;
-    e->encproj = P.encproj;
-    auto enc_body = [&]() -> int {
-        HIPCHK(hipMemcpyAsync(P.g_desc, P.gh, L.total, hipMemcpyHostToDevice, e->st));
-        MelParams mp;
-        memset(&mp, 0, sizeof(mp));
-        mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
-        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
-        launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
-        return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G) ? -1 : 0;
-    };
-    int rc = enc_body();
-    e->encproj = encproj_saved;
-    hipError_t ce = hipStreamEndCapture(e->st, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
-    if (ce != hipSuccess) return fail("hipStreamEndCapture (encoder graph) failed: %s", hipGetErrorString(ce));
-    hipError_t ie = hipGraphInstantiate(enc_out, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (ie != hipSuccess) return fail("hipGraphInstantiate (encoder graph) failed: %s", hipGetErrorString(ie));
-    // decode graph on the second stream
-    graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(e->st2, hipStreamCaptureModeThreadLocal));
-    auto dec_body = [&]() -> int {
-        HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, e->st2));
-        DecParams dp;
-        make_dec_params(e, g_rows, B, T * G, dp);
-        dp.encproj = P.encproj;
-        launch_decode_begin(dp, e->st2);
-        int it = 0;
-        for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, e->st2);
-        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st2, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
-        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
+    auto capture = [&](hipStream_t st, const char *what, hipGraphExec_t *out, const std::function<int()> &body) -> int {
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        e->encproj = P.encproj;
+        use_ws(e, e->ws[p]);
+        const int rc = body();
+        e->encproj = encproj_saved;
+        use_ws(e, e->ws[0]);
+        hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+        if (ce != hipSuccess) return fail("hipStreamEndCapture (%s graph) failed: %s", what, hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail("hipGraphInstantiate (%s graph) failed: %s", what, hipGetErrorString(ie));
         return 0;
     };
-    rc = dec_body();
-    ce = hipStreamEndCapture(e->st2, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
-    if (ce != hipSuccess) return fail("hipStreamEndCapture (decode graph) failed: %s", hipGetErrorString(ce));
-    ie = hipGraphInstantiate(dec_out, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
-    if (ie != hipSuccess) return fail("hipGraphInstantiate (decode graph) failed: %s", hipGetErrorString(ie));
+    // first piece on the engine's stream: descriptors, front end, subsampling, layers [0, L/2) -- or the whole encoder
+    if (capture(e->st, "encoder", seg0_out, [&]() -> int {
+            HIPCHK(hipMemcpyAsync(P.g_desc, P.gh, L.total, hipMemcpyHostToDevice, e->st));
+            MelParams mp;
+            memset(&mp, 0, sizeof(mp));
+            mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+            mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+            launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
+            return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, depth == 2 ? 0 : -1) ? -1 : 0;
+        })) return -1;
+    *seg1_out = nullptr;
+    if (depth == 2 && capture(e->st, "encoder (second half)", seg1_out, [&]() -> int {
+            return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, 1) ? -1 : 0;
+        })) return -1;
+    // decode graph on the second stream
+    if (capture(e->st2, "decode", dec_out, [&]() -> int {
+            HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, e->st2));
+            DecParams dp;
+            make_dec_params(e, g_rows, B, T * G, dp);
+            dp.encproj = P.encproj;
+            launch_decode_begin(dp, e->st2);
+            int it = 0;
+            for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, e->st2);
+            hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st2, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+            HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
+            return 0;
+        })) return -1;
     return 0;
 }
 
-// Completes the step of parity p whose encoder graph is in flight: waits for it, launches its decode graph on the second
-// stream (by now the NEXT step's encoder graph is queued behind it on the engine's stream and starts at once), waits for
-// that, finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
-// The decode graph is launched only once its input is ready: a launch parked behind an event wait for the ~1 ms the
-// encoder takes made every boundary of the encoder chain slower (1.21 vs 1.07 ms per step at batch 1, measured).
+// second encoder piece of the step in slot p (depth 2): queued on st3 behind the first piece's event.  This wait is short
+// in steady state (the first piece was launched a whole call earlier) -- unlike the decode graph it is not parked for long.
+static int pipe_launch_seg1(nasr_engine *e, int p) {
+    nasr_engine::Pipe &P = e->pipe[p];
+    if (P.stage != 1) return 0;
+    if (P.depth == 2) {
+        static const bool host_wait = getenv("NASR_SKEW_HOSTWAIT") != nullptr;
+        if (host_wait) HIPCHK(hipEventSynchronize(P.seg0_done));
+        else HIPCHK(hipStreamWaitEvent(e->st3, P.seg0_done, 0));
+        HIPCHK(hipGraphLaunch(P.seg1_graphs[P.key], e->st3));
+        HIPCHK(hipEventRecord(P.enc_done, e->st3));
+    }
+    P.stage = 2;
+    return 0;
+}
+
+// Completes the step in slot p: (launches its second encoder piece if that has not happened,) waits for its encoder,
+// launches its decode graph on the decode stream (by now the next steps' encoder pieces are queued on their streams),
+// waits for that, finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
 static int pipe_finish(nasr_engine *e, int p) {
     nasr_engine::Pipe &P = e->pipe[p];
-    if (!P.pending) return 0;
+    if (P.stage == 0) return 0;
+    if (pipe_launch_seg1(e, p)) return -1;
     const int B = (int)P.streams.size(), TS = P.T * P.G;
     HIPCHK(hipEventSynchronize(P.enc_done));
     for (int b = 0; b < B; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[B + b] = P.streams[b]->tok_read; }
@@ -1534,15 +1608,20 @@ static int pipe_finish(nasr_engine *e, int p) {
         HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
         HIPCHK(hipStreamSynchronize(e->st2));
     }
-    P.pending = false;
+    P.stage = 0;
     return consume_collect(e, P.gh_collect, P.streams.data(), B);
 }
 
-// completes whatever the pipeline has in flight (tokens stay queued on their streams); cheap when nothing is
+// completes whatever the pipeline has in flight, oldest step first (tokens stay queued on their streams); cheap when nothing is
 static int pipe_drain(nasr_engine *e) {
     if (!e->pipe_ready) return 0;
-    for (int k = 0; k < 2; k++)
-        if (pipe_finish(e, e->pipe_parity ^ k)) return -1;                 // the older step first
+    for (int64_t q = e->pipe_seq - nasr_engine::NSLOT; q < e->pipe_seq; q++) {
+        if (q < 0) continue;
+        const int p = (int)(q % nasr_engine::NSLOT);
+        if (e->pipe[p].stage != 0 && e->pipe[p].seq == q && pipe_finish(e, p)) return -1;
+    }
+    // the synchronous paths that follow use workspace set 0 on the engine's stream: nothing of the other lanes may be running
+    if (e->st3) HIPCHK(hipStreamSynchronize(e->st3));
     return 0;
 }
 
@@ -1550,20 +1629,23 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     if (ensure_pipe(e)) return -1;
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
-    const int p = e->pipe_parity;
+    const int depth = e->opt_pipeline >= 2 && e->hp.n_layers >= 2 ? 2 : 1;
+    const int64_t seq = e->pipe_seq;
+    const int p = (int)(seq % nasr_engine::NSLOT);
     nasr_engine::Pipe &P = e->pipe[p];
-    if (pipe_finish(e, p)) return -1;                      // not in steady state: this parity was consumed a step ago
-    const int64_t key = ((int64_t)B << 32) | ((int64_t)T << 16) | (int64_t)G;
-    auto ge = P.enc_graphs.find(key);
-    if (ge == P.enc_graphs.end()) {
+    if (pipe_finish(e, p)) return -1;                      // the slot's previous occupant (NSLOT steps ago): done in steady state
+    const int64_t key = ((int64_t)B << 40) | ((int64_t)T << 24) | ((int64_t)G << 8) | (int64_t)depth;
+    auto ge = P.seg0_graphs.find(key);
+    if (ge == P.seg0_graphs.end()) {
         if (pipe_drain(e)) return -1;
         HIPCHK(hipStreamSynchronize(e->st));
-        hipGraphExec_t enc = nullptr, dec = nullptr;
+        hipGraphExec_t g0 = nullptr, g1 = nullptr, dec = nullptr;
         {
             CaptureExclusive alone;
-            if (build_pipe_graphs(e, p, B, T, R, G, &enc, &dec)) return -1;
+            if (build_pipe_graphs(e, p, B, T, R, G, depth, &g0, &g1, &dec)) return -1;
         }
-        ge = P.enc_graphs.emplace(key, enc).first;
+        ge = P.seg0_graphs.emplace(key, g0).first;
+        if (g1) P.seg1_graphs[key] = g1;
         P.dec_graphs[key] = dec;
     }
     const GraphDescLayout L = graph_desc_layout(B, G);
@@ -1586,7 +1668,7 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
         }
     }
     HIPCHK(hipGraphLaunch(ge->second, e->st));
-    HIPCHK(hipEventRecord(P.enc_done, e->st));
+    HIPCHK(hipEventRecord(depth == 2 ? P.seg0_done : P.enc_done, e->st));
     for (int b = 0; b < B; b++) {                          // every count is a pure function of the samples pushed
         nasr_stream *s = streams[b];
         const PcmDesc &d = gh_pcm[b];
@@ -1596,14 +1678,24 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
         const int par = s->cc_par;
         for (int g = 0; g < G; g++) chunk_bookkeeping(s, b);
         s->cc_par = par ^ 1;
-        s->last_T = T * G; s->last_row = b;
+        s->last_T = T * G; s->last_row = b; s->last_ws = p;
     }
-    P.pending = true;
+    P.stage = depth == 2 ? 1 : 2;
+    P.seq = seq;
+    P.depth = depth;
     P.streams.assign(streams, streams + B);
     P.T = T; P.G = G; P.key = key;
-    // the previous step: its encoder graph is finishing or done, this step's is queued right behind it; decode it now
-    if (pipe_finish(e, p ^ 1)) return -1;
-    e->pipe_parity ^= 1;
+    e->pipe_seq = seq + 1;
+    // the step before this one: its second encoder piece goes onto its lane now (its first piece has had a whole call)
+    if (seq >= 1) {
+        nasr_engine::Pipe &Q = e->pipe[(int)((seq - 1) % nasr_engine::NSLOT)];
+        if (Q.seq == seq - 1 && pipe_launch_seg1(e, (int)((seq - 1) % nasr_engine::NSLOT))) return -1;
+    }
+    // the step `depth` calls back: its encoder is finishing or done, everything younger is queued behind it; decode it now
+    if (seq >= depth) {
+        const int q = (int)((seq - depth) % nasr_engine::NSLOT);
+        if (e->pipe[q].seq == seq - depth && pipe_finish(e, q)) return -1;
+    }
     e->graph_replays++;
     e->pipe_steps++;
     deliver(streams, B, tokens_out, tokens_cap, n_tokens);
@@ -1802,13 +1894,22 @@ extern "C" int nasr_engine_step(nasr_engine *e, nasr_stream *const *streams, int
             e->pcm_stage_cap = total + 65536;
             HIPCHK(hipMalloc((void **)&e->pcm_stage, e->pcm_stage_cap * 2));
         }
+        auto &pin = e->pcm_pin[e->pcm_pin_next++ & 3];
+        if (total > pin.cap) {
+            HIPCHK(hipStreamSynchronize(e->st));
+            if (pin.p) hipHostFree(pin.p);
+            pin.p = nullptr;
+            pin.cap = total + 65536;
+            HIPCHK(hipHostMalloc((void **)&pin.p, pin.cap * 2, hipHostMallocDefault));
+        }
         size_t o = 0;
-        ProfScope ps(e, "h2d_pcm", (double)total * 2);
         for (int b = 0; b < B; b++) {
-            if (n_samples[b] > 0) HIPCHK(hipMemcpyAsync(e->pcm_stage + o, pcm[b], (size_t)n_samples[b] * 2, hipMemcpyHostToDevice, e->st));
+            if (n_samples[b] > 0) memcpy(pin.p + o, pcm[b], (size_t)n_samples[b] * 2);
             base[b] = e->pcm_stage + o;
             o += (size_t)n_samples[b];
         }
+        ProfScope ps(e, "h2d_pcm", (double)total * 2);
+        if (total > 0) HIPCHK(hipMemcpyAsync(e->pcm_stage, pin.p, total * 2, hipMemcpyHostToDevice, e->st));
     } else {
         for (int b = 0; b < B; b++) base[b] = pcm[b];
     }
@@ -2024,7 +2125,7 @@ extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, flo
         if (which == NASR_TAP_ENCODER_OUT && !(e->debug && need_debug())) {
             // without debug buffers: valid until the next chunk step of this engine
             if (e->hp.num_prompts > 0 || T == 0) return fail("encoder-out tap needs debug mode here");
-            HIPCHK(hipMemcpy(out, e->x + (size_t)s->last_row * T * D, (size_t)T * D * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(out, e->ws[s->last_ws].x + (size_t)s->last_row * T * D, (size_t)T * D * 4, hipMemcpyDeviceToHost));
             return (int64_t)T * D;
         }
         if (!need_debug()) return fail("debug taps not enabled");

@@ -132,9 +132,9 @@ nemo_context *nemo_init_with_device(const char *model_path, int device, int dtyp
 
 nemo_context *nemo_init(const char *model_path) { return nemo_init_with_device(model_path, 0, NASR_DTYPE_BF16, 64); }
 
-bool nemo_set_pipeline(nemo_context *ctx, bool on) {
+bool nemo_set_pipeline(nemo_context *ctx, int depth) {
     if (!ctx || !ctx->engine) return false;
-    if (nasr_engine_set_option(ctx->engine, "pipeline", on ? 1 : 0) < 0) {
+    if (nasr_engine_set_option(ctx->engine, "pipeline", depth) < 0) {
         fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
         return false;
     }

@@ -16,12 +16,13 @@
 
 static void usage(const char *prog) {
     fprintf(stderr,
-            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline]\n"
+            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline | --pipeline2]\n"
             "  audio: raw s16le, 16 kHz, mono.  right_context in {0, 1, 6, 13} (80 ms .. 1.12 s lookahead)\n"
             "  --read-chunks N: read N chunks of audio per call (default 1 = the reference's read size); a file is\n"
             "                   transcribed fastest with N = 256: same transcript, the chunks of a read share one launch sequence\n"
             "  --timestamps:    print the final transcript again with {seconds} in front of every word\n"
             "  --pipeline:      decode of one read runs beside the encoder of the next (same transcript; each delta appears one read later)\n"
+            "  --pipeline2:     in addition the two halves of the encoder of consecutive reads run side by side (deltas two reads later)\n"
             "  --diarize <diarize.gguf> [--rttm <file>] [--speaker-text <file>] [--json <file>] [--num-speakers K] [--sub-shift SEC] [--vad-onset P] [--vad-offset P]\n"
             "                   speaker diarization beside the transcript (speaker-tagged transcript on stdout at EOF)\n", prog);
 }
@@ -31,7 +32,8 @@ int main(int argc, char **argv) {
     const char *model_path = argv[1], *audio_path = argv[2];
     int chunk_ms = 80, right_context = 0, device = 0, dtype = 1, positional = 0;
     const char *lang = nullptr;
-    bool print_tokens = false, timestamps = false, pipeline = false;
+    bool print_tokens = false, timestamps = false;
+    int pipeline = 0;
     int read_chunks = 1, num_speakers = -1;
     float sub_shift_sec = 0.75f, vad_onset = -1.0f, vad_offset = -1.0f;
     std::string diarize_gguf, rttm_path, speaker_text_path, json_path;
@@ -43,7 +45,8 @@ int main(int argc, char **argv) {
         else if (a == "--f32") dtype = 0;
         else if (a == "--print-tokens") print_tokens = true;
         else if (a == "--timestamps") timestamps = true;
-        else if (a == "--pipeline") pipeline = true;
+        else if (a == "--pipeline") pipeline = 1;
+        else if (a == "--pipeline2") pipeline = 2;
         else if (a == "--read-chunks" && i + 1 < argc) read_chunks = atoi(argv[++i]);
         else if (a == "--diarize" && i + 1 < argc) diarize_gguf = argv[++i];
         else if (a == "--rttm" && i + 1 < argc) rttm_path = argv[++i];
@@ -64,7 +67,7 @@ int main(int argc, char **argv) {
 
     nemo_context *ctx = nemo_init_with_device(model_path, device, dtype, 1);
     if (!ctx) { fprintf(stderr, "Failed to load ASR model\n"); return 1; }
-    if (pipeline && !nemo_set_pipeline(ctx, true)) { fprintf(stderr, "Failed to enable pipelined steps\n"); nemo_free(ctx); return 1; }
+    if (pipeline && !nemo_set_pipeline(ctx, pipeline)) { fprintf(stderr, "Failed to enable pipelined steps\n"); nemo_free(ctx); return 1; }
     if (lang && !nemo_set_language(ctx, lang)) { fprintf(stderr, "Failed to set language '%s'\n", lang); nemo_free(ctx); return 1; }
     nemo_cache_config cfg = nemo_cache_config::default_config();
     cfg.att_right_context = right_context;

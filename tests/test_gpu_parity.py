@@ -185,7 +185,7 @@ def test_graph_replay_equals_eager(W, om32, dtype, R, B):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype,R,B", [(capi.DTYPE_F32, 0, 2), (capi.DTYPE_BF16, 0, 1), (capi.DTYPE_BF16, 13, 3), (capi.DTYPE_F32, 1, 1)])
+@pytest.mark.parametrize("dtype,R,B", [(capi.DTYPE_F32, 0, 2), (capi.DTYPE_BF16, 0, 1), (capi.DTYPE_BF16, 13, 3), (capi.DTYPE_F32, 1, 1), (capi.DTYPE_BF16, 1, 8)])
 def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
     """Engine option "pipeline": the decode graph of step s runs on a second HIP stream beside the encoder graph of step
     s + 1 and the call of step s returns the tokens of step s - 1.  Same kernels on the same inputs: the token stream, the
@@ -198,7 +198,7 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
     pcms = [synth.make_pcm(60 + b, secs) for b in range(2 * B)]
     n_steps = pcms[0].size // piece
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         eng.set_option("pipeline", mode)
         grp = [[eng.stream(R) for _ in range(B)] for _ in range(2)]      # two groups of streams take turns
         toks = [[] for _ in range(2 * B)]
@@ -229,10 +229,12 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
         for g in range(2):
             for s in grp[g]:
                 s.destroy()
-    assert res[1][0] == res[0][0] and sum(len(t) for t in res[0][0]) > 0
-    assert np.array_equal(res[1][1], res[0][1]) and np.array_equal(res[1][2], res[0][2])
-    assert [st[0] for st in res[1][3]] == [st[0] for st in res[0][3]] and res[0][3][0][0] > 5
-    assert [st[2] for st in res[1][3]] == [st[2] for st in res[0][3]]
+    assert sum(len(t) for t in res[0][0]) > 0 and res[0][3][0][0] > 5
+    for mode in (1, 2):       # 1: decode beside the next encoder; 2: + the encoder halves of consecutive steps side by side
+        assert res[mode][0] == res[0][0], mode
+        assert np.array_equal(res[mode][1], res[0][1]) and np.array_equal(res[mode][2], res[0][2]), mode
+        assert [st[0] for st in res[mode][3]] == [st[0] for st in res[0][3]]
+        assert [st[2] for st in res[mode][3]] == [st[2] for st in res[0][3]]
     if dtype == capi.DTYPE_F32:          # token-exact against the oracle, stream 0
         ost = ob.OracleStream(om32, R)
         to = []
@@ -599,7 +601,7 @@ B, R = 4, 1
 piece = synth.shift_samples(R)
 pcms = [synth.make_pcm(80 + b, 6.0) for b in range(B)]
 res = {{}}
-for mode in (0, 1):
+for mode in (0, 1, 2):
     eng = capi.Engine(W, n_layers=2, dtype=capi.DTYPE_F32, max_streams=B)
     eng.set_option("pipeline", mode)
     sts = [eng.stream(R) for _ in range(B)]
@@ -615,7 +617,7 @@ for mode in (0, 1):
     for s in sts:
         s.destroy()
     eng.close()
-assert res[0] == res[1], "pipelined tokens differ"
+assert res[0] == res[1] == res[2], "pipelined tokens differ"
 om = ob.OracleModel(W, 2)
 for b in range(B):
     ost = ob.OracleStream(om, R)
@@ -631,6 +633,7 @@ print("TOKENS", sum(len(t) for t in res[1]))
     assert r.returncode == 0, r.stderr[-2000:]
     assert int(r.stdout.split("TOKENS")[1].split()[0]) > 20
     stats = [ln for ln in r.stderr.splitlines() if "decode fallbacks" in ln]
-    assert len(stats) == 2
+    assert len(stats) == 3
     n_fallback = int(stats[1].split("decode fallbacks")[1].split()[0])        # second engine = pipelined
+    assert int(stats[2].split("decode fallbacks")[1].split()[0]) > 0           # third = skewed encoder halves too
     assert "pipelined" in stats[1] and n_fallback > 0, stats
