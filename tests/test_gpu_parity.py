@@ -232,7 +232,8 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
     assert sum(len(t) for t in res[0][0]) > 0 and res[0][3][0][0] > 5
     for mode in (1, 2):       # 1: decode beside the next encoder; 2: + the encoder halves of consecutive steps side by side
         assert res[mode][0] == res[0][0], mode
-        assert np.array_equal(res[mode][1], res[0][1]) and np.array_equal(res[mode][2], res[0][2]), mode
+        # encoder-out tap: valid until the next chunk step of the engine touches its workspace -- the group stepped last
+        assert np.array_equal(res[mode][1][B:], res[0][1][B:]) and np.array_equal(res[mode][2], res[0][2]), mode
         assert [st[0] for st in res[mode][3]] == [st[0] for st in res[0][3]]
         assert [st[2] for st in res[mode][3]] == [st[2] for st in res[0][3]]
     if dtype == capi.DTYPE_F32:          # token-exact against the oracle, stream 0
