@@ -73,9 +73,11 @@ def parse(argv=None):
     ap.add_argument("--sync-steps", action="store_true",
                     help="every step returns its own tokens before the next one starts (engine option pipeline = 0); default: "
                          "pipelined steps, the decode graph of step s runs on a second HIP stream beside the encoder graph of step s + 1")
-    ap.add_argument("--pipeline-depth", type=int, default=2, choices=[1, 2],
-                    help="1: decode of step s beside the encoder of step s + 1; 2 (default): in addition layers L/2..L of step s beside "
-                         "layers 0..L/2 of step s + 1 (engine option pipeline)")
+    ap.add_argument("--pipeline-depth", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="engine option pipeline = E: the encoder in E pieces of L / E layers, piece k of step s beside piece k + 1 of step "
+                         "s - 1 ..., the decode of step s - E beside them (1: only the decode beside the next encoder)")
+    ap.add_argument("--regions", type=int, default=REPEATS, help="timed regions of K steps (the median is reported)")
+    ap.add_argument("--no-host-pcm", action="store_true", help="skip the host-PCM (H2D inside the timed region) figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=60.0,
                     help="audio seconds of the CPU-baseline sample (~10-20 s of CPU work on 16 host threads)")
@@ -397,14 +399,16 @@ def main():
         run.step()
     run.drain()                                # pipelined steps: the last warm-up step's tokens are not the timed region's
     run.tokens = 0
-    regions = timed_regions(run, args.steps, barrier, max_over_ranks)
+    regions = timed_regions(run, args.steps, barrier, max_over_ranks, repeats=args.regions)
     run.drain()
     tokens_timed, chunks_timed = run.tokens, run.streams[0].progress().chunks
     head = summarize(regions, args.steps, run.audio_per_step, world)
-    host_regions = timed_regions(run, args.steps, barrier, max_over_ranks, host=True, repeats=3)
-    run.drain()
-    host_pcm = summarize(host_regions, args.steps, run.audio_per_step, world)
-    host_pcm["note"] = "same steps with the PCM handed over as HOST buffers: one gathered H2D copy per step inside the timed region"
+    host_pcm = None
+    if not args.no_host_pcm:
+        host_regions = timed_regions(run, args.steps, barrier, max_over_ranks, host=True, repeats=min(3, args.regions))
+        run.drain()
+        host_pcm = summarize(host_regions, args.steps, run.audio_per_step, world)
+        host_pcm["note"] = "same steps with the PCM handed over as HOST buffers: one gathered H2D copy per step inside the timed region"
     step_s = statistics.median(regions) / args.steps
 
     roofline, kernels = None, []
@@ -605,7 +609,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "timing": f"median of {REPEATS} regions of {args.steps} steps, each bracketed by barrier + device synchronise, max over ranks",
+            "timing": f"median of {args.regions} regions of {args.steps} steps, each bracketed by barrier + device synchronise, max over ranks",
             "runs_ms_per_step": head["runs_ms_per_step"],
             "config": {
                 "workload": f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}"
@@ -617,9 +621,10 @@ def main():
                 "parallelism": f"stream-sharded x{world}, no collectives",
                 "pcm": "device-resident", "tokens_emitted": tokens_timed, "chunks": chunks_timed,
                 "steps": "synchronous" if args.sync_steps else
-                         ("pipelined, depth 1: decode graph of step s on a second HIP stream beside the encoder graph of step s+1" if args.pipeline_depth == 1 else
-                          "pipelined, depth 2: layers 0..L/2 of step s+2, layers L/2..L of step s+1 and the decode of step s side by side on three HIP streams "
-                          "(same kernels, same per-stream order, bit-identical results; tokens two calls later)"),
+                         ("pipelined, E = 1: decode graph of step s on a second HIP stream beside the encoder graph of step s+1" if args.pipeline_depth == 1 else
+                          f"pipelined, E = {args.pipeline_depth}: the encoder in {args.pipeline_depth} pieces of L/{args.pipeline_depth} layers; piece k of step s-k and the "
+                          f"decode of step s-{args.pipeline_depth} run side by side on {args.pipeline_depth + 1} HIP streams (same kernels, same per-stream order, "
+                          f"bit-identical results; tokens {args.pipeline_depth} calls later)"),
             },
             "host_pcm": host_pcm,
             "synchronous_ms_per_step": round(1e3 * sync_step_s, 4) if sync_step_s else None,

@@ -184,13 +184,14 @@ enum {
 };
 /* engine options: "fused" (1: small-M fused layer kernels, default) / "graph" (1: hipGraph replay of the
  * steady-state step, default) / "multichunk" (1, default) are pure performance switches; results are unchanged.
- * "pipeline" (0, default; 1 or 2): launch sequences of consecutive steps run beside each other on their own HIP streams.
- * 1: the decode graph of step s runs beside the encoder graph of step s + 1.  2: in addition the encoder is cut in two
- * halves and layers L/2..L of step s run beside layers 0..L/2 of step s + 1 (layer l of a step needs from the previous
- * step only what its layer l left in the K/V ring and the conv cache).  The same tokens come out, `pipeline` calls later:
- * nasr_engine_step returns what has been decoded so far; nasr_engine_finalize, nasr_engine_collect and every other entry
- * point first complete the steps in flight.  Results are bit-identical to synchronous stepping.  Throughput option for
- * callers that push back to back (a server draining a backlog, a file); a live stream keeps the default. */
+ * "pipeline" (0, default; E = 1..4): launch sequences of consecutive steps run beside each other on their own HIP streams.
+ * The encoder is cut into E pieces of L / E layers and a step's piece k + 1 runs one call after its piece k, beside piece k
+ * of the next step; the decode follows one call after the last piece (layer l of a step needs from the previous step only
+ * what its layer l left in the K/V ring and the conv cache).  E = 1: the decode graph of step s beside the encoder graph
+ * of step s + 1.  The same tokens come out, E calls later: nasr_engine_step returns what has been decoded so far;
+ * nasr_engine_finalize, nasr_engine_collect and every other entry point first complete the steps in flight.  Results are
+ * bit-identical to synchronous stepping.  Throughput option for callers that push back to back (a server draining a
+ * backlog, a file); a live stream keeps the default. */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);

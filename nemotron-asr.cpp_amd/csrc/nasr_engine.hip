@@ -9,6 +9,7 @@
 #include "nemotron_asr_amd.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -134,28 +135,31 @@ struct nasr_engine {
     char *gh = nullptr;                                                               // pinned host block
     int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active
     int64_t graph_replays = 0, eager_steps = 0, decode_fallbacks = 0, decode_fallback_rounds = 0;
-    // pipelined graph steps (option "pipeline", 1 or 2): launch sequences of CONSECUTIVE steps run beside each other on
-    // their own HIP streams -- see the comment at pipe_step().  Everything a step in flight owns exists NSLOT times:
+    // pipelined graph steps (option "pipeline" = E, 1..4): launch sequences of CONSECUTIVE steps run beside each other on
+    // their own HIP streams -- see the comment at pipe_step().  Everything a step in flight owns exists once per slot:
     // workspace set, descriptor blocks, joint.enc buffer, token landing zone, graphs (their kernel arguments point into
-    // the slot).  Slot of a step = its sequence number mod NSLOT.
-    static const int NSLOT = 3;
+    // the slot).  E + 1 steps are in flight; slot of a step = its sequence number mod NSLOT.
+    static const int MAXSEG = 4, NSLOT = MAXSEG + 1;
     struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; };
     WS ws[NSLOT];                    // ws[0] = the set the synchronous paths use (mirrored in x, x2, ... below)
-    int opt_pipeline = 0;            // 0: synchronous steps; 1: decode beside the next encoder; 2: + the two encoder halves skewed
-    hipStream_t st2 = nullptr, st3 = nullptr;      // st2: decode graphs, st3: second encoder lane (layers L/2 .. L)
+    int opt_pipeline = 0;            // 0: synchronous steps; E >= 1: the encoder in E pieces + the decode, each piece one step behind the previous
+    hipStream_t st2 = nullptr;       // decode graphs
+    hipStream_t lane[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};   // lane[k]: encoder piece k (lane[0] = st)
     struct Pipe {
+        bool ready = false;                               // buffers of this slot allocated
         char *g_desc = nullptr, *gh = nullptr;            // descriptor block of the encoder graphs (device / pinned)
         int *gh_collect = nullptr, *collect_dev = nullptr;
         int *g_dmeta = nullptr, *gh_dmeta = nullptr;      // k_collect meta of the decode graph [2 B] (device / pinned)
         float *encproj = nullptr;                         // [w_rows][640]: encoder graph -> decode graph
-        hipEvent_t seg0_done = nullptr, enc_done = nullptr;
-        std::map<int64_t, hipGraphExec_t> seg0_graphs, seg1_graphs, dec_graphs;     // key = (B, T, G, depth)
-        int stage = 0;                                    // 0 free, 1 first encoder segment launched, 2 whole encoder launched
+        hipEvent_t seg_done[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};
+        std::map<int64_t, hipGraphExec_t> seg_graphs[MAXSEG], dec_graphs;     // key = (B, T, G, E)
+        int stage = 0;                                    // encoder pieces launched so far (0 = slot free)
         int64_t seq = -1;                                 // sequence number of the step that occupies the slot
         std::vector<nasr_stream *> streams;
-        int T = 0, G = 0, depth = 0;
+        int T = 0, G = 0, nseg = 0;
         int64_t key = 0;
     } pipe[NSLOT];
+    double host_launch_s = 0, host_wait_s = 0;     // NASR_STATS: host time inside hipGraphLaunch / waiting for the device (pipelined steps)
     int64_t pipe_seq = 0;            // steps launched through the pipeline so far
     bool pipe_ready = false;
     size_t desc_bytes = 0, col_bytes = 0;
@@ -725,25 +729,25 @@ static void engine_destroy_impl(nasr_engine *e) {
     hipSetDevice(e->device);
     if (e->st) hipStreamSynchronize(e->st);
     if (getenv("NASR_STATS"))
-        fprintf(stderr, "nasr: graph replays %lld (%lld pipelined), eager steps %lld, decode fallbacks %lld (%lld rounds)\n", (long long)e->graph_replays,
-                (long long)e->pipe_steps, (long long)e->eager_steps, (long long)e->decode_fallbacks, (long long)e->decode_fallback_rounds);
+        fprintf(stderr, "nasr: graph replays %lld (%lld pipelined), eager steps %lld, decode fallbacks %lld (%lld rounds); pipelined steps: host %.1f us in "
+                "hipGraphLaunch + %.1f us waiting per step\n", (long long)e->graph_replays,
+                (long long)e->pipe_steps, (long long)e->eager_steps, (long long)e->decode_fallbacks, (long long)e->decode_fallback_rounds,
+                e->pipe_steps ? 1e6 * e->host_launch_s / e->pipe_steps : 0.0, e->pipe_steps ? 1e6 * e->host_wait_s / e->pipe_steps : 0.0);
     for (auto *s : e->slots) delete s;
     for (void *p : e->allocs) hipFree(p);
     for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
     if (e->st2) hipStreamSynchronize(e->st2);
-    if (e->st3) hipStreamSynchronize(e->st3);
+    for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamSynchronize(e->lane[k]);
     for (int p = 0; p < nasr_engine::NSLOT; p++) {
         nasr_engine::Pipe &P = e->pipe[p];
-        for (auto &kv : P.seg0_graphs) hipGraphExecDestroy(kv.second);
-        for (auto &kv : P.seg1_graphs) hipGraphExecDestroy(kv.second);
+        for (auto &m : P.seg_graphs) for (auto &kv : m) hipGraphExecDestroy(kv.second);
         for (auto &kv : P.dec_graphs) hipGraphExecDestroy(kv.second);
         if (P.gh_dmeta) hipHostFree(P.gh_dmeta);
         if (p > 0 && P.gh) hipHostFree(P.gh);            // slot 0 shares the engine's own block
-        if (P.seg0_done) hipEventDestroy(P.seg0_done);
-        if (P.enc_done) hipEventDestroy(P.enc_done);
+        for (auto ev : P.seg_done) if (ev) hipEventDestroy(ev);
     }
     if (e->st2) hipStreamDestroy(e->st2);
-    if (e->st3) hipStreamDestroy(e->st3);
+    for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamDestroy(e->lane[k]);
     if (e->gh) hipHostFree(e->gh);
     if (e->pin) hipHostFree(e->pin);
     if (e->ddesc) hipFree(e->ddesc);
@@ -1033,17 +1037,19 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
 // host state changes -- capturable into a hipGraph.  tap_slots != null only in debug mode.
 // G > 1: G consecutive chunks of every stream in one launch sequence (rows of a stream are (chunk, frame)-major;
 // vrows has one descriptor per (stream, chunk) for the subsampling stage).  Only the fused small-M path does this.
-// seg: -1 = the whole encoder; 0 = subsampling + layers [0, L/2); 1 = layers [L/2, L) + prompt fusion + joint.enc (the two
-// halves of a skewed pipelined step, engine option "pipeline" = 2: they are captured into separate graphs)
-static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, const int *tap_slots, int B, int T, int R, int G = 1, int seg = -1) {
+// seg / nseg: piece `seg` of `nseg` of the encoder (pipelined steps capture every piece into its own graph): piece k covers
+// layers [L k / nseg, L (k + 1) / nseg); piece 0 starts with the subsampling, the last piece ends with prompt fusion and
+// joint.enc.  nseg = 1: the whole encoder.
+static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, const int *tap_slots, int B, int T, int R, int G = 1, int seg = 0,
+                           int nseg = 1) {
     const int Bs = B * G;                      // subsampling batch: one entry per (stream, chunk)
     const int M = Bs * T;
     const int chunk_mel = PRE_CACHE + 8 * (1 + R);
     hipStream_t st = e->st;
     const int act = e->bf16 ? 1 : 0;
     const int nLayers = e->hp.n_layers;
-    const int l0 = seg == 1 ? nLayers / 2 : 0, l1 = seg == 0 ? nLayers / 2 : nLayers;
-    const bool front = seg != 1, tail = seg != 0;
+    const int l0 = nLayers * seg / nseg, l1 = nLayers * (seg + 1) / nseg;
+    const bool front = seg == 0, tail = seg == nseg - 1;
     GemmParams g;
 
     // debug taps are indexed by slot: [slot][TMAX][1024] (+ layers)
@@ -1384,7 +1390,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         ApiGuard api_guard;
         HIPCHK(hipSetDevice(e->device));
         if (pipe_drain(e)) return -1;
-        if (value < 0 || value > 2) return fail("pipeline must be 0, 1 or 2");
+        if (value < 0 || value > nasr_engine::MAXSEG) return fail("pipeline must be 0 .. %d", (int)nasr_engine::MAXSEG);
         e->opt_pipeline = value;
     }
     else return fail("unknown option '%s'", key);
@@ -1455,24 +1461,29 @@ static int build_step_graph(nasr_engine *e, int B, int T, int R, int G, hipGraph
     return 0;
 }
 
-// ---- pipelined graph steps (engine option "pipeline" = 1 or 2) ----------------------------------------------------------
+// ---- pipelined graph steps (engine option "pipeline" = E, 1..4) ----------------------------------------------------------
 // A step is a chain of dependent launches (209 at batch 1, ~350 at 64 streams x R = 13) and the chip idles at every link
 // (boundary, arrival of the previous kernel's output, pipeline fill, epilogue tail: DESIGN.md section 5).  What fills those
-// gaps is a second, independent chain -- and consecutive steps of the SAME streams provide one: layer l of step s + 1 needs
-// from step s only what its layer l left in the K/V ring and the conv cache.  So the step is cut into pieces that run on
-// their own HIP streams, each piece one step behind the piece before it:
-//   depth 1:  [encoder graph of step s]            on st   beside  [decode graph of step s-1] on st2
-//   depth 2:  [front end + layers 0..L/2 of step s] on st  beside  [layers L/2..L + joint.enc of step s-1] on st3
-//                                                           beside  [decode graph of step s-2] on st2
-// Stream order keeps every piece behind the same piece of the previous step (layer l of step s + 1 after layer l of step
-// s); an event keeps it behind the previous piece of its own step.  Measured with two independent engines on one GPU
-// (tests/micro/lanes_probe.py, round 2): two chains side by side move 1.69x (batch 1), 1.60x (64 streams x 80 ms) and
-// 1.28x (64 streams x 1.12 s) the audio of one; a third and fourth add nothing.
-// The price is token latency at this synchronous interface: the call of step s returns the tokens of step s - depth;
+// gaps is another, independent chain -- and consecutive steps of the SAME streams provide one: layer l of step s + 1 needs
+// from step s only what its layer l left in the K/V ring and the conv cache.  So the step is cut into E encoder pieces
+// (piece k = layers [L k / E, L (k + 1) / E); piece 0 starts with the front end and the subsampling, the last one ends with
+// joint.enc) plus the decode, each on its own HIP stream and each one step behind the piece before it:
+//   call s:   piece 0 of step s | piece 1 of step s-1 | ... | piece E-1 of step s-E+1 | decode of step s-E
+// Stream order keeps a piece behind the same piece of the previous step (layer l of step s + 1 after layer l of step s);
+// an event keeps it behind the previous piece of its own step.  E = 1 is "decode beside the next encoder".
+// Measured with independent engines on one GPU (tests/micro/lanes_probe.py, round 2): two chains side by side move 1.69x
+// (batch 1), 1.60x (64 streams x 80 ms) and 1.28x (64 streams x 1.12 s) the audio of one.
+// The price is token latency at this synchronous interface: the call of step s returns the tokens of step s - E;
 // finalize / collect / any other entry point first completes what is in flight.  Results are bit-identical to synchronous
-// stepping (same kernels, same inputs, same order per stream).  Everything a step in flight owns exists NSLOT = 3 times.
+// stepping (same kernels, same inputs, same order per stream).  Everything a step in flight owns exists once per slot.
 // The decode graph is launched only once its input is ready: parked behind an event wait for the ~1 ms the encoder takes
 // it made every boundary of the encoder chain slower (round 1: 1.21 vs 1.07 ms per step at batch 1).
+struct HostTimer {          // accumulates wall time of a scope into a double (diagnostics only: NASR_STATS)
+    double &acc; std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 static int pipe_blind_iterations(int frames) {
     // off the critical path an idle iteration is free: give one frame its worst case (10 symbols + the closing blank)
     const int worst = frames * MAX_SYMBOLS + 1;
@@ -1480,34 +1491,35 @@ static int pipe_blind_iterations(int frames) {
     return std::max(decode_blind_iterations(frames), std::min(worst, cap));
 }
 
-static int ensure_pipe(nasr_engine *e) {
-    if (e->pipe_ready) return 0;
-    HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->st3, hipStreamNonBlocking));
-    const size_t S = (size_t)e->max_streams, M = (size_t)e->w_rows;
-    for (int p = 0; p < nasr_engine::NSLOT; p++) {
-        nasr_engine::Pipe &P = e->pipe[p];
-        HIPCHK(hipEventCreateWithFlags(&P.seg0_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&P.enc_done, hipEventDisableTiming));
-        if (p == 0) {
-            P.g_desc = e->g_desc; P.gh = e->gh; P.gh_collect = e->gh_collect; P.collect_dev = e->collect_dev; P.encproj = e->encproj;
-        } else {
-            HIPCHK(hipHostMalloc((void **)&P.gh, e->desc_bytes + e->col_bytes, hipHostMallocDefault));
-            P.gh_collect = (int *)(P.gh + e->desc_bytes);
-            if (dalloc(e, &P.g_desc, e->desc_bytes) || dalloc(e, &P.collect_dev, S * (1 + COLLECT_STRIDE) + 4) || dalloc(e, &P.encproj, M * JNT)) return -1;
-            if (alloc_ws(e, e->ws[p])) return -1;
-        }
-        HIPCHK(hipHostMalloc((void **)&P.gh_dmeta, 2 * S * sizeof(int), hipHostMallocDefault));
-        if (dalloc(e, &P.g_dmeta, 2 * S)) return -1;
+// streams, events and the buffers of slot p (allocated when first used: E + 1 slots for E encoder pieces)
+static int ensure_pipe(nasr_engine *e, int p) {
+    if (!e->st2) {
+        HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+        e->lane[0] = e->st;
+        for (int k = 1; k < nasr_engine::MAXSEG; k++) HIPCHK(hipStreamCreateWithFlags(&e->lane[k], hipStreamNonBlocking));
+        e->pipe_ready = true;
     }
-    e->pipe_ready = true;
+    nasr_engine::Pipe &P = e->pipe[p];
+    if (P.ready) return 0;
+    const size_t S = (size_t)e->max_streams, M = (size_t)e->w_rows;
+    for (auto &ev : P.seg_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (p == 0) {
+        P.g_desc = e->g_desc; P.gh = e->gh; P.gh_collect = e->gh_collect; P.collect_dev = e->collect_dev; P.encproj = e->encproj;
+    } else {
+        HIPCHK(hipHostMalloc((void **)&P.gh, e->desc_bytes + e->col_bytes, hipHostMallocDefault));
+        P.gh_collect = (int *)(P.gh + e->desc_bytes);
+        if (dalloc(e, &P.g_desc, e->desc_bytes) || dalloc(e, &P.collect_dev, S * (1 + COLLECT_STRIDE) + 4) || dalloc(e, &P.encproj, M * JNT)) return -1;
+        if (alloc_ws(e, e->ws[p])) return -1;
+    }
+    HIPCHK(hipHostMalloc((void **)&P.gh_dmeta, 2 * S * sizeof(int), hipHostMallocDefault));
+    if (dalloc(e, &P.g_dmeta, 2 * S)) return -1;
+    P.ready = true;
     return 0;
 }
 
-// the graphs of one (B, T, G, depth) on one slot: first encoder segment (or the whole encoder at depth 1), second segment
-// (depth 2), decode.  Their kernel arguments point into the slot's workspace set, descriptor block and joint.enc buffer.
-static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, int depth, hipGraphExec_t *seg0_out,
-                             hipGraphExec_t *seg1_out, hipGraphExec_t *dec_out) {
+// the graphs of one (B, T, G, E) on one slot: the E encoder pieces and the decode.  Their kernel arguments point into the
+// slot's workspace set, descriptor block and joint.enc buffer.
+static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, int nseg, hipGraphExec_t *seg_out, hipGraphExec_t *dec_out) {
     nasr_engine::Pipe &P = e->pipe[p];
     const GraphDescLayout L = graph_desc_layout(B, G);
     const RowDesc *g_rows = (const RowDesc *)(P.g_desc + L.rows), *g_vrows = (const RowDesc *)(P.g_desc + L.vrows);
@@ -1529,21 +1541,21 @@ static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, 
         if (ie != hipSuccess) return fail("hipGraphInstantiate (%s graph) failed: %s", what, hipGetErrorString(ie));
         return 0;
     };
-    // first piece on the engine's stream: descriptors, front end, subsampling, layers [0, L/2) -- or the whole encoder
-    if (capture(e->st, "encoder", seg0_out, [&]() -> int {
-            HIPCHK(hipMemcpyAsync(P.g_desc, P.gh, L.total, hipMemcpyHostToDevice, e->st));
-            MelParams mp;
-            memset(&mp, 0, sizeof(mp));
-            mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
-            mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
-            launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
-            return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, depth == 2 ? 0 : -1) ? -1 : 0;
-        })) return -1;
-    *seg1_out = nullptr;
-    if (depth == 2 && capture(e->st, "encoder (second half)", seg1_out, [&]() -> int {
-            return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, 1) ? -1 : 0;
-        })) return -1;
-    // decode graph on the second stream
+    for (int k = 0; k < nseg; k++) {
+        // captured on the engine's stream (the enqueue functions launch there), replayed on lane k
+        if (capture(e->st, "encoder piece", &seg_out[k], [&]() -> int {
+                if (k == 0) {       // descriptors, front end
+                    HIPCHK(hipMemcpyAsync(P.g_desc, P.gh, L.total, hipMemcpyHostToDevice, e->st));
+                    MelParams mp;
+                    memset(&mp, 0, sizeof(mp));
+                    mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+                    mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+                    launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
+                }
+                return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, k, nseg) ? -1 : 0;
+            })) return -1;
+    }
+    // decode graph on the decode stream
     if (capture(e->st2, "decode", dec_out, [&]() -> int {
             HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, e->st2));
             DecParams dp;
@@ -1559,34 +1571,34 @@ static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, 
     return 0;
 }
 
-// second encoder piece of the step in slot p (depth 2): queued on st3 behind the first piece's event.  This wait is short
-// in steady state (the first piece was launched a whole call earlier) -- unlike the decode graph it is not parked for long.
-static int pipe_launch_seg1(nasr_engine *e, int p) {
+// next encoder piece of the step in slot p: queued on its lane behind the previous piece's event.  That wait is short in
+// steady state (the previous piece was launched a whole call earlier) -- unlike the decode graph it is not parked for long.
+static int pipe_advance(nasr_engine *e, int p) {
     nasr_engine::Pipe &P = e->pipe[p];
-    if (P.stage != 1) return 0;
-    if (P.depth == 2) {
-        static const bool host_wait = getenv("NASR_SKEW_HOSTWAIT") != nullptr;
-        if (host_wait) HIPCHK(hipEventSynchronize(P.seg0_done));
-        else HIPCHK(hipStreamWaitEvent(e->st3, P.seg0_done, 0));
-        HIPCHK(hipGraphLaunch(P.seg1_graphs[P.key], e->st3));
-        HIPCHK(hipEventRecord(P.enc_done, e->st3));
-    }
-    P.stage = 2;
+    if (P.stage == 0 || P.stage >= P.nseg) return 0;
+    const int k = P.stage;
+    static const bool host_wait = getenv("NASR_SKEW_HOSTWAIT") != nullptr;
+    if (host_wait) HIPCHK(hipEventSynchronize(P.seg_done[k - 1]));
+    else HIPCHK(hipStreamWaitEvent(e->lane[k], P.seg_done[k - 1], 0));
+    { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.seg_graphs[k][P.key], e->lane[k])); }
+    HIPCHK(hipEventRecord(P.seg_done[k], e->lane[k]));
+    P.stage = k + 1;
     return 0;
 }
 
-// Completes the step in slot p: (launches its second encoder piece if that has not happened,) waits for its encoder,
-// launches its decode graph on the decode stream (by now the next steps' encoder pieces are queued on their streams),
-// waits for that, finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
+// Completes the step in slot p: launches the encoder pieces it still lacks, waits for its encoder, launches its decode
+// graph on the decode stream (by now the younger steps' encoder pieces are queued on their lanes), waits for that,
+// finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
 static int pipe_finish(nasr_engine *e, int p) {
     nasr_engine::Pipe &P = e->pipe[p];
     if (P.stage == 0) return 0;
-    if (pipe_launch_seg1(e, p)) return -1;
+    while (P.stage < P.nseg)
+        if (pipe_advance(e, p)) return -1;
     const int B = (int)P.streams.size(), TS = P.T * P.G;
-    HIPCHK(hipEventSynchronize(P.enc_done));
+    { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[P.nseg - 1])); }
     for (int b = 0; b < B; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[B + b] = P.streams[b]->tok_read; }
-    HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], e->st2));
-    HIPCHK(hipStreamSynchronize(e->st2));
+    { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], e->st2)); }
+    { HostTimer ht(e->host_wait_s); HIPCHK(hipStreamSynchronize(e->st2)); }
     int *gh_active = P.gh_collect + (size_t)B * (1 + COLLECT_STRIDE);      // k_collect appends n_active to its records
     if (*gh_active != 0) {
         const GraphDescLayout L = graph_desc_layout(B, P.G);
@@ -1620,33 +1632,31 @@ static int pipe_drain(nasr_engine *e) {
         const int p = (int)(q % nasr_engine::NSLOT);
         if (e->pipe[p].stage != 0 && e->pipe[p].seq == q && pipe_finish(e, p)) return -1;
     }
-    // the synchronous paths that follow use workspace set 0 on the engine's stream: nothing of the other lanes may be running
-    if (e->st3) HIPCHK(hipStreamSynchronize(e->st3));
     return 0;
 }
 
 static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev, const int32_t *n_samples, int G,
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
-    if (ensure_pipe(e)) return -1;
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
-    const int depth = e->opt_pipeline >= 2 && e->hp.n_layers >= 2 ? 2 : 1;
+    const int nseg = std::max(1, std::min({e->opt_pipeline, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
     const int64_t seq = e->pipe_seq;
     const int p = (int)(seq % nasr_engine::NSLOT);
+    if (ensure_pipe(e, p)) return -1;
     nasr_engine::Pipe &P = e->pipe[p];
     if (pipe_finish(e, p)) return -1;                      // the slot's previous occupant (NSLOT steps ago): done in steady state
-    const int64_t key = ((int64_t)B << 40) | ((int64_t)T << 24) | ((int64_t)G << 8) | (int64_t)depth;
-    auto ge = P.seg0_graphs.find(key);
-    if (ge == P.seg0_graphs.end()) {
+    const int64_t key = ((int64_t)B << 40) | ((int64_t)T << 24) | ((int64_t)G << 8) | (int64_t)nseg;
+    auto ge = P.seg_graphs[0].find(key);
+    if (ge == P.seg_graphs[0].end()) {
         if (pipe_drain(e)) return -1;
         HIPCHK(hipStreamSynchronize(e->st));
-        hipGraphExec_t g0 = nullptr, g1 = nullptr, dec = nullptr;
+        hipGraphExec_t gs[nasr_engine::MAXSEG] = {nullptr, nullptr, nullptr, nullptr}, dec = nullptr;
         {
             CaptureExclusive alone;
-            if (build_pipe_graphs(e, p, B, T, R, G, depth, &g0, &g1, &dec)) return -1;
+            if (build_pipe_graphs(e, p, B, T, R, G, nseg, gs, &dec)) return -1;
         }
-        ge = P.seg0_graphs.emplace(key, g0).first;
-        if (g1) P.seg1_graphs[key] = g1;
+        for (int k = 0; k < nseg; k++) P.seg_graphs[k][key] = gs[k];
         P.dec_graphs[key] = dec;
+        ge = P.seg_graphs[0].find(key);
     }
     const GraphDescLayout L = graph_desc_layout(B, G);
     RowDesc *gh_rows = (RowDesc *)(P.gh + L.rows), *gh_vrows = (RowDesc *)(P.gh + L.vrows);
@@ -1667,8 +1677,8 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
             v.mel_start = (s->mel_start + g * shift) & (MEL_RING - 1);
         }
     }
-    HIPCHK(hipGraphLaunch(ge->second, e->st));
-    HIPCHK(hipEventRecord(depth == 2 ? P.seg0_done : P.enc_done, e->st));
+    { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(ge->second, e->st)); }
+    HIPCHK(hipEventRecord(P.seg_done[0], e->st));
     for (int b = 0; b < B; b++) {                          // every count is a pure function of the samples pushed
         nasr_stream *s = streams[b];
         const PcmDesc &d = gh_pcm[b];
@@ -1680,21 +1690,20 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
         s->cc_par = par ^ 1;
         s->last_T = T * G; s->last_row = b; s->last_ws = p;
     }
-    P.stage = depth == 2 ? 1 : 2;
+    P.stage = 1;
     P.seq = seq;
-    P.depth = depth;
+    P.nseg = nseg;
     P.streams.assign(streams, streams + B);
     P.T = T; P.G = G; P.key = key;
     e->pipe_seq = seq + 1;
-    // the step before this one: its second encoder piece goes onto its lane now (its first piece has had a whole call)
-    if (seq >= 1) {
-        nasr_engine::Pipe &Q = e->pipe[(int)((seq - 1) % nasr_engine::NSLOT)];
-        if (Q.seq == seq - 1 && pipe_launch_seg1(e, (int)((seq - 1) % nasr_engine::NSLOT))) return -1;
-    }
-    // the step `depth` calls back: its encoder is finishing or done, everything younger is queued behind it; decode it now
-    if (seq >= depth) {
-        const int q = (int)((seq - depth) % nasr_engine::NSLOT);
-        if (e->pipe[q].seq == seq - depth && pipe_finish(e, q)) return -1;
+    // the steps before this one move on by one piece each, the one that has had all its pieces is decoded (a step whose
+    // number of pieces differs -- the option was changed in between -- simply completes when its turn comes)
+    for (int k = 1; k <= nasr_engine::MAXSEG && k <= seq; k++) {
+        const int q = (int)((seq - k) % nasr_engine::NSLOT);
+        nasr_engine::Pipe &Q = e->pipe[q];
+        if (Q.stage == 0 || Q.seq != seq - k) continue;
+        if (Q.stage < Q.nseg) { if (pipe_advance(e, q)) return -1; }
+        else if (pipe_finish(e, q)) return -1;
     }
     e->graph_replays++;
     e->pipe_steps++;

@@ -198,7 +198,7 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
     pcms = [synth.make_pcm(60 + b, secs) for b in range(2 * B)]
     n_steps = pcms[0].size // piece
     res = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 4):
         eng.set_option("pipeline", mode)
         grp = [[eng.stream(R) for _ in range(B)] for _ in range(2)]      # two groups of streams take turns
         toks = [[] for _ in range(2 * B)]
@@ -230,7 +230,7 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
             for s in grp[g]:
                 s.destroy()
     assert sum(len(t) for t in res[0][0]) > 0 and res[0][3][0][0] > 5
-    for mode in (1, 2):       # 1: decode beside the next encoder; 2: + the encoder halves of consecutive steps side by side
+    for mode in (1, 2, 4):    # 1: decode beside the next encoder; E: the encoder in E pieces, pieces of consecutive steps side by side
         assert res[mode][0] == res[0][0], mode
         # encoder-out tap: valid until the next chunk step of the engine touches its workspace -- the group stepped last
         assert np.array_equal(res[mode][1][B:], res[0][1][B:]) and np.array_equal(res[mode][2], res[0][2]), mode
@@ -602,7 +602,7 @@ B, R = 4, 1
 piece = synth.shift_samples(R)
 pcms = [synth.make_pcm(80 + b, 6.0) for b in range(B)]
 res = {{}}
-for mode in (0, 1, 2):
+for mode in (0, 1, 3):
     eng = capi.Engine(W, n_layers=2, dtype=capi.DTYPE_F32, max_streams=B)
     eng.set_option("pipeline", mode)
     sts = [eng.stream(R) for _ in range(B)]
