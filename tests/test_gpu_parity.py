@@ -618,7 +618,7 @@ for mode in (0, 1, 3):
     for s in sts:
         s.destroy()
     eng.close()
-assert res[0] == res[1] == res[2], "pipelined tokens differ"
+assert res[0] == res[1] == res[3], "pipelined tokens differ"
 om = ob.OracleModel(W, 2)
 for b in range(B):
     ost = ob.OracleStream(om, R)
