@@ -140,14 +140,16 @@ def pmc_traffic(kernel_symbol_part, tag):
         ks = json.loads(f.read_text())["kernels"]
     except (ValueError, KeyError):
         return None
+    tot, n = 0.0, 0                       # a HIP-event category can cover several kernel symbols (k_gemm_roles / k_gemm_tiled2): launch-weighted mean
     for name, rec in ks.items():
-        if kernel_symbol_part in name:
-            return rec.get("hbm_bytes_per_launch_corrected")
-    return None
+        if any(part in name for part in kernel_symbol_part) and "hbm_bytes_per_launch_corrected" in rec:
+            tot += rec["hbm_bytes_per_launch_corrected"] * rec.get("launches_FETCH_SIZE", 1)
+            n += rec.get("launches_FETCH_SIZE", 1)
+    return round(tot / n) if n else None
 
 
-_SYMBOL = {"k_fused_ln_gemm": "k_fused_skinny<0>", "k_fused_plain_gemm": "k_fused_skinny<1>", "k_fused_attn_gemm": "k_fused_skinny<2>",
-           "k_fused_dwconv_gemm": "k_fused_skinny<3>", "k_gemm_tiled": "k_gemm_", "k_gemm_skinny": "k_gemm_skinny", "k_gemm_mid": "k_gemm_mid"}
+_SYMBOL = {"k_fused_ln_gemm": ("k_fused_skinny<0>",), "k_fused_plain_gemm": ("k_fused_skinny<1>",), "k_fused_attn_gemm": ("k_fused_skinny<2>",),
+           "k_fused_dwconv_gemm": ("k_fused_skinny<3>",), "k_gemm_tiled": ("k_gemm_roles", "k_gemm_tiled2"), "k_gemm_skinny": ("k_gemm_skinny",)}
 
 
 class Run:
@@ -254,7 +256,7 @@ def profile_pass(run, n_steps, label, pmc_tag, restore_pipeline, bound=None):
     # batch 1 / R = 0 streams every weight once with M = 1 (HBM-bound); 64 streams x R = 13 has M = 896 rows
     # per GEMM (MFMA-bound).  In between the larger of the two lower bounds decides.
     mfma_bound = bound == "mfma" if bound else flops / (MFMA_PEAK_TFLOPS * 1e12) > nbytes / (HBM_PEAK_GBS * 1e9)
-    traffic = pmc_traffic(_SYMBOL.get(dom["name"], dom["name"]), pmc_tag)
+    traffic = pmc_traffic(_SYMBOL.get(dom["name"], (dom["name"],)), pmc_tag)
     common = dict(kernel=dom["name"], avg_launch_us=round(avg_s * 1e6, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
                   launches_per_step=per_step, share_of_step=round(share, 4), alg_bytes_per_launch=round(nbytes),
                   alg_flops_per_launch=round(flops), traffic=traffic, workload=label,

@@ -121,7 +121,7 @@ __device__ __forceinline__ int panel_off(int row, int chunk) {  // byte offset i
 //    LDS write and does not drain vmcnt(0) in front of every ds_read; completion is counted by hand
 //    (8 DMA instructions per wave per chunk).
 // ------------------------------------------------------------------------------------
-constexpr int G2_P = 3, G2_NS = 4, G2_SLOT = 32768;
+constexpr int G2_SLOT = 32768;
 
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -159,7 +159,12 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams &p, int split, 
     }
 }
 
+// NS = slots of the LDS ring (NS - 1 chunks in flight).  NS = 4: 128 KiB, one workgroup per CU.  NS = 2: 64 KiB (+ the 66 KiB
+// the staged epilogue needs), TWO workgroups per CU -- of this launch or of a launch of another HIP stream (pipelined steps run
+// two or three launch chains side by side): one workgroup's fill, waits and epilogue run under the other's MFMAs.
+template <int NS>
 __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int P = NS - 1;
     // 8 waves = 2 per SIMD: wave w owns n-tile pair (w & 3) x m-tiles [(w >> 2) * 4, +4).  One wave's
     // LDS-DMA issue (expensive: ~100+ cycles per 1 KiB instruction) overlaps its SIMD partner's MFMAs.
     extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -210,15 +215,15 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
         for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int i = 0; i < G2_P; i++)
+    for (int i = 0; i < P; i++)
         if (i < nchunks) issue(c0 + i, i);
     for (int i = 0; i < nchunks; i++) {
-        const int rem = nchunks - 1 - i < G2_P - 1 ? nchunks - 1 - i : G2_P - 1;   // chunks allowed to stay in flight
+        const int rem = nchunks - 1 - i < P - 1 ? nchunks - 1 - i : P - 1;         // chunks allowed to stay in flight
         if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // 4 DMA instructions per wave per chunk
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i-1 is fully consumed
-        const char *sp = ring + (i & (G2_NS - 1)) * G2_SLOT;
+        const char *sp = ring + (i % NS) * G2_SLOT;
         const char *wl = sp + 16384 + ng4 * 4096 + lane * 16;
         uint4 w[2][2];
         w[0][0] = *(const uint4 *)(wl);
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
                 acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
             }
         }
-        if (i + G2_P < nchunks) issue(c0 + i + G2_P, (i + G2_P) & (G2_NS - 1));
+        if (i + P < nchunks) issue(c0 + i + P, (i + P) % NS);
     }
     __syncthreads();                           // every wave is done with the ring
     float *stage = (float *)ring;
@@ -259,7 +264,9 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
 // 13.0 instead of 15.2 us on the W1 shape, 12.5 instead of 13.6 on W2 (M = 896); slightly slower below 8 chunks per
 // workgroup, where k_gemm_tiled2 stays.  1024 threads leave 128 VGPRs per wave: fragments of half a chunk per register set.
 // ------------------------------------------------------------------------------------
+template <int NS>
 __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int P = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int nblk = gridDim.x;
     int id = blockIdx.x;
@@ -296,17 +303,17 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
             glds16(wpd + (size_t)(2 * kc + 1) * 64, wb + 1024);
         };
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < P; i++)
             if (i < nchunks) issue(c0 + i, i);
         for (int i = 0; i <= nchunks; i++) {                 // barriers 0 .. nchunks (the consumers' last one closes the pipeline)
             if (i < nchunks) {
-                const int rem = nchunks - 1 - i < 2 ? nchunks - 1 - i : 2;
+                const int rem = nchunks - 1 - i < P - 1 ? nchunks - 1 - i : P - 1;
                 if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
-            if (i + 3 < nchunks) issue(c0 + i + 3, (i + 3) & 3);
+            if (i + P < nchunks) issue(c0 + i + P, (i + P) % NS);
         }
         __syncthreads();                       // (consumers: done with the ring) ...
         __syncthreads();                       // ... (consumers: accumulators parked in it): the loaders help to store them
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
     // multiply (i, half 0) from A | all reads of chunk i complete before barrier i + 1
     for (int i = 0; i <= nchunks; i++) {
         __builtin_amdgcn_s_barrier();
-        const unsigned so = (unsigned)(i & 3) * G2_SLOT;
+        const unsigned so = (unsigned)(i % NS) * G2_SLOT;
         if (i < nchunks) {
             const unsigned wa = w_addr + so, ba = b_addr[0] + so;
             LDS_RD(wA[0], wa, 0); LDS_RD(wA[1], wa, 2048);
@@ -371,9 +378,22 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
     staged_epilogue<1024>(p, split, m0, ng * 128, stage);
 }
 
+static int gemm_ring_slots() {      // 4 (default): one workgroup per CU, three chunks in flight; 2: two workgroups per CU, one chunk in flight
+    static const int v = getenv("NASR_GEMM_SLOTS") ? atoi(getenv("NASR_GEMM_SLOTS")) : 4;
+    return v == 2 || v == 3 ? v : 4;
+}
+static size_t gemm_lds_bytes(int ns) {     // the ring, or the f32 tile the epilogue parks in it, whichever is larger
+    const size_t ring = (size_t)ns * G2_SLOT, stage = (size_t)TM * STG_LD * 4;
+    return ring > stage ? ring : stage;
+}
+
 void init_gemm_kernel_attributes() {
-    hipFuncSetAttribute((const void *)k_gemm_tiled2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
-    hipFuncSetAttribute((const void *)k_gemm_roles, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_tiled2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_roles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_tiled2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
+    hipFuncSetAttribute((const void *)k_gemm_roles<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
+    hipFuncSetAttribute((const void *)k_gemm_tiled2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
+    hipFuncSetAttribute((const void *)k_gemm_roles<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
 }
 
 int gemm_skinny_max_m() {
@@ -393,10 +413,18 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
         dim3 grid(n_groups * m_chunks * p.splits);
         static const int roles_min_chunks = getenv("NASR_ROLES_MIN_CHUNKS") ? atoi(getenv("NASR_ROLES_MIN_CHUNKS")) : 8;
-        if ((p.K >> 6) / p.splits >= roles_min_chunks)
-            hipLaunchKernelGGL(k_gemm_roles, grid, dim3(1024), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
-        else
-            hipLaunchKernelGGL(k_gemm_tiled2, grid, dim3(512), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+        const bool roles = (p.K >> 6) / p.splits >= roles_min_chunks;
+        const int ns = gemm_ring_slots();
+        const size_t lds = gemm_lds_bytes(ns);
+#define NASR_LAUNCH_TILED(NS_)                                                                                             \
+        do {                                                                                                               \
+            if (roles) hipLaunchKernelGGL(k_gemm_roles<NS_>, grid, dim3(1024), lds, st, p, n_groups, m_chunks);             \
+            else hipLaunchKernelGGL(k_gemm_tiled2<NS_>, grid, dim3(512), lds, st, p, n_groups, m_chunks);                   \
+        } while (0)
+        if (ns == 2) NASR_LAUNCH_TILED(2);
+        else if (ns == 3) NASR_LAUNCH_TILED(3);
+        else NASR_LAUNCH_TILED(4);
+#undef NASR_LAUNCH_TILED
     }
 }
 
