@@ -9,7 +9,7 @@
 # steps in all: rocprofv3 (ROCm 7.2) crashes in its queue interceptor after ~15 000 graph-launched kernels in one process.
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-ARGS="--no-cpu-baseline --no-profile-pass --no-buffered --no-extra-configs --no-host-pcm --regions 1 --sync-steps --steps 40 --warmup 5 $*"
+ARGS="--no-cpu-baseline --no-profile-pass --no-buffered --no-extra-configs --no-host-pcm --regions 1 --sync-steps --steps ${PROF_STEPS:-40} --warmup 3 $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/prof_$TAG.log 2>&1
 echo "stats pass rc=$? segv=$(grep -c SIGSEGV $OUT/prof_$TAG.log) $(grep -o '"ms_per_step": [0-9.]*' $OUT/prof_$TAG.log | head -1)"
