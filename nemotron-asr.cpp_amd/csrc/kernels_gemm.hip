@@ -253,6 +253,99 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
 }
 
 // ------------------------------------------------------------------------------------
+// 128 (M) x 64 (N) tile of the same structure, for the split-K GEMMs with N = 1024 (W2, Wo, pw2) at M = 896: the 128 x 128
+// tile gives 56 output tiles, so K had to be split four ways to fill the chip and every GEMM wrote 4 x 3.67 MB of f32
+// partials that k_post read back (round 1: 59 MB per layer).  Half-width tiles fill the chip with TWO splits: half the
+// partial bytes on both sides of the seam.  8 waves = 2 n-tile pairs x 4 quarters of the rows (32 x 32 per wave); slot =
+// 16 KiB activation panel + 8 KiB weight tiles per 64-deep chunk, 3 DMA instructions per wave and chunk.
+// ------------------------------------------------------------------------------------
+constexpr int T64_SLOT = 24576, T64_STG_LD = 68;
+template <int NS>
+__global__ __launch_bounds__(512) void k_gemm_t64(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int P = NS - 1;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ng2 = wave & 1, mq = wave >> 1, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = c1 - c0, m0 = mc * TM, ntile0 = ng * 4;
+    // this wave DMAs weight tile (ntile0 + (wave >> 1), k-tile wave & 1) and panel rows [wave * 16, +16)
+    const uint4 *wpd = (const uint4 *)p.W + ((size_t)(ntile0 + (wave >> 1)) * KT + (wave & 1)) * 64 + lane;
+    const int prow = lane >> 3, pc = lane & 7;
+    const char *asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = wave * 16 + i * 8 + prow;
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kc, int slot) {
+        const unsigned sb = ring_base + slot * T64_SLOT;
+#pragma unroll
+        for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+        glds16(wpd + (size_t)(2 * kc) * 64, sb + 16384 + wave * 1024);          // [n-tile 0..3][k-tile 0..1][1 KiB]
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        if (i < nchunks) issue(c0 + i, i);
+    for (int i = 0; i < nchunks; i++) {
+        const int rem = nchunks - 1 - i < P - 1 ? nchunks - 1 - i : P - 1;         // chunks allowed to stay in flight
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");             // 3 DMA instructions per wave per chunk
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char *sp = ring + (i % NS) * T64_SLOT;
+        const char *wl = sp + 16384 + ng2 * 4096 + lane * 16;
+        uint4 w[2][2];
+        w[0][0] = *(const uint4 *)(wl);
+        w[0][1] = *(const uint4 *)(wl + 1024);
+        w[1][0] = *(const uint4 *)(wl + 2048);
+        w[1][1] = *(const uint4 *)(wl + 3072);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                const uint4 bv = *(const uint4 *)(sp + panel_off((mq * 2 + mt) * 16 + r, k2 * 4 + q));
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+            }
+        }
+        if (i + P < nchunks) issue(c0 + i + P, (i + P) % NS);
+    }
+    __syncthreads();                           // every wave is done with the ring
+    float *stage = (float *)ring;              // f32 tile [128][68]
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+            *(float4 *)(stage + ((mq * 2 + mt) * 16 + r) * T64_STG_LD + (ng2 * 2 + j) * 16 + q * 4) =
+                make_float4(acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < TM * 16; e += 512) {                // a wave stores four whole 256-byte rows of the tile per instruction
+        const int row = e >> 4, c4 = (e & 15) * 4, m = m0 + row, n0 = ng * 64 + c4;
+        const float4 v = *(const float4 *)(stage + row * T64_STG_LD + c4);
+        if (m >= p.M) continue;
+        if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + ((size_t)split * p.M + m) * p.ldo + n0, v);
+        else epi_quad<true>(p, split, m, n0, v.x, v.y, v.z, v.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // the same tile and ring with ROLE-SPECIALISED waves (tests/micro/gemm_probe.hip, mode 7): in k_gemm_tiled2 every wave
 // issues its share of the LDS-DMA (4 instructions of ~100 cycles per chunk), reads its fragments and multiplies -- one
 // after the other, and all eight waves in the same phase behind the per-chunk barrier: 0.5 us per chunk where the DMA
@@ -392,9 +485,17 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_roles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
     hipFuncSetAttribute((const void *)k_gemm_roles<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
+    hipFuncSetAttribute((const void *)k_gemm_t64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_tiled2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
     hipFuncSetAttribute((const void *)k_gemm_roles<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
 }
+
+// the split-K GEMMs with N = 1024 use 128 x 64 tiles when that halves the split factor (see k_gemm_t64)
+bool gemm_use_t64(int M, int N, int epi) {
+    static const int on = getenv("NASR_GEMM_T64") ? atoi(getenv("NASR_GEMM_T64")) : 1;
+    return on && epi == EPI_PART_F32 && N == 1024 && M > gemm_skinny_max_m() && (N / 128) * ((M + 127) / 128) < 128;
+}
+int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 128; }
 
 int gemm_skinny_max_m() {
     static const int v = getenv("NASR_SKINNY_MAXM") ? atoi(getenv("NASR_SKINNY_MAXM")) : 128;   // measured: 128 rows 3.94 vs 4.36 ms per step, 256 rows 4.40 vs 3.88
@@ -411,6 +512,11 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_skinny<4>, grid, dim3(256), 0, st, p);
     } else {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+        if (gemm_use_t64(p.M, p.N, p.epi)) {       // half-width tiles: the caller chose splits for N / 64 column groups (gemm_tile_n)
+            n_groups = p.N / 64;
+            hipLaunchKernelGGL(k_gemm_t64<4>, dim3(n_groups * m_chunks * p.splits), dim3(512), 4 * T64_SLOT, st, p, n_groups, m_chunks);
+            return;
+        }
         dim3 grid(n_groups * m_chunks * p.splits);
         static const int roles_min_chunks = getenv("NASR_ROLES_MIN_CHUNKS") ? atoi(getenv("NASR_ROLES_MIN_CHUNKS")) : 8;
         const bool roles = (p.K >> 6) / p.splits >= roles_min_chunks;
