@@ -425,7 +425,7 @@ def main():
     buffered = None
     if rank == 0 and world == 1 and (B, args.chunks_per_step) == (1, 1) and not args.no_buffered:
         eng, L = run.eng, run.L
-        G, n_push = 256, 5
+        G, n_push = 256, 8
         nb = synth.shift_samples(R) * G
         pb = synth.make_pcm(1000, (n_push + 1) * nb / synth.SAMPLE_RATE + 0.01)[:(n_push + 1) * nb]
         db = eng.upload(pb)
@@ -438,16 +438,18 @@ def main():
         cb = (C.c_int32 * 1)(tb.size)
         nbb = (C.c_int32 * 1)(nb)
         ntb = (C.c_int32 * 1)()
-        tt = []
-        for k in range(n_push + 1):
+        eng.set_option("pipeline", 0)            # pushes of 20 s of audio: one synchronous launch sequence each
+        def push(k):
             ptr = (C.c_void_p * 1)(db + 2 * k * nb)
-            eng.synchronize()
-            tq = time.perf_counter()
             if L.nasr_engine_step(eng.h, hb, 1, ptr, nbb, tpb, cb, ntb, capi.FLAG_PCM_DEVICE) < 0:
                 raise RuntimeError(L.nasr_last_error().decode())
-            eng.synchronize()
-            tt.append(time.perf_counter() - tq)
-        tsum = sum(tt[1:])                      # the first push builds the graph
+        push(0)                                  # the first push builds the graph
+        eng.synchronize()
+        tq = time.perf_counter()
+        for k in range(1, n_push + 1):
+            push(k)
+        eng.synchronize()
+        tsum = time.perf_counter() - tq
         buffered = dict(chunks_per_push=G, pushes=n_push, ms_per_push=round(1e3 * tsum / n_push, 3),
                         value=round(n_push * nb / synth.SAMPLE_RATE / tsum, 1), unit="audio-s/s",
                         note="same engine, same stream semantics (80 ms lookahead, chunk-by-chunk caches), the 256 chunks of "

@@ -251,6 +251,32 @@ std::string nemo_stream_process_incremental(nemo_stream_context *sctx, const int
     return out;
 }
 
+bool nemo_stream_collect_batch(nemo_stream_context *const *sctx, int B, std::string *out) {
+    if (!sctx || B <= 0) return false;
+    std::vector<nasr_stream *> st((size_t)B);
+    std::vector<std::vector<int32_t>> buf((size_t)B, std::vector<int32_t>(256));
+    std::vector<int32_t *> ptr((size_t)B);
+    std::vector<int32_t> cap((size_t)B, 256), cnt((size_t)B);
+    for (int b = 0; b < B; b++) {
+        if (!sctx[b]) return false;
+        st[b] = sctx[b]->stream;
+        ptr[b] = buf[b].data();
+    }
+    for (bool more = true; more;) {
+        if (nasr_engine_collect(sctx[0]->nctx->engine, st.data(), B, ptr.data(), cap.data(), cnt.data()) < 0) {
+            fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+            return false;
+        }
+        more = false;
+        for (int b = 0; b < B; b++) {
+            const std::string text = absorb(sctx[b], buf[b].data(), cnt[b]);
+            if (out) out[b] += text;
+            more = more || cnt[b] >= cap[b];
+        }
+    }
+    return true;
+}
+
 std::string nemo_stream_finalize(nemo_stream_context *sctx) {
     if (!sctx) return "";
     int32_t tok[256], cap = 256, cnt = 0;

@@ -79,6 +79,9 @@ void nemo_stream_free(nemo_stream_context *sctx);
 // text delta of stream b.  This is what a multi-stream server's worker calls instead of looping.
 bool nemo_stream_process_batch(nemo_stream_context *const *sctx, int B, const int16_t *const *audio,
                                const int *n_samples, std::string *out);
+// MI355X extension: with pipelined steps, complete the steps in flight of B streams (one engine) and return their text --
+// what a batch former calls when its queue runs empty (nasr_engine_collect)
+bool nemo_stream_collect_batch(nemo_stream_context *const *sctx, int B, std::string *out);
 
 // token ids -> text: U+2581 starts a word (reference src/nemo-ggml.cpp:1556-1583); ids outside the vocab are skipped
 std::string tokens_to_text(const std::vector<int> &tokens, const std::vector<std::string> &vocab);

@@ -25,6 +25,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -84,6 +85,7 @@ std::vector<std::unique_ptr<Lane>> g_lanes;
 std::atomic<bool> g_stop{false};
 std::atomic<uint32_t> g_next_id{1};
 int g_default_rc = 0;
+int g_pipeline = 0;
 
 void enqueue(Event &&ev) {
     Lane &ln = *g_lanes[ev.id % g_lanes.size()];
@@ -129,6 +131,25 @@ void worker_loop(Lane *lane) {
     nemo_context *model = lane->model;
     std::map<uint32_t, Session> sessions;
     uint64_t n_batches = 0, n_batched_streams = 0;
+    std::set<uint32_t> in_flight;               // --pipeline: sessions whose last steps may still be on the GPU
+    auto drain = [&]() {                         // complete the steps in flight and send their text (FIFO empty, END, LANG)
+        if (in_flight.empty()) return;
+        std::vector<uint32_t> ids;
+        std::vector<nemo_stream_context *> sc;
+        for (uint32_t id : in_flight) {
+            auto it = sessions.find(id);
+            if (it != sessions.end()) { ids.push_back(id); sc.push_back(it->second.sctx); }
+        }
+        in_flight.clear();
+        if (sc.empty()) return;
+        std::vector<std::string> out(sc.size());
+        const bool ok = nemo_stream_collect_batch(sc.data(), (int)sc.size(), out.data());
+        for (size_t b = 0; b < sc.size(); b++) {
+            Session &s = sessions[ids[b]];
+            if (!ok) s.conn->send_str(OP_ERROR, ids[b], "engine collect failed");
+            else if (!out[b].empty()) s.conn->send_str(OP_TEXT, ids[b], out[b]);
+        }
+    };
     auto flush = [&]() {
         // group sessions with pending audio by right_context; one engine call per group
         std::map<int, std::vector<uint32_t>> groups;
@@ -149,6 +170,7 @@ void worker_loop(Lane *lane) {
             for (int b = 0; b < B; b++) {
                 Session &s = sessions[g.second[(size_t)b]];
                 s.pending.clear();
+                if (g_pipeline > 0) in_flight.insert(g.second[(size_t)b]);
                 if (!ok) s.conn->send_str(OP_ERROR, g.second[(size_t)b], "engine step failed");
                 else if (!out[(size_t)b].empty()) s.conn->send_str(OP_TEXT, g.second[(size_t)b], out[(size_t)b]);
             }
@@ -183,6 +205,7 @@ void worker_loop(Lane *lane) {
             case Ev::LANG:
                 if (it == sessions.end()) break;
                 flush();                         // audio queued before the switch uses the old language
+                drain();
                 if (nemo_stream_set_language(it->second.sctx, ev.text.c_str())) {
                     char buf[160];
                     const int n = snprintf(buf, sizeof(buf), "{\"id\":%u,\"lang\":\"%s\",\"index\":%d}", ev.id, ev.text.c_str(), it->second.sctx->prompt_index);
@@ -192,6 +215,7 @@ void worker_loop(Lane *lane) {
             case Ev::END:
                 if (it == sessions.end()) break;
                 flush();
+                in_flight.erase(ev.id);           // finalize completes the steps in flight itself
                 it->second.conn->send_str(OP_ENDED, ev.id, nemo_stream_finalize(it->second.sctx));
                 nemo_stream_free(it->second.sctx);
                 sessions.erase(it);
@@ -199,12 +223,18 @@ void worker_loop(Lane *lane) {
             case Ev::CLOSE:
                 if (it == sessions.end()) break;
                 it->second.pending.clear();
+                in_flight.erase(ev.id);
                 nemo_stream_free(it->second.sctx);
                 sessions.erase(it);
                 break;
             }
         }
         flush();
+        if (g_pipeline > 0) {                    // nothing else queued: do not sit on finished text
+            bool idle;
+            { std::lock_guard<std::mutex> lk(lane->mtx); idle = lane->queue.empty(); }
+            if (idle) drain();
+        }
     }
     for (auto &kv : sessions) nemo_stream_free(kv.second.sctx);
     fprintf(stderr, "worker: %llu engine calls, %.2f streams per call\n", (unsigned long long)n_batches,
@@ -281,7 +311,9 @@ void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_f
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N]\n"
+        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E]\n"
+                        "  --pipeline E: consecutive engine calls overlap on the GPU (E = 1..4, 2 is the optimum); a stream's text arrives\n"
+                        "                E calls later while the FIFO is busy and at once when it runs empty\n"
                         "  --devices: one engine + worker per listed GPU; stream s is served by entry s mod count\n", argv[0]);
         return 1;
     }
@@ -305,12 +337,14 @@ int main(int argc, char **argv) {
         }
         else if (a == "--max-streams" && i + 1 < argc) max_streams = atoi(argv[++i]);
         else if (a == "--f32") dtype = 0;
+        else if (a == "--pipeline" && i + 1 < argc) g_pipeline = atoi(argv[++i]);
         else { fprintf(stderr, "Unknown flag: %s\n", a.c_str()); return 1; }
     }
     for (int dev : devices) {
         std::unique_ptr<Lane> ln(new Lane());
         ln->model = nemo_init_with_device(argv[1], dev, dtype, max_streams);
         if (!ln->model) { fprintf(stderr, "Failed to load ASR model on device %d\n", dev); return 1; }
+        if (g_pipeline > 0 && !nemo_set_pipeline(ln->model, g_pipeline)) return 1;
         g_lanes.push_back(std::move(ln));
     }
     int fd;

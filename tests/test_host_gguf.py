@@ -167,10 +167,12 @@ def _recv(sock):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype_flag", ["--f32", None])
-def test_server_batches_streams(tmp_path, dtype_flag):
+@pytest.mark.parametrize("dtype_flag,pipeline", [("--f32", 0), (None, 0), ("--f32", 2)])
+def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
     """Wire protocol of the reference server (src/server-protocol.h:24-41) served by the batch-forming worker:
-    3 streams on 2 connections (two right_context groups), text == oracle tokens -> text, errors are framed."""
+    3 streams on 2 connections (two right_context groups), text == oracle tokens -> text, errors are framed.
+    pipeline = 2: the worker's engine calls overlap on the GPU (text arrives calls later or when the FIFO runs empty):
+    the concatenated text of every stream is still the oracle's."""
     import socket
     import time
     from oracle import binding as ob
@@ -183,8 +185,8 @@ def test_server_batches_streams(tmp_path, dtype_flag):
     assert srv.exists(), "run __graft_entry__.build()"
     path = str(tmp_path / "asr.sock")
     # two lanes (engine + FIFO + worker each) on the one GPU of the test box: stream s is served by lane s mod 2
-    proc = subprocess.Popen([str(srv), str(model), "--unix", path] + ([dtype_flag] if dtype_flag else []) + ["--max-streams", "8", "--devices", "0,0"],
-                            stderr=subprocess.PIPE, text=True)
+    proc = subprocess.Popen([str(srv), str(model), "--unix", path] + ([dtype_flag] if dtype_flag else []) + ["--max-streams", "8", "--devices", "0,0"]
+                            + (["--pipeline", str(pipeline)] if pipeline else []), stderr=subprocess.PIPE, text=True)
     try:
         for _ in range(600):
             if Path(path).exists() or proc.poll() is not None:
