@@ -130,7 +130,7 @@ class _StubEngine:
 
 def pmc_traffic(kernel_symbol_part, tag):
     """HBM bytes per launch of a kernel from the rocprofv3 --pmc passes committed under profiles/ for THIS build
-    (profiles/r2_pmc_traffic_<tag>.json, written by tests/prof_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE as
+    (profiles/r2_pmc_traffic_<tag>.json, written by tests/prof_r2.sh: FETCH_SIZE x 2 + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside this process; null when no
     summary for the configuration / kernel is committed."""
     f = ROOT / "profiles" / f"r2_pmc_traffic_{tag}.json"
@@ -140,7 +140,7 @@ def pmc_traffic(kernel_symbol_part, tag):
         ks = json.loads(f.read_text())["kernels"]
     except (ValueError, KeyError):
         return None
-    tot, n = 0.0, 0                       # a HIP-event category can cover several kernel symbols (k_gemm_roles / k_gemm_tiled2): launch-weighted mean
+    tot, n = 0.0, 0                       # a HIP-event category can cover several kernel symbols (k_gemm_roles / k_gemm_t64 / k_gemm_tiled2): launch-weighted mean
     for name, rec in ks.items():
         if any(part in name for part in kernel_symbol_part) and "hbm_bytes_per_launch_corrected" in rec:
             tot += rec["hbm_bytes_per_launch_corrected"] * rec.get("launches_FETCH_SIZE", 1)
@@ -149,7 +149,7 @@ def pmc_traffic(kernel_symbol_part, tag):
 
 
 _SYMBOL = {"k_fused_ln_gemm": ("k_fused_skinny<0>",), "k_fused_plain_gemm": ("k_fused_skinny<1>",), "k_fused_attn_gemm": ("k_fused_skinny<2>",),
-           "k_fused_dwconv_gemm": ("k_fused_skinny<3>",), "k_gemm_tiled": ("k_gemm_roles", "k_gemm_tiled2"), "k_gemm_skinny": ("k_gemm_skinny",)}
+           "k_fused_dwconv_gemm": ("k_fused_skinny<3>",), "k_gemm_tiled": ("k_gemm_roles", "k_gemm_tiled2", "k_gemm_t64"), "k_gemm_skinny": ("k_gemm_skinny",)}
 
 
 class Run:
