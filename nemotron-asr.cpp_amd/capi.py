@@ -5,12 +5,13 @@ CPU fallback: if the library is missing or no MI355X is visible the calls raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libnemotron_asr_amd.so"
+LIB_PATH = Path(os.environ.get("NASR_LIB_PATH") or HERE / "libnemotron_asr_amd.so")   # NASR_LIB_PATH: a diagnostic build of the same ABI
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q8_0 = 0, 1, 2, 8

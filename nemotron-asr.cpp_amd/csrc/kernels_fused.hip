@@ -110,8 +110,13 @@ __device__ __forceinline__ float dot32(const float *qs, const void *row) {   // 
 
 #define PIN_SGPR(x) asm volatile("" ::"s"(x))
 
-template <int PRO>
-__global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
+// MMAX = compile-time bound of M: 1 (one row: the chunk-by-chunk single stream), 2, or 16 (any M the small-M path takes).
+// The M <= 2 forms keep every prologue input in registers at once; giving them their own instantiation keeps the
+// row-staging form's 144 registers of partials out of their allocation: the one-row kernels fit 128 VGPRs = 4 waves per
+// SIMD, so the kernels of up to four launch chains (pipelined steps + decode) are resident on a CU together -- at 228
+// VGPRs two were the limit and a third chain queued behind them.
+template <int PRO, int MMAX>
+__global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k_fused_skinny(FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmParams &g = p.g;
     const int nt = blockIdx.x, split = blockIdx.y;
@@ -123,13 +128,15 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
     float *red = (float *)smem;                    // [4][64][4] floats = 4 KiB
     char *panel = smem + 4096;                     // [16][KP] bf16
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
-    const int M = g.M;
+    const int M = MMAX == 1 ? 1 : g.M;
+    constexpr bool SMALL = MMAX <= 2;              // M <= 2: block-per-row prologues
+    constexpr int MR = MMAX == 1 ? 1 : 2;
     STAMP(0);
 
     // The weight stream does not depend on the prologue: this wave's tiles (<= 8 KiB) are requested at the top of
     // the kernel so that their 2.2-2.4 us run under the prologue -- but AFTER the prologue's own first loads: the
     // memory pipeline serves a wave's requests in order, and the prologue inputs are the critical path.
-    constexpr int U = 8;
+    constexpr int U = (PRO == PRO_DWCONV && MMAX == 1) ? 2 : 8;   // k-tiles per wave (pw2 at split-K 4: 2; the launcher checks)
     const int nts = t1 - t0;
     const int w0 = t0 + nts * wave / 4, w1 = t0 + nts * (wave + 1) / 4;   // host guarantees w1 - w0 <= U
     const u32x4 *wp = (const u32x4 *)g.W + (size_t)nt * KT * 64 + lane;
@@ -157,18 +164,18 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         PIN_SGPR(g.epi); PIN_SGPR(g.out_f32); PIN_SGPR(g.ldo); PIN_SGPR(g.out_act); PIN_SGPR(g.ldo_act); PIN_SGPR(g.N);
         PIN_SGPR(g.q_out); PIN_SGPR(g.kv_pool); PIN_SGPR(g.kv_slot_stride); PIN_SGPR(g.rows); PIN_SGPR(g.T);
     };
-    if (!((PRO == PRO_LN && M <= 2) || PRO == PRO_ATTN || PRO == PRO_PLAIN || (PRO == PRO_DWCONV && M <= 2))) issue_weights();
+    if (!((PRO == PRO_LN && SMALL) || PRO == PRO_ATTN || PRO == PRO_PLAIN || (PRO == PRO_DWCONV && SMALL))) issue_weights();
     STAMP(1);
 
-    if (PRO == PRO_LN && M <= 2) {
+    if (PRO == PRO_LN && SMALL) {
         // block-per-row: every global load of the prologue is issued up front (one memory round trip)
         const int c4 = threadIdx.x * 4;
         const float4 lw = *(const float4 *)(p.ln_w + c4), lb = *(const float4 *)(p.ln_b + c4);
         float4 ow = make_float4(0.f, 0.f, 0.f, 0.f), ob = ow;
         if (p.lno_w) { ow = *(const float4 *)(p.lno_w + c4); ob = *(const float4 *)(p.lno_b + c4); }
-        float4 xv[2], t[2][8];
+        float4 xv[MR], t[MR][8];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
+        for (int m = 0; m < MR; m++) {
             if (m < M) {
                 xv[m] = *(const float4 *)(p.x_in + (size_t)m * D + c4);
 #pragma unroll
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         }
         issue_weights();
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
+        for (int m = 0; m < MR; m++) {
             if (m < M) {
                 float4 v = xv[m];
                 if (p.part_splits > 0) {
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         if ((int)threadIdx.x < M * DH) { qu[threadIdx.x] = qq + bu; qv[threadIdx.x] = qq + bv; }
         __syncthreads();
         score(kk, pp, m0, j0, ok0);
-        if (npair > 128) {                                           // M = 2: the remaining pairs
+        if (MMAX > 1 && npair > 128) {                               // M = 2: the remaining pairs
             int m1, j1;
             const bf16_t *prow1;
             const bool ok1 = pair_rows(128 + (threadIdx.x >> 1), m1, j1, prow1);
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
         const ConvParams &c = p.cv;
         const int T = c.T, ks1 = c.ks - 1;
         const int k0 = t0 * 32;
-        if (M <= 2) {
+        if (SMALL) {
             // block-per-row, 4 channels per thread; taps unrolled so all loads are in flight together
             const int c4 = threadIdx.x * 4;
             const float4 lw = *(const float4 *)(c.ln_w + c4), lb = *(const float4 *)(c.ln_b + c4);
@@ -555,8 +562,20 @@ __global__ __launch_bounds__(256) void k_fused_skinny(FusedParams p) {
 }
 
 void init_fused_kernel_attributes() {   // LN / dwconv row staging can exceed the 64 KiB default dynamic-LDS limit at M = 16
-    hipFuncSetAttribute((const void *)k_fused_skinny<PRO_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
-    hipFuncSetAttribute((const void *)k_fused_skinny<PRO_DWCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
+    hipFuncSetAttribute((const void *)k_fused_skinny<PRO_LN, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
+    hipFuncSetAttribute((const void *)k_fused_skinny<PRO_DWCONV, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
+}
+
+template <int MMAX>
+static void launch_fused_m(const FusedParams &p, hipStream_t st, size_t lds) {
+    const GemmParams &g = p.g;
+    dim3 grid(g.N / 16, g.splits);
+    switch (p.pro) {
+    case PRO_LN: hipLaunchKernelGGL((k_fused_skinny<PRO_LN, MMAX>), grid, dim3(256), lds, st, p); break;
+    case PRO_PLAIN: hipLaunchKernelGGL((k_fused_skinny<PRO_PLAIN, MMAX>), grid, dim3(256), 4096, st, p); break;
+    case PRO_ATTN: hipLaunchKernelGGL((k_fused_skinny<PRO_ATTN, MMAX>), dim3(g.N / 128, g.splits), dim3(256), lds, st, p); break;   // (column group, head)
+    case PRO_DWCONV: hipLaunchKernelGGL((k_fused_skinny<PRO_DWCONV, MMAX>), grid, dim3(256), lds, st, p); break;
+    }
 }
 
 void launch_fused_skinny(const FusedParams &p, hipStream_t st) {
@@ -565,13 +584,10 @@ void launch_fused_skinny(const FusedParams &p, hipStream_t st) {
     size_t lds = 4096 + (size_t)16 * KP * 2;
     if (p.pro == PRO_ATTN) lds += (size_t)(2 * 16 * DH + 16 * KVC) * 4;
     if ((p.pro == PRO_LN || p.pro == PRO_DWCONV) && g.M > 2) lds += (size_t)g.M * D * 4;   // f32 row staging
-    dim3 grid(g.N / 16, g.splits);
-    switch (p.pro) {
-    case PRO_LN: hipLaunchKernelGGL(k_fused_skinny<PRO_LN>, grid, dim3(256), lds, st, p); break;
-    case PRO_PLAIN: hipLaunchKernelGGL(k_fused_skinny<PRO_PLAIN>, grid, dim3(256), 4096, st, p); break;
-    case PRO_ATTN: hipLaunchKernelGGL(k_fused_skinny<PRO_ATTN>, dim3(g.N / 128, g.splits), dim3(256), lds, st, p); break;   // (column group, head)
-    case PRO_DWCONV: hipLaunchKernelGGL(k_fused_skinny<PRO_DWCONV>, grid, dim3(256), lds, st, p); break;
-    }
+    const bool fits_u2 = p.pro != PRO_DWCONV || (g.K / 32 / g.splits + 3) / 4 <= 2;   // the one-row dwconv form holds 2 k-tiles per wave
+    if (g.M == 1 && fits_u2) launch_fused_m<1>(p, st, lds);
+    else if (g.M == 2) launch_fused_m<2>(p, st, lds);
+    else launch_fused_m<16>(p, st, lds);
 }
 
 }  // namespace nasr

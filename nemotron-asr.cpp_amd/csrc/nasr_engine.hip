@@ -47,7 +47,12 @@ extern "C" const char *nasr_last_error(void) { return g_err; }
 // previous error during capture" when another thread copies or allocates).  Every entry point that talks to HIP
 // therefore holds this lock shared; building a step graph (rare: once per (B, T, G)) takes it exclusively.
 #ifdef NASR_STAMPS
+// diagnostic build (make stamps; never shipped): every fused layer kernel stamps the 100 MHz real-time counter at 8 points in
+// its first and last workgroup.  One region of 8 x 24 launches per pipeline slot: after a run the buffer holds the last replay
+// of every slot's graphs = the time line of the last NSLOT steps on their lanes (tests/micro/stamps_timeline.py reads the dump).
 static unsigned long long *g_stamp_buf = nullptr;
+static int g_stamp_pipe = 0;
+static const int STAMP_PER_SLOT = 8 * 24, STAMP_SLOTS = 5;
 #endif
 static std::shared_mutex g_api_mu;
 struct ApiGuard {
@@ -145,6 +150,8 @@ struct nasr_engine {
     int opt_pipeline = 0;            // 0: synchronous steps; E >= 1: the encoder in E pieces + the decode, each piece one step behind the previous
     hipStream_t st2 = nullptr;       // decode graphs
     hipStream_t lane[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};   // lane[k]: encoder piece k (lane[0] = st)
+    int n_lanes = 1;                 // lanes that run side by side (each on a hardware queue of its own): the number of pieces is capped by it
+    bool dec_on_last_lane = false;   // no hardware queue left for the decode graphs: they run on the last piece's lane, right behind that piece
     struct Pipe {
         bool ready = false;                               // buffers of this slot allocated
         char *g_desc = nullptr, *gh = nullptr;            // descriptor block of the encoder graphs (device / pinned)
@@ -152,6 +159,8 @@ struct nasr_engine {
         int *g_dmeta = nullptr, *gh_dmeta = nullptr;      // k_collect meta of the decode graph [2 B] (device / pinned)
         float *encproj = nullptr;                         // [w_rows][640]: encoder graph -> decode graph
         hipEvent_t seg_done[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t dec_done = nullptr;
+        bool dec_launched = false;
         std::map<int64_t, hipGraphExec_t> seg_graphs[MAXSEG], dec_graphs;     // key = (B, T, G, E)
         int stage = 0;                                    // encoder pieces launched so far (0 = slot free)
         int64_t seq = -1;                                 // sequence number of the step that occupies the slot
@@ -649,7 +658,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     init_gemm_kernel_attributes();
     init_fused_kernel_attributes();
 #ifdef NASR_STAMPS
-    if (!g_stamp_buf) { hipMalloc((void **)&g_stamp_buf, 256 * 32 * 8); hipMemset(g_stamp_buf, 0, 256 * 32 * 8); }
+    if (!g_stamp_buf) { hipMalloc((void **)&g_stamp_buf, (size_t)STAMP_SLOTS * STAMP_PER_SLOT * 32 * 8); hipMemset(g_stamp_buf, 0, (size_t)STAMP_SLOTS * STAMP_PER_SLOT * 32 * 8); }
 #endif
     if (load_weights(e, weights, n_weights)) { engine_destroy_impl(e); return -1; }
 
@@ -713,15 +722,21 @@ static void engine_destroy_impl(nasr_engine *e) {
     if (e && g_stamp_buf) {
         hipSetDevice(e->device);
         hipDeviceSynchronize();
-        std::vector<unsigned long long> h(256 * 32);
+        std::vector<unsigned long long> h((size_t)STAMP_SLOTS * STAMP_PER_SLOT * 32);
         hipMemcpy(h.data(), g_stamp_buf, h.size() * 8, hipMemcpyDeviceToHost);
-        const unsigned long long t0 = h[0];
-        for (int s = 0; s < 24 && t0; s++) {          // first three layers: ticks of 10 ns relative to slot 0 / block 0 / stamp 0
-            fprintf(stderr, "slot %2d blk0:", s);
-            for (int i = 0; i < 8; i++) fprintf(stderr, " %6lld", h[s * 32 + i] ? (long long)(h[s * 32 + i] - t0) : -1LL);
-            fprintf(stderr, "  | last:");
-            for (int i = 0; i < 8; i++) fprintf(stderr, " %6lld", h[s * 32 + 16 + i] ? (long long)(h[s * 32 + 16 + i] - t0) : -1LL);
-            fprintf(stderr, "\n");
+        const char *path = getenv("NASR_STAMPS_OUT");
+        FILE *f = path ? fopen(path, "w") : stderr;
+        if (f) {                                       // one line per launch: pipeline slot, launch index (8 x layer + k), 8 + 8 stamps (10 ns ticks)
+            for (int ps = 0; ps < STAMP_SLOTS; ps++)
+                for (int k = 0; k < STAMP_PER_SLOT; k++) {
+                    const unsigned long long *r = &h[((size_t)ps * STAMP_PER_SLOT + k) * 32];
+                    if (!r[0]) continue;
+                    fprintf(f, "%d %d", ps, k);
+                    for (int i = 0; i < 8; i++) fprintf(f, " %llu", r[i]);
+                    for (int i = 0; i < 8; i++) fprintf(f, " %llu", r[16 + i]);
+                    fprintf(f, "\n");
+                }
+            if (f != stderr) fclose(f);
         }
     }
 #endif
@@ -745,6 +760,7 @@ static void engine_destroy_impl(nasr_engine *e) {
         if (P.gh_dmeta) hipHostFree(P.gh_dmeta);
         if (p > 0 && P.gh) hipHostFree(P.gh);            // slot 0 shares the engine's own block
         for (auto ev : P.seg_done) if (ev) hipEventDestroy(ev);
+        if (P.dec_done) hipEventDestroy(P.dec_done);
     }
     if (e->st2) hipStreamDestroy(e->st2);
     for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamDestroy(e->lane[k]);
@@ -920,8 +936,8 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
     int cur = 0;
     int prev_splits = l0 > 0 ? 4 : 0;   // split-K partials pending from the previous layer's FFN2
 #ifdef NASR_STAMPS
-    unsigned long long *stamp_buf = g_stamp_buf;           // diagnostic build: 8 launches x 24 layers x 32 stamps
-    int stamp_slot = 0;
+    unsigned long long *stamp_buf = g_stamp_buf + (size_t)g_stamp_pipe * STAMP_PER_SLOT * 32;
+    int stamp_slot = 8 * l0;
 #endif
     auto launch = [&](FusedParams &f, const char *name, double bytes, double flops) {
         ProfScope ps(e, name, bytes, flops);
@@ -1049,10 +1065,22 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     const int act = e->bf16 ? 1 : 0;
     const int nLayers = e->hp.n_layers;
     // the first piece also carries the front end and the subsampling: with two pieces the boundary sits one layer early
-    // (11 + 13 layers; measured against 12 + 12 and 10 + 14: batch 1 0.642 / 0.653 / 0.669 ms, 64 streams x R = 13 2.948 / 2.961 / 3.019)
+    // (11 + 13 layers; measured against 12 + 12 and 10 + 14: batch 1 0.642 / 0.653 / 0.669 ms, 64 streams x R = 13 2.948 / 2.961 / 3.019);
+    // with three it is 7 + 9 + 8 (batch 1: 0.500 ms; 8 + 8 + 8 0.522, 7 + 8 + 9 0.511, 7 + 10 + 7 0.526, 6 + 10 + 8 0.527)
     static const int shift_env = getenv("NASR_SKEW_SHIFT") ? atoi(getenv("NASR_SKEW_SHIFT")) : -1;
     const int shift = shift_env >= 0 ? shift_env : (nseg == 2 && nLayers >= 8 ? 1 : 0);
-    auto bound = [&](int k) { return k <= 0 ? 0 : k >= nseg ? nLayers : std::max(1, nLayers * k / nseg - shift); };
+    static const char *bounds_env = getenv("NASR_SKEW_BOUNDS");       // experiment: explicit first layers of pieces 1.., e.g. "7,15"
+    auto bound = [&](int k) {
+        if (k <= 0) return 0;
+        if (k >= nseg) return nLayers;
+        if (bounds_env) {
+            const char *q = bounds_env;
+            for (int i = 1; i < k && q; i++) { q = strchr(q, ','); if (q) q++; }
+            if (q && atoi(q) > 0 && atoi(q) < nLayers) return atoi(q);
+        }
+        if (nseg == 3 && nLayers >= 6) return k == 1 ? nLayers * 7 / 24 : nLayers * 16 / 24;
+        return std::max(1, nLayers * k / nseg - shift);
+    };
     const int l0 = bound(seg), l1 = bound(seg + 1);
     const bool front = seg == 0, tail = seg == nseg - 1;
     GemmParams g;
@@ -1496,18 +1524,69 @@ static int pipe_blind_iterations(int frames) {
     return std::max(decode_blind_iterations(frames), std::min(worst, cap));
 }
 
+// ---- which HIP streams run side by side -------------------------------------------------------------------------------------
+// The runtime multiplexes the streams of a process onto a few hardware queues (4 by default, GPU_MAX_HW_QUEUES): two streams on
+// one queue are ONE launch chain.  Which queue a new stream gets depends on what the process created before, so the lanes are
+// chosen by measurement: candidate streams are created until three more are found that overlap with the engine's stream and
+// with each other (two 150 us spin kernels launched back to back take 150 us on different queues, 300 us on one).  Measured
+// (batch 1, MI355X): three encoder lanes + the decode on four queues 0.52 ms per step, the same option with two lanes landing
+// on one queue 0.73 ms -- slower than two lanes (0.63 ms).  More than 4 queues is no way out: hardware queues beyond the four
+// compute pipes are time-sliced (GPU_MAX_HW_QUEUES=8: 2 ms per step).
+__global__ void k_spin(unsigned long long ticks) {           // 100 MHz real-time counter
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+    const unsigned long long ticks = 15000;                   // 150 us
+    double best = 1e9;
+    for (int rep = 0; rep < 2; rep++) {
+        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best < 240.0;                                      // side by side: ~165 us; one queue: ~315 us
+}
+static int pick_lanes(nasr_engine *e) {
+    std::vector<hipStream_t> chosen{e->st}, rejected;
+    for (int tries = 0; tries < 12 && (int)chosen.size() < 4; tries++) {
+        hipStream_t c = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        bool ok = true;
+        for (hipStream_t s : chosen) ok = ok && streams_overlap(s, c);
+        (ok ? chosen : rejected).push_back(c);
+    }
+    for (hipStream_t c : rejected) hipStreamDestroy(c);
+    // 4 queues: lanes 0..2 + the decode stream; 3: lanes 0..2, decode behind the last piece; 2: two lanes, decode behind the
+    // second; 1 (GPU_MAX_HW_QUEUES=1): everything on the engine's stream
+    const int n = (int)chosen.size();
+    e->lane[0] = e->st;
+    e->n_lanes = std::max(1, std::min(n == 4 ? 3 : n, (int)nasr_engine::MAXSEG));
+    for (int k = 1; k < e->n_lanes; k++) e->lane[k] = chosen[(size_t)k];
+    if (n == 4) e->st2 = chosen[3];
+    else e->dec_on_last_lane = true;
+    if (getenv("NASR_DEC_LANE") && e->st2) {       // experiment knob: no decode stream; "4" = its queue becomes a fourth lane
+        if (atoi(getenv("NASR_DEC_LANE")) == 4) { e->lane[3] = e->st2; e->n_lanes = 4; }
+        else hipStreamDestroy(e->st2);
+        e->st2 = nullptr; e->dec_on_last_lane = true;
+    }
+    if (getenv("NASR_STATS")) fprintf(stderr, "nasr: pipelined steps: %d lane(s) side by side, decode %s\n", e->n_lanes, e->dec_on_last_lane ? "behind the last piece" : "on its own queue");
+    return 0;
+}
+
 // streams, events and the buffers of slot p (allocated when first used: E + 1 slots for E encoder pieces)
 static int ensure_pipe(nasr_engine *e, int p) {
-    if (!e->st2) {
-        HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
-        e->lane[0] = e->st;
-        for (int k = 1; k < nasr_engine::MAXSEG; k++) HIPCHK(hipStreamCreateWithFlags(&e->lane[k], hipStreamNonBlocking));
+    if (!e->pipe_ready) {
+        if (pick_lanes(e)) return -1;
         e->pipe_ready = true;
     }
     nasr_engine::Pipe &P = e->pipe[p];
     if (P.ready) return 0;
     const size_t S = (size_t)e->max_streams, M = (size_t)e->w_rows;
     for (auto &ev : P.seg_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&P.dec_done, hipEventDisableTiming));
     if (p == 0) {
         P.g_desc = e->g_desc; P.gh = e->gh; P.gh_collect = e->gh_collect; P.collect_dev = e->collect_dev; P.encproj = e->encproj;
     } else {
@@ -1535,6 +1614,9 @@ static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, 
         HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         e->encproj = P.encproj;
         use_ws(e, e->ws[p]);
+#ifdef NASR_STAMPS
+        g_stamp_pipe = p;
+#endif
         const int rc = body();
         e->encproj = encproj_saved;
         use_ws(e, e->ws[0]);
@@ -1561,16 +1643,17 @@ static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, 
             })) return -1;
     }
     // decode graph on the decode stream
-    if (capture(e->st2, "decode", dec_out, [&]() -> int {
-            HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, e->st2));
+    hipStream_t cs = e->st2 ? e->st2 : e->lane[nseg - 1];       // where the decode graph is captured (it is replayed on dec_stream())
+    if (capture(cs, "decode", dec_out, [&]() -> int {
+            HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, cs));
             DecParams dp;
             make_dec_params(e, g_rows, B, T * G, dp);
             dp.encproj = P.encproj;
-            launch_decode_begin(dp, e->st2);
+            launch_decode_begin(dp, cs);
             int it = 0;
-            for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, e->st2);
-            hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st2, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
-            HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
+            for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, cs);
+            hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, cs, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+            HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, cs));
             return 0;
         })) return -1;
     return 0;
@@ -1582,9 +1665,12 @@ static int pipe_advance(nasr_engine *e, int p) {
     nasr_engine::Pipe &P = e->pipe[p];
     if (P.stage == 0 || P.stage >= P.nseg) return 0;
     const int k = P.stage;
-    static const bool host_wait = getenv("NASR_SKEW_HOSTWAIT") != nullptr;
-    if (host_wait) HIPCHK(hipEventSynchronize(P.seg_done[k - 1]));
-    else HIPCHK(hipStreamWaitEvent(e->lane[k], P.seg_done[k - 1], 0));
+    // the previous piece was launched a whole call earlier: normally it is done.  If not, the HOST waits: a stream wait would
+    // put a barrier packet that finds its event pending into the lane's queue, and pending cross-queue barriers slow every
+    // queue's dispatch down (tests/micro/pipe_probe.hip: 2.0 -> 2.6 us per kernel at 2 lanes, far worse with more queues)
+    static const bool stream_wait = getenv("NASR_SKEW_STREAMWAIT") != nullptr;
+    if (stream_wait) HIPCHK(hipStreamWaitEvent(e->lane[k], P.seg_done[k - 1], 0));
+    else if (hipEventQuery(P.seg_done[k - 1]) != hipSuccess) { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[k - 1])); }
     { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.seg_graphs[k][P.key], e->lane[k])); }
     HIPCHK(hipEventRecord(P.seg_done[k], e->lane[k]));
     P.stage = k + 1;
@@ -1594,16 +1680,32 @@ static int pipe_advance(nasr_engine *e, int p) {
 // Completes the step in slot p: launches the encoder pieces it still lacks, waits for its encoder, launches its decode
 // graph on the decode stream (by now the younger steps' encoder pieces are queued on their lanes), waits for that,
 // finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
+// the decode graph runs on the decode stream, or -- when no hardware queue is left for one -- on the lane of the last encoder
+// piece, stream-ordered behind it
+static hipStream_t dec_stream(nasr_engine *e, const nasr_engine::Pipe &P) { return e->dec_on_last_lane ? e->lane[P.nseg - 1] : e->st2; }
+
+static int pipe_finish_launch(nasr_engine *e, int p) {
+    nasr_engine::Pipe &P = e->pipe[p];
+    if (P.stage == 0 || P.dec_launched) return 0;
+    while (P.stage < P.nseg)
+        if (pipe_advance(e, p)) return -1;
+    const int B = (int)P.streams.size();
+    if (!e->dec_on_last_lane) { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[P.nseg - 1])); }
+    for (int b = 0; b < B; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[B + b] = P.streams[b]->tok_read; }
+    { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], dec_stream(e, P))); }
+    HIPCHK(hipEventRecord(P.dec_done, dec_stream(e, P)));
+    P.dec_launched = true;
+    return 0;
+}
+
 static int pipe_finish(nasr_engine *e, int p) {
     nasr_engine::Pipe &P = e->pipe[p];
     if (P.stage == 0) return 0;
-    while (P.stage < P.nseg)
-        if (pipe_advance(e, p)) return -1;
+    if (pipe_finish_launch(e, p)) return -1;
+    P.dec_launched = false;
     const int B = (int)P.streams.size(), TS = P.T * P.G;
-    { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[P.nseg - 1])); }
-    for (int b = 0; b < B; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[B + b] = P.streams[b]->tok_read; }
-    { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], e->st2)); }
-    { HostTimer ht(e->host_wait_s); HIPCHK(hipStreamSynchronize(e->st2)); }
+    hipStream_t ds = dec_stream(e, P);
+    { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.dec_done)); }
     int *gh_active = P.gh_collect + (size_t)B * (1 + COLLECT_STRIDE);      // k_collect appends n_active to its records
     if (*gh_active != 0) {
         const GraphDescLayout L = graph_desc_layout(B, P.G);
@@ -1614,16 +1716,16 @@ static int pipe_finish(nasr_engine *e, int p) {
         e->decode_fallbacks++;
         for (;;) {
             e->decode_fallback_rounds++;
-            enqueue_decode_iters(e, dp, B, round, itn, e->st2);
-            HIPCHK(hipMemcpyAsync(gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, e->st2));
-            HIPCHK(hipStreamSynchronize(e->st2));
+            enqueue_decode_iters(e, dp, B, round, itn, ds);
+            HIPCHK(hipMemcpyAsync(gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, ds));
+            HIPCHK(hipStreamSynchronize(ds));
             if (*gh_active == 0) break;
             if (itn > TS * MAX_SYMBOLS + 64) return fail("decode did not terminate");
             round = std::min(2 * round, 32);
         }
-        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, e->st2, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
-        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, e->st2));
-        HIPCHK(hipStreamSynchronize(e->st2));
+        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, ds, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, ds));
+        HIPCHK(hipStreamSynchronize(ds));
     }
     P.stage = 0;
     return consume_collect(e, P.gh_collect, P.streams.data(), B);
@@ -1643,7 +1745,8 @@ static int pipe_drain(nasr_engine *e) {
 static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev, const int32_t *n_samples, int G,
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
-    const int nseg = std::max(1, std::min({e->opt_pipeline, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
+    if (ensure_pipe(e, (int)(e->pipe_seq % nasr_engine::NSLOT))) return -1;     // also picks the lanes
+    const int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
     const int64_t seq = e->pipe_seq;
     const int p = (int)(seq % nasr_engine::NSLOT);
     if (ensure_pipe(e, p)) return -1;
@@ -1703,13 +1806,25 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
     e->pipe_seq = seq + 1;
     // the steps before this one move on by one piece each, the one that has had all its pieces is decoded (a step whose
     // number of pieces differs -- the option was changed in between -- simply completes when its turn comes)
+    int fin[nasr_engine::MAXSEG], nfin = 0;                // steps that have had all their pieces: decoded in this call, oldest first
+    for (int k = nasr_engine::MAXSEG; k >= 1; k--) {
+        if (k > seq) continue;
+        const int q = (int)((seq - k) % nasr_engine::NSLOT);
+        const nasr_engine::Pipe &Q = e->pipe[q];
+        if (Q.stage != 0 && Q.seq == seq - k && Q.stage >= Q.nseg) fin[nfin++] = q;
+    }
+    // decode on the last piece's lane: queue it there before the next step's last piece goes onto that lane
+    if (e->dec_on_last_lane)
+        for (int i = 0; i < nfin; i++)
+            if (pipe_finish_launch(e, fin[i])) return -1;
     for (int k = 1; k <= nasr_engine::MAXSEG && k <= seq; k++) {
         const int q = (int)((seq - k) % nasr_engine::NSLOT);
         nasr_engine::Pipe &Q = e->pipe[q];
         if (Q.stage == 0 || Q.seq != seq - k) continue;
         if (Q.stage < Q.nseg) { if (pipe_advance(e, q)) return -1; }
-        else if (pipe_finish(e, q)) return -1;
     }
+    for (int i = 0; i < nfin; i++)                         // the decodes of two steps share the decoder state: one at a time
+        if (pipe_finish(e, fin[i])) return -1;
     e->graph_replays++;
     e->pipe_steps++;
     deliver(streams, B, tokens_out, tokens_cap, n_tokens);

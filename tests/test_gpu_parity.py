@@ -198,7 +198,7 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
     pcms = [synth.make_pcm(60 + b, secs) for b in range(2 * B)]
     n_steps = pcms[0].size // piece
     res = {}
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 3, 4):
         eng.set_option("pipeline", mode)
         grp = [[eng.stream(R) for _ in range(B)] for _ in range(2)]      # two groups of streams take turns
         toks = [[] for _ in range(2 * B)]
@@ -579,7 +579,8 @@ def test_smoke_entry():
     assert smoke.run(verbose=False)
 
 
-def test_pipelined_decode_fallback_path(tmp_path):
+@pytest.mark.parametrize("dec_lane", [False, True])
+def test_pipelined_decode_fallback_path(tmp_path, dec_lane):
     """The decode graph of a pipelined step carries a fixed number of iterations; a burst of symbols beyond it is finished
     eagerly on the second stream before the next decode graph is launched.  With the budget cut to its minimum
     (NASR_PIPE_ITERS=1, own process: the knob is read once) the fallback runs many times -- tokens still equal synchronous
@@ -630,6 +631,8 @@ for b in range(B):
 print("TOKENS", sum(len(t) for t in res[1]))
 """)
     env = dict(os.environ, NASR_PIPE_ITERS="1", NASR_STATS="1")
+    if dec_lane:        # no stream for the decode graphs: they (and their eager fallback rounds) run behind the last encoder piece
+        env["NASR_DEC_LANE"] = "1"
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert int(r.stdout.split("TOKENS")[1].split()[0]) > 20
