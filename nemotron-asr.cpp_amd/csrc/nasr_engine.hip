@@ -927,29 +927,34 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
 }
 
 // ---- small-M form of the 24 layers: 8 launches per layer (kernels_fused.hip) ------------------------
-// layers [l0, l1): a segment boundary hands over x (X[0]: four flips per layer) and the split-K partials of FFN2
-static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G, int l0, int l1) {
+// launches [k0, k1) of the 8 x n_layers launches of the fused layers: a piece boundary may sit inside a layer (every
+// intermediate lives in the step's workspace set), so the pieces of a pipelined step can be balanced to a launch
+static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G, int k0, int k1) {
     const int TS = G * T;                      // rows per stream in this launch (G chunks batched)
     const int M = B * TS, nL = e->hp.n_layers, ks = e->hp.kernel_size;
     hipStream_t st = e->st;
     float *X[2] = {e->x, e->x2};
     int cur = 0;
-    int prev_splits = l0 > 0 ? 4 : 0;   // split-K partials pending from the previous layer's FFN2
+    int prev_splits = 0;                // split-K partials pending from the previous layer's FFN2
+    int kidx = 0;                       // index of the launch being described
 #ifdef NASR_STAMPS
     unsigned long long *stamp_buf = g_stamp_buf + (size_t)g_stamp_pipe * STAMP_PER_SLOT * 32;
-    int stamp_slot = 8 * l0;
 #endif
     auto launch = [&](FusedParams &f, const char *name, double bytes, double flops) {
+        const int k = kidx++;
+        if (k < k0 || k >= k1) return;                          // another piece's launch
         ProfScope ps(e, name, bytes, flops);
 #ifdef NASR_STAMPS
-        f.stamps = stamp_buf + (size_t)(stamp_slot++) * 32;
+        f.stamps = stamp_buf + (size_t)k * 32;
 #endif
         launch_fused_skinny(f, st);
     };
     auto wbytes = [&](int N, int K) { return (double)N * K * 2 + (double)M * (K + N) * 4; };
-    for (int l = l0; l < l1; l++) {
+    for (int l = k0 / 8; l < (k1 + 7) / 8 && l < nL; l++) {
         LayerW &L = e->L[l];
         FusedParams f;
+        kidx = 8 * l; cur = 0;
+        prev_splits = l > 0 ? 4 : 0;
         // K1: [norm_out of layer l-1] + LN_ff1 -> W1 -> SiLU
         memset(&f, 0, sizeof(f));
         f.pro = PRO_LN; f.x_in = X[cur]; f.x_out = X[cur ^ 1]; f.part = e->part; f.part_splits = prev_splits; f.scale = 0.5f;
@@ -988,7 +993,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
             ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = 1;
             ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T; ap.TS = TS;
             ap.ctx_out = e->ctx;
-            { ProfScope ps(e, "k_attention", (double)B * (3.0 * (LCTX + T)) * D * 2, 2.0 * M * (LCTX + T) * D * 3); launch_attention(ap, st); }
+            if (kidx >= k0 && kidx < k1) { ProfScope ps(e, "k_attention", (double)B * (3.0 * (LCTX + T)) * D * 2, 2.0 * M * (LCTX + T) * D * 3); launch_attention(ap, st); }   // rides with the launch that consumes it
             wo_splits = 4;
             memset(&f, 0, sizeof(f));
             f.pro = PRO_PLAIN; f.g.A = e->ctx; f.g.lda = D; f.g.W = L.wo; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4;
@@ -1017,7 +1022,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
             cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
             cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = TS; cp.ks = ks;
             cp.c_out = e->cbuf; cp.act_bf16 = 1;
-            { ProfScope ps(e, "k_dwconv", (double)M * D * 6 + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks); launch_dwconv(cp, st); }
+            if (kidx >= k0 && kidx < k1) { ProfScope ps(e, "k_dwconv", (double)M * D * 6 + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks); launch_dwconv(cp, st); }
             memset(&f, 0, sizeof(f));
             f.pro = PRO_PLAIN; f.g.A = e->cbuf; f.g.lda = D; f.g.W = L.pw2; f.g.M = M; f.g.N = D; f.g.K = D; f.g.splits = 4;
             f.g.epi = EPI_PART_F32; f.g.out_f32 = e->part; f.g.ldo = D;
@@ -1037,11 +1042,12 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         launch(f, "k_fused_plain_gemm", wbytes(D, FF), 2.0 * M * D * FF);
         prev_splits = 4;
     }
-    if (l1 < nL) return 0;                     // the next segment's first kernel picks x and the partials up
+    if (k1 < 8 * nL) return 0;                 // the next piece's first kernel picks the intermediates up
     // x = norm_out(x + 0.5 * FFN2) of the last layer (cur is back at X[0] = e->x: 4 flips per layer)
+    cur = 0;
     PostParams q;
     memset(&q, 0, sizeof(q));
-    q.x = X[cur]; q.M = M; q.part = e->part; q.splits = prev_splits; q.scale = 0.5f; q.ln_out = 1;
+    q.x = X[cur]; q.M = M; q.part = e->part; q.splits = 4; q.scale = 0.5f; q.ln_out = 1;
     q.ln1_w = e->L[nL - 1].ln_out_w; q.ln1_b = e->L[nL - 1].ln_out_b;
     if (X[cur] != e->x) q.copy_out = e->x;
     ProfScope ps(e, "k_post", (double)M * D * 24);
@@ -1128,7 +1134,24 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     const int TS = G * T;                      // rows per stream in this launch
     if (G > 1 && e->debug) return fail("internal: multi-chunk steps are not available in debug mode");
     if (fused) {
-        if (run_layers_fused(e, rows, B, T, G, l0, l1)) return -1;
+        // pieces of the fused path can be cut at any launch: the first one also carries the front end (about 8 launches' worth
+        // of time), the last one the joint's encoder projection.  Three pieces: 57 + 69 + 66 launches of 192.  Worth little:
+        // batch 1 0.492-0.497 ms per step against 0.498-0.500 at 7 + 9 + 8 layers (56 + 72 + 64) -- with three lanes the step is
+        // no longer bound by its longest lane (tests/micro/stamps_timeline.py: the kernels of the three chains mostly alternate
+        // instead of overlapping: 0 / 1 / 2 / 3 kernels in flight 29 / 40 / 20 / 10 % of the time).
+        static const char *b8_env = getenv("NASR_SKEW_BOUNDS8");          // experiment: explicit first launches of pieces 1.., e.g. "59,126"
+        auto bound8 = [&](int k) {
+            if (k <= 0) return 0;
+            if (k >= nseg) return 8 * nLayers;
+            if (b8_env) {
+                const char *q = b8_env;
+                for (int i = 1; i < k && q; i++) { q = strchr(q, ','); if (q) q++; }
+                if (q && atoi(q) > 0 && atoi(q) < 8 * nLayers) return atoi(q);
+            }
+            if (nseg == 3 && nLayers >= 6 && !bounds_env) return (k == 1 ? 57 : 126) * nLayers / 24;
+            return 8 * bound(k);
+        };
+        if (run_layers_fused(e, rows, B, T, G, bound8(seg), bound8(seg + 1))) return -1;
     } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
         if (front) {
