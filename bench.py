@@ -149,8 +149,8 @@ def pmc_traffic(kernel_symbol_part, tag):
     return round(tot / n) if n else None
 
 
-_SYMBOL = {"k_fused_ln_gemm": ("k_fused_skinny<0>",), "k_fused_plain_gemm": ("k_fused_skinny<1>",), "k_fused_attn_gemm": ("k_fused_skinny<2>",),
-           "k_fused_dwconv_gemm": ("k_fused_skinny<3>",), "k_gemm_tiled": ("k_gemm_roles", "k_gemm_tiled2", "k_gemm_t64"), "k_gemm_skinny": ("k_gemm_skinny",)}
+_SYMBOL = {"k_fused_ln_gemm": ("k_fused_skinny<0,",), "k_fused_plain_gemm": ("k_fused_skinny<1,",), "k_fused_attn_gemm": ("k_fused_skinny<2,",),
+           "k_fused_dwconv_gemm": ("k_fused_skinny<3,",), "k_gemm_tiled": ("k_gemm_roles", "k_gemm_tiled2", "k_gemm_t64"), "k_gemm_skinny": ("k_gemm_skinny",)}
 
 
 class Run:

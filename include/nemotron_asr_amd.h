@@ -190,8 +190,10 @@ enum {
  * what its layer l left in the K/V ring and the conv cache).  E = 1: the decode graph of step s beside the encoder graph
  * of step s + 1.  The same tokens come out, E calls later: nasr_engine_step returns what has been decoded so far;
  * nasr_engine_finalize, nasr_engine_collect and every other entry point first complete the steps in flight.  Results are
- * bit-identical to synchronous stepping.  Throughput option for callers that push back to back (a server draining a
- * backlog, a file); a live stream keeps the default. */
+ * bit-identical to synchronous stepping.  The engine runs at most as many pieces as it finds HIP streams that truly run side
+ * by side (it measures which streams share a hardware queue at the first pipelined step: normally 3 lanes + a decode stream,
+ * so E = 4 runs as 3; fewer when the process leaves it fewer queues).  Throughput option for callers that push back to back
+ * (a server draining a backlog, a file); a live stream keeps the default. */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);

@@ -16,13 +16,14 @@
 
 static void usage(const char *prog) {
     fprintf(stderr,
-            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline | --pipeline2]\n"
+            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline | --pipeline2 | --pipeline3]\n"
             "  audio: raw s16le, 16 kHz, mono.  right_context in {0, 1, 6, 13} (80 ms .. 1.12 s lookahead)\n"
             "  --read-chunks N: read N chunks of audio per call (default 1 = the reference's read size); a file is\n"
             "                   transcribed fastest with N = 256: same transcript, the chunks of a read share one launch sequence\n"
             "  --timestamps:    print the final transcript again with {seconds} in front of every word\n"
             "  --pipeline:      decode of one read runs beside the encoder of the next (same transcript; each delta appears one read later)\n"
             "  --pipeline2:     in addition the two halves of the encoder of consecutive reads run side by side (deltas two reads later)\n"
+            "  --pipeline3:     the encoder in three pieces (deltas three reads later): the fastest way through a file\n"
             "  --diarize <diarize.gguf> [--rttm <file>] [--speaker-text <file>] [--json <file>] [--num-speakers K] [--sub-shift SEC] [--vad-onset P] [--vad-offset P]\n"
             "                   speaker diarization beside the transcript (speaker-tagged transcript on stdout at EOF)\n", prog);
 }
@@ -47,6 +48,7 @@ int main(int argc, char **argv) {
         else if (a == "--timestamps") timestamps = true;
         else if (a == "--pipeline") pipeline = 1;
         else if (a == "--pipeline2") pipeline = 2;
+        else if (a == "--pipeline3") pipeline = 3;
         else if (a == "--read-chunks" && i + 1 < argc) read_chunks = atoi(argv[++i]);
         else if (a == "--diarize" && i + 1 < argc) diarize_gguf = argv[++i];
         else if (a == "--rttm" && i + 1 < argc) rttm_path = argv[++i];

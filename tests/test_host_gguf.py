@@ -125,9 +125,10 @@ def test_cli_end_to_end(tmp_path):
                       for t, f in zip(ref, ost.token_frames()))
     assert lines[-2] == stamped
     # pipelined steps: same transcript and tokens (each delta is printed one read later, the rest by finalize)
-    r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--print-tokens", "--pipeline"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stderr
-    assert [int(x) for x in r.stdout.splitlines()[-1].split()[1:]] == ref
+    for flag in ("--pipeline", "--pipeline3"):
+        r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--print-tokens", flag], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert [int(x) for x in r.stdout.splitlines()[-1].split()[1:]] == ref, flag
     r = subprocess.run([str(cli), str(model), str(audio), "80", "5"], capture_output=True, text=True)
     assert r.returncode == 1 and "right_context" in r.stderr
     # the default of nemo_init (bf16 engine, no --f32): against the bf16-emulating oracle -- same leading tokens, high aligned
@@ -167,7 +168,7 @@ def _recv(sock):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype_flag,pipeline", [("--f32", 0), (None, 0), ("--f32", 2)])
+@pytest.mark.parametrize("dtype_flag,pipeline", [("--f32", 0), (None, 0), ("--f32", 3)])
 def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
     """Wire protocol of the reference server (src/server-protocol.h:24-41) served by the batch-forming worker:
     3 streams on 2 connections (two right_context groups), text == oracle tokens -> text, errors are framed.
