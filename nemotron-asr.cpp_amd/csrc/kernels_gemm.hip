@@ -490,10 +490,19 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_roles<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
 }
 
-// the split-K GEMMs with N = 1024 use 128 x 64 tiles when that halves the split factor (see k_gemm_t64)
+// 128 x 64 tiles (k_gemm_t64): for the split-K GEMMs with N = 1024 when that halves the split factor, and for any other GEMM
+// whose 128 x 128 tiling gives at most 64 workgroups (a quarter of the CUs).  With pipelined steps "fill the chip" is the wrong
+// rule for the in-between sizes: CUs one launch leaves idle run another chain's kernels.  Measured with three lanes, half-width
+// tiles wherever the 128 x 128 tiling had <= 128 workgroups against the split-K form only: 16 streams x R = 13 (32-64 tiles)
+// 1.22 vs 1.32 ms per step, 32 streams (64-128 tiles) 1.82 vs 1.77, 64 streams (pw1: 112 tiles -> 224) 2.66 vs 2.65 -- although
+// alone the 112-tile launch takes 13.3 us and the vendor library's MT128x64 kernel 10.6 (tests/prof_gemm_shapes.sh).
 bool gemm_use_t64(int M, int N, int epi) {
     static const int on = getenv("NASR_GEMM_T64") ? atoi(getenv("NASR_GEMM_T64")) : 1;
-    return on && epi == EPI_PART_F32 && N == 1024 && M > gemm_skinny_max_m() && (N / 128) * ((M + 127) / 128) < 128;
+    if (!on || M <= gemm_skinny_max_m()) return false;
+    const int tiles = (N / 128) * ((M + 127) / 128);
+    if (epi == EPI_PART_F32) return N == 1024 && tiles < 128;
+    static const int wide_max = getenv("NASR_GEMM_T64_WIDE") ? atoi(getenv("NASR_GEMM_T64_WIDE")) : 64;
+    return tiles <= wide_max;
 }
 int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 128; }
 

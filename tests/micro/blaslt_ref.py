@@ -1,19 +1,28 @@
-"""What the vendor library (hipBLASLt through torch.matmul) reaches on the large-M GEMM shapes of the layer --
-a yardstick for k_gemm_tiled2, not a dependency of the engine."""
-import torch, time
-torch.manual_seed(0)
-dev = "cuda"
-for (M, N, K) in [(896, 4096, 1024), (896, 1024, 4096), (896, 3072, 1024), (896, 1024, 1024), (896, 2048, 1024)]:
+"""micro-benchmark: what the vendor GEMM library (hipBLASLt / rocBLAS through torch.matmul) takes for the five GEMM shapes of a
+conformer layer at 64 streams x R = 13 (M = 896 rows, bf16) -- a reference point for k_gemm_roles / k_gemm_t64, whose epilogues
+(bias, SiLU, GLU, split-K partials, K/V scatter) the library calls do not have.  Run under rocprofv3 --kernel-trace --stats for
+per-kernel durations, or alone for event timings.
+usage: python3 tests/micro/blaslt_ref.py [M]"""
+import sys
+import torch
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 896
+shapes = [("W1   (N=4096,K=1024)", 4096, 1024), ("W2   (N=1024,K=4096)", 1024, 4096), ("QKV  (N=3072,K=1024)", 3072, 1024),
+          ("pw1  (N=2048,K=1024)", 2048, 1024), ("Wo/pw2 (N=1024,K=1024)", 1024, 1024)]
+dev = torch.device("cuda:0")
+for name, N, K in shapes:
     a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
-    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
-    for _ in range(20):
-        c = a @ w.t()
+    ws = [torch.randn(N, K, device=dev, dtype=torch.bfloat16) for _ in range(24)]      # 24 layers' worth: no weight reuse from cache
+    for w in ws[:3]:
+        torch.matmul(a, w.t())
     torch.cuda.synchronize()
-    n = 200
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(n):
-            c = a @ w.t()
-    g.replay(); torch.cuda.synchronize()
-    t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-    print(f"M={M} N={N} K={K}: {dt * 1e6:.2f} us  {2 * M * N * K / dt / 1e12:.0f} TFLOP/s", flush=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        for w in ws:
+            torch.matmul(a, w.t())
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / (reps * len(ws))
+    print(f"{name}: {us:6.2f} us per GEMM back to back = {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s")
