@@ -920,7 +920,13 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
     if (!e->bf16) return 1;
     const bool skinny = M <= gemm_skinny_max_m();
     int tasks = skinny ? (N / 16) * ((M + 63) / 64) : (N / gemm_tile_n(M, N, EPI_PART_F32)) * ((M + 127) / 128);
-    if (!skinny) return tasks <= 72 ? 4 : (tasks < 256 ? 2 : 1);   // ~one wave of workgroups; partial traffic grows with the split factor
+    static const int large_splits = getenv("NASR_LARGE_SPLITS") ? atoi(getenv("NASR_LARGE_SPLITS")) : 0;      // experiment knob
+    if (!skinny && large_splits > 0) return large_splits;
+    // partial traffic grows with the split factor, and with pipelined steps the CUs a launch leaves idle run another chain's
+    // kernels: four splits only up to 40 tiles (three lanes, R = 13: 12 / 16 streams = 32 tiles 1.15 / 1.23 ms with 4 splits
+    // against 1.23 / 1.30 with 2; 24 streams = 48 tiles 1.53 vs 1.50; 32 streams = 64 tiles 1.82 vs 1.68; 64 streams = 112 tiles:
+    // 2 splits 2.76, 1 split 2.75, 4 splits 3.03)
+    if (!skinny) return tasks <= 40 ? 4 : (tasks < 256 ? 2 : 1);
     int s = 1;
     while (s < 8 && tasks * s < 256 && (K / 32) / (s * 2) >= 4) s *= 2;
     return s;
