@@ -1014,7 +1014,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         launch(f, "k_fused_ln_gemm", wbytes(2 * D, D), 2.0 * M * 2 * D * D);
         cur ^= 1;
         // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2; same rule as K4
-        static const int pw2_splits_env = getenv("NASR_PW2_SPLITS") ? atoi(getenv("NASR_PW2_SPLITS")) : 4;
+        static const int pw2_splits_env = getenv("NASR_PW2_SPLITS") && atoi(getenv("NASR_PW2_SPLITS")) == 8 ? 8 : 4;   // experiment knob: 4 or 8 (the one-row kernel holds 2 k-tiles per wave)
         const int pw2_splits = M <= fuse_max_m ? pw2_splits_env : 4;
         if (M <= fuse_max_m) {
             memset(&f, 0, sizeof(f));

@@ -579,8 +579,8 @@ def test_smoke_entry():
     assert smoke.run(verbose=False)
 
 
-@pytest.mark.parametrize("dec_lane", [False, True])
-def test_pipelined_decode_fallback_path(tmp_path, dec_lane):
+@pytest.mark.parametrize("dec_lane,hw_queues", [(False, None), (True, None), (False, "2"), (False, "1")])
+def test_pipelined_decode_fallback_path(tmp_path, dec_lane, hw_queues):
     """The decode graph of a pipelined step carries a fixed number of iterations; a burst of symbols beyond it is finished
     eagerly on the second stream before the next decode graph is launched.  With the budget cut to its minimum
     (NASR_PIPE_ITERS=1, own process: the knob is read once) the fallback runs many times -- tokens still equal synchronous
@@ -633,6 +633,8 @@ print("TOKENS", sum(len(t) for t in res[1]))
     env = dict(os.environ, NASR_PIPE_ITERS="1", NASR_STATS="1")
     if dec_lane:        # no stream for the decode graphs: they (and their eager fallback rounds) run behind the last encoder piece
         env["NASR_DEC_LANE"] = "1"
+    if hw_queues:       # fewer hardware queues than lanes: the engine finds fewer streams that overlap and runs fewer pieces
+        env["GPU_MAX_HW_QUEUES"] = hw_queues
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert int(r.stdout.split("TOKENS")[1].split()[0]) > 20
@@ -641,3 +643,12 @@ print("TOKENS", sum(len(t) for t in res[1]))
     n_fallback = int(stats[1].split("decode fallbacks")[1].split()[0])        # second engine = pipelined
     assert int(stats[2].split("decode fallbacks")[1].split()[0]) > 0           # third = skewed encoder halves too
     assert "pipelined" in stats[1] and n_fallback > 0, stats
+    lanes = [ln for ln in r.stderr.splitlines() if "lane(s) side by side" in ln]
+    assert len(lanes) == 2, r.stderr[-1500:]                                     # the two pipelined engines picked their lanes
+    n_lanes = int(lanes[-1].split("pipelined steps:")[1].split()[0])
+    if hw_queues:
+        assert n_lanes <= int(hw_queues) and "behind the last piece" in lanes[-1], lanes
+    elif dec_lane:
+        assert "behind the last piece" in lanes[-1], lanes
+    else:
+        assert n_lanes >= 2, lanes
