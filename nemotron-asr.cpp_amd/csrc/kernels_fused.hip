@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 float *cc_out = c.cc_pool + (size_t)rd.slot * c.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * ks1 * D;
                 const float *gl = c.glu + (size_t)b * T * D;
                 float4 acc;
+                bool cache_written = false;
                 if (c.ks == 9) {
                     float4 z[9];
 #pragma unroll
@@ -425,6 +426,11 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                     acc = make_float4(z[0].x * w[0].x, z[0].y * w[0].y, z[0].z * w[0].z, z[0].w * w[0].w);
 #pragma unroll
                     for (int k = 1; k < 9; k++) { acc.x += z[k].x * w[k].x; acc.y += z[k].y * w[k].y; acc.z += z[k].z * w[k].z; acc.w += z[k].w * w[k].w; }
+                    if (writer && i == 0 && T == 1) {      // the stream's new cache = window rows 1..8: already in registers
+#pragma unroll                                             // (the load-then-store loop below made block (0,0) 1.3 us the kernel's last)
+                        for (int r2 = 0; r2 < 8; r2++) *(float4 *)(cc_out + (size_t)r2 * D + c4) = z[r2 + 1];
+                        cache_written = true;
+                    }
                 } else {
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     for (int k = 0; k < c.ks; k++) {
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                     n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
                     store4_panel(panel, m, c4 - k0, KP, n.x, n.y, n.z, n.w);
                 }
-                if (writer && i == 0) {
+                if (writer && i == 0 && !cache_written) {
                     for (int r2 = 0; r2 < ks1; r2++) {
                         const int rr = T + r2;
                         *(float4 *)(cc_out + (size_t)r2 * D + c4) =
