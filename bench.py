@@ -460,6 +460,13 @@ def main():
 
     # ---- diarization side-car beside the headline workload (only on request; configs[4] is measured below) --------------
     def diarization_entry(r, n_ov):
+        # three encoder lanes + the decode stream occupy all four hardware queues of the runtime: the side-car's stream would
+        # share one of them (measured: 8.1 ms per step against 7.1 ms with two lanes).  The ASR engine gives one lane back BEFORE
+        # the side-car's stream is created (a new stream gets the least-used queue) and runs two lanes here.
+        side_depth = 0 if args.sync_steps else min(args.pipeline_depth, 2)
+        r.drain()
+        r.eng.set_option("lanes", 2)
+        r.eng.set_option("pipeline", side_depth)
         dW = synth.make_diar_weights()
         deng = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * r.B), device=local_rank)
         hist = 10080 - 160                                   # samples of history a new 10 ms hop needs
@@ -483,11 +490,6 @@ def main():
         # step of the same audio runs on the engine's stream (ctypes releases the GIL during both calls)
         import threading
         gate_go, gate_done = threading.Barrier(2), threading.Barrier(2)
-        # three encoder lanes + the decode stream occupy all four hardware queues of the runtime: the side-car's stream would
-        # share one of them (measured: 8.1 ms per step against 7.1 ms with two lanes), so the ASR engine runs two lanes here
-        side_depth = 0 if args.sync_steps else min(args.pipeline_depth, 2)
-        r.drain()
-        r.eng.set_option("pipeline", side_depth)
 
         def side_car():
             for _ in range(n_ov):

@@ -193,7 +193,10 @@ enum {
  * bit-identical to synchronous stepping.  The engine runs at most as many pieces as it finds HIP streams that truly run side
  * by side (it measures which streams share a hardware queue at the first pipelined step: normally 3 lanes + a decode stream,
  * so E = 4 runs as 3; fewer when the process leaves it fewer queues).  Throughput option for callers that push back to back
- * (a server draining a backlog, a file); a live stream keeps the default. */
+ * (a server draining a backlog, a file); a live stream keeps the default.
+ * "lanes" (1..4): keep at most this many encoder lanes and give the other lanes' streams back -- for a process with another GPU
+ * client (the diarization side-car): a stream created after this call gets a hardware queue the engine no longer uses.  Not
+ * reversible for the engine's lifetime. */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);

@@ -151,6 +151,7 @@ struct nasr_engine {
     hipStream_t st2 = nullptr;       // decode graphs
     hipStream_t lane[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};   // lane[k]: encoder piece k (lane[0] = st)
     int n_lanes = 1;                 // lanes that run side by side (each on a hardware queue of its own): the number of pieces is capped by it
+    int max_lanes = MAXSEG;          // option "lanes": the engine keeps at most this many (the others' hardware queues are left to other clients of the process)
     bool dec_on_last_lane = false;   // no hardware queue left for the decode graphs: they run on the last piece's lane, right behind that piece
     struct Pipe {
         bool ready = false;                               // buffers of this slot allocated
@@ -800,6 +801,7 @@ static int stage_desc(nasr_engine *e, const std::vector<Tp> &host, const Tp **de
 }
 
 static int pipe_drain(nasr_engine *e);     // completes a pipelined step that is still in flight (defined with the graph steps)
+static void release_lanes(nasr_engine *e);  // destroys the lane streams beyond max_lanes
 
 // ---- streams ------------------------------------------------------------------------------------
 // keep_reference_state: what the reference's nemo_stream_context::reset() leaves behind (src/nemo-stream.cpp:95-115):
@@ -1455,6 +1457,16 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         if (value < 0 || value > nasr_engine::MAXSEG) return fail("pipeline must be 0 .. %d", (int)nasr_engine::MAXSEG);
         e->opt_pipeline = value;
     }
+    else if (!strcmp(key, "lanes")) {
+        // give hardware queues back: another GPU client of the process (the diarization side-car) whose stream is created AFTER
+        // this call lands on a queue this engine no longer uses (the runtime hands a new stream the least-used queue)
+        ApiGuard api_guard;
+        HIPCHK(hipSetDevice(e->device));
+        if (value < 1 || value > nasr_engine::MAXSEG) return fail("lanes must be 1 .. %d", (int)nasr_engine::MAXSEG);
+        if (pipe_drain(e)) return -1;
+        e->max_lanes = value;
+        release_lanes(e);
+    }
     else return fail("unknown option '%s'", key);
     return 0;
 }
@@ -1605,11 +1617,19 @@ static int pick_lanes(nasr_engine *e) {
     return 0;
 }
 
+static void release_lanes(nasr_engine *e) {
+    if (!e->pipe_ready) return;                                // applied when the lanes are picked
+    for (int k = std::max(1, e->max_lanes); k < nasr_engine::MAXSEG; k++)
+        if (e->lane[k]) { hipStreamSynchronize(e->lane[k]); hipStreamDestroy(e->lane[k]); e->lane[k] = nullptr; }
+    e->n_lanes = std::min(e->n_lanes, std::max(1, e->max_lanes));
+}
+
 // streams, events and the buffers of slot p (allocated when first used: E + 1 slots for E encoder pieces)
 static int ensure_pipe(nasr_engine *e, int p) {
     if (!e->pipe_ready) {
         if (pick_lanes(e)) return -1;
         e->pipe_ready = true;
+        release_lanes(e);
     }
     nasr_engine::Pipe &P = e->pipe[p];
     if (P.ready) return 0;
