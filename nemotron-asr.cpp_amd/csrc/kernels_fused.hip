@@ -347,8 +347,10 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
         uint2 vv[11];
         value_rows(0, vv);
         if ((int)threadIdx.x < M * DH) { ((bf16_t *)qu)[threadIdx.x] = f32_to_bf16(qq + bu); ((bf16_t *)qv)[threadIdx.x] = f32_to_bf16(qq + bv); }
+        STAMP(2);
         __syncthreads();
         score(kk, pp, m0, j0, ok0);
+        STAMP(3);
         if (MMAX > 1 && npair > 128) {                               // M = 2: the remaining pairs
             int m1, j1;
             const bf16_t *prow1;
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
             if (lane + 64 < KV) sc[m * KVC + lane + 64] = e1 * inv;
         }
         __syncthreads();
+        STAMP(6);
         // P.V: thread = (key group kgp of 8, 4 consecutive d); partial sums of the 8 groups reduced through LDS
         {
             float *pv = qu;                                          // reuse: [2 rows][8 groups][128]
