@@ -506,8 +506,16 @@ bool gemm_use_t64(int M, int N, int epi) {
 }
 int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 128; }
 
+// Largest M served by the weight-streaming ("skinny") kernel; above it the LDS-tiled kernels take over.  Round 1 had 128 (chosen
+// on synchronous steps).  Re-measured in round 2 (ms per step, <= 32 / <= 64 / <= 128 rows skinny):
+//   three lanes: 64 streams x R = 0 (M = 64) 1.15 / 1.33 / 1.33; 40 / 48 streams x R = 0 1.04 / 1.13 and 1.06 / 1.19 / -;
+//                64 x R = 1 (M = 128) 1.29 / 1.30 / 1.89; 8 x R = 13 and 16 x R = 6 (M = 112) 1.13 / 1.13 / 1.62;
+//                32 rows and fewer: skinny wins (32 streams x R = 0 0.94 against 1.00 tiled; 16 x R = 1 0.89 / 0.99)
+//   synchronous: M = 64 2.66 / - / 2.56, M = 48 2.56 / - / 2.41, M = 112 2.66 / - / 2.81, M = 128 2.95 / - / 3.17
+// -> 32 rows.  ONE threshold for both modes: which kernel a GEMM runs on must not depend on the mode, or pipelined steps would
+// stop being bit-identical to synchronous ones (the synchronous step pays <= 6 % for it between 33 and 64 rows and gains above).
 int gemm_skinny_max_m() {
-    static const int v = getenv("NASR_SKINNY_MAXM") ? atoi(getenv("NASR_SKINNY_MAXM")) : 128;   // measured: 128 rows 3.94 vs 4.36 ms per step, 256 rows 4.40 vs 3.88
+    static const int v = getenv("NASR_SKINNY_MAXM") ? atoi(getenv("NASR_SKINNY_MAXM")) : 32;
     return v;
 }
 
