@@ -333,6 +333,92 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 vv[u] = *(const uint2 *)(vbase + (size_t)ring * D);
             }
         };
+        if (MMAX == 1) {
+            // One row (T = 1, KV = 71).  The scattered form below (a thread pair per key, 128 contiguous bytes per thread as eight
+            // 16-byte loads) keeps the CU's address unit busy for 2.5 us before the last of its 35 load instructions per wave has
+            // even been issued (stamps: "all loads issued" at 2.57 us; each instruction touches 64 different 64-byte segments).
+            // Here a load instruction of a wave covers 4 whole head rows (256 contiguous bytes each): lane = (sub-row sr, chunk
+            // c of 8 dims), key j = 16 t + 4 wave + sr in pass t = 0..4.  A lane forms the partial dot of its 8 dims (v_dot2 on
+            // bf16 q + bias, as before), the 16 lanes of a row add up on the DPP path, and P.V runs in the same layout (each lane
+            // accumulates its 8 dims over its 5 keys).  No q staging through LDS, no softmax barrier: every wave computes the
+            // statistics of the 71 scores itself.
+            const RowDesc rd = rds[0];
+            const int sr = lane >> 4, c = lane & 15;
+            const float4 *qp = (const float4 *)(a.q + h * DH + c * 8);
+            const float4 *up = (const float4 *)(a.bias_u + h * DH + c * 8), *vp = (const float4 *)(a.bias_v + h * DH + c * 8);
+            const float4 q0 = qp[0], q1 = qp[1], u0 = up[0], u1 = up[1], b0 = vp[0], b1 = vp[1];
+            uint4 kk[5], pp[5], vr[5];
+            int jk[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                jk[t] = t * 16 + wave * 4 + sr;
+                const int jc = jk[t] < KV ? jk[t] : 0;
+                pp[t] = *(const uint4 *)((const bf16_t *)a.posproj + (size_t)(jc + T - 1) * D + h * DH + c * 8);
+            }
+            issue_weights();
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const int jc = jk[t] < KV ? jk[t] : 0;
+                int ring = rd.kv_head + jc;
+                if (ring >= KVC) ring -= KVC;
+                if (ring >= KVC) ring -= KVC;
+                const bf16_t *krow = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)ring * D + h * DH + c * 8;
+                kk[t] = *(const uint4 *)krow;
+                vr[t] = *(const uint4 *)(krow + (size_t)KVC * D);
+            }
+            STAMP(2);
+            auto pk2 = [](float x, float y) { return (uint32_t)f32_to_bf16(x) | ((uint32_t)f32_to_bf16(y) << 16); };
+            const uint32_t qu8[4] = {pk2(q0.x + u0.x, q0.y + u0.y), pk2(q0.z + u0.z, q0.w + u0.w), pk2(q1.x + u1.x, q1.y + u1.y), pk2(q1.z + u1.z, q1.w + u1.w)};
+            const uint32_t qv8[4] = {pk2(q0.x + b0.x, q0.y + b0.y), pk2(q0.z + b0.z, q0.w + b0.w), pk2(q1.x + b1.x, q1.y + b1.y), pk2(q1.z + b1.z, q1.w + b1.w)};
+            const int valid = rd.valid_len < LCTX ? rd.valid_len : LCTX;
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const uint32_t kw[4] = {kk[t].x, kk[t].y, kk[t].z, kk[t].w}, pw[4] = {pp[t].x, pp[t].y, pp[t].z, pp[t].w};
+                float s1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, qu8[e]), __builtin_bit_cast(bf16x2, kw[e]), s1, false);
+                    s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, qv8[e]), __builtin_bit_cast(bf16x2, pw[e]), s1, false);
+                }
+                s1 += dpp_mov<0xB1>(s1);                                // the 16 lanes of the row
+                s1 += dpp_mov<0x4E>(s1);
+                s1 += dpp_mov<0x141>(s1);
+                s1 += dpp_mov<0x140>(s1);
+                if (c == 0 && jk[t] < KV) {
+                    float v = s1 * scale;
+                    if (jk[t] < LCTX - valid) v += -1e9f;
+                    sc[jk[t]] = v;
+                }
+            }
+            STAMP(3);
+            __syncthreads();
+            const float v0 = lane < KV ? sc[lane] : -INFINITY, v1 = lane + 64 < KV ? sc[lane + 64] : -INFINITY;
+            const float mx = wmax_f(fmaxf(v0, v1));
+            const float inv = 1.0f / wsum_f((lane < KV ? __expf(v0 - mx) : 0.0f) + (lane + 64 < KV ? __expf(v1 - mx) : 0.0f));
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const float w = jk[t] < KV ? __expf(sc[jk[t]] - mx) * inv : 0.0f;
+                const uint32_t vw[4] = {vr[t].x, vr[t].y, vr[t].z, vr[t].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc8[2 * e] += w * __uint_as_float(vw[e] << 16);
+                    acc8[2 * e + 1] += w * __uint_as_float(vw[e] & 0xffff0000u);
+                }
+            }
+            STAMP(6);
+            float *pv = qu;                                             // [16 row groups][128]
+            *(float4 *)(pv + (wave * 4 + sr) * DH + c * 8) = make_float4(acc8[0], acc8[1], acc8[2], acc8[3]);
+            *(float4 *)(pv + (wave * 4 + sr) * DH + c * 8 + 4) = make_float4(acc8[4], acc8[5], acc8[6], acc8[7]);
+            __syncthreads();
+            if ((int)threadIdx.x < DH) {
+                const int d = threadIdx.x;
+                float o = 0.f;
+#pragma unroll
+                for (int gI = 0; gI < 16; gI++) o += pv[gI * DH + d];
+                *(bf16_t *)(panel + ((((d >> 3) ^ 0) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
+            }
+        } else {
         // (a) + (b) for pass 0 / row 0
         int m0, j0;
         const bf16_t *prow0;
@@ -397,6 +483,7 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 for (int gI = 0; gI < 8; gI++) o += pv[(m * 8 + gI) * DH + d];
                 *(bf16_t *)(panel + m * KP * 2 + ((((d >> 3) ^ (m & 15)) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
             }
+        }
         }
         __syncthreads();
     } else if (PRO == PRO_DWCONV) {
