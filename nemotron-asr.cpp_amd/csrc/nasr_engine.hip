@@ -1569,7 +1569,7 @@ static int pipe_blind_iterations(int frames) {
 // The runtime multiplexes the streams of a process onto a few hardware queues (4 by default, GPU_MAX_HW_QUEUES): two streams on
 // one queue are ONE launch chain.  Which queue a new stream gets depends on what the process created before, so the lanes are
 // chosen by measurement: candidate streams are created until three more are found that overlap with the engine's stream and
-// with each other (two 150 us spin kernels launched back to back take 150 us on different queues, 300 us on one).  Measured
+// with each other (two 150 us spin kernels launched back to back take the time of one on different queues, of two on one).  Measured
 // (batch 1, MI355X): three encoder lanes + the decode on four queues 0.52 ms per step, the same option with two lanes landing
 // on one queue 0.73 ms -- slower than two lanes (0.63 ms).  More than 4 queues is no way out: hardware queues beyond the four
 // compute pipes are time-sliced (GPU_MAX_HW_QUEUES=8: 2 ms per step).
@@ -1577,26 +1577,32 @@ __global__ void k_spin(unsigned long long ticks) {           // 100 MHz real-tim
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
-static bool streams_overlap(hipStream_t a, hipStream_t b) {
+static double spin_us(hipStream_t a, hipStream_t b) {          // wall time of one spin kernel on a (b == nullptr) or one on each
     const unsigned long long ticks = 15000;                   // 150 us
     double best = 1e9;
     for (int rep = 0; rep < 2; rep++) {
-        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        hipStreamSynchronize(a);
+        if (b) hipStreamSynchronize(b);
         const auto t0 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
-        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
-        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        if (b) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+        hipStreamSynchronize(a);
+        if (b) hipStreamSynchronize(b);
         best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
-    return best < 240.0;                                      // side by side: ~165 us; one queue: ~315 us
+    return best;
 }
+// side by side: about the time of one spin (~165 us); one queue: two (~315 us).  The threshold is relative to what ONE spin
+// takes from this host thread right now, so a slow or busy host does not turn into "everything shares a queue".
+static bool streams_overlap(hipStream_t a, hipStream_t b, double alone_us) { return spin_us(a, b) < 1.5 * alone_us; }
 static int pick_lanes(nasr_engine *e) {
     std::vector<hipStream_t> chosen{e->st}, rejected;
+    const double alone_us = spin_us(e->st, nullptr);
     for (int tries = 0; tries < 12 && (int)chosen.size() < 4; tries++) {
         hipStream_t c = nullptr;
         HIPCHK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
         bool ok = true;
-        for (hipStream_t s : chosen) ok = ok && streams_overlap(s, c);
+        for (hipStream_t s : chosen) ok = ok && streams_overlap(s, c, alone_us);
         (ok ? chosen : rejected).push_back(c);
     }
     for (hipStream_t c : rejected) hipStreamDestroy(c);
