@@ -326,8 +326,101 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     }
 }
 
+// ---- one new row per stream (T = 1: every R = 0 batch), bf16 caches ------------------------------------------------------------
+// k_attention_mfma feeds its MFMAs with 16-byte loads in the operand layout (16 lanes = 16 different rows): at T = 1 there is
+// next to no arithmetic and the kernel is bound by its address unit (12.4 us per launch at 64 streams, the same as at T = 14).
+// Here a wave's load instruction covers 4 whole 256-byte head rows: lane = (sub-row sr, chunk c of 8 dims), key
+// j = 16 t + 4 wave + sr in pass t = 0..4; partial v_dot2 sums of a row's 16 lanes add up on the DPP path; P.V in the same
+// layout.  The arithmetic is that of the one-row prologue of k_fused_skinny<PRO_ATTN, 1> (kernels_fused.hip), operation for
+// operation: a stream gets the same context row whether it is stepped alone (fused layer) or in a batch.
+typedef __attribute__((ext_vector_type(2))) __bf16 attn_bf16x2;
+__global__ __launch_bounds__(256) void k_attention_row1(AttnParams a) {
+    __shared__ float sc[96];
+    __shared__ __attribute__((aligned(16))) float pv[16 * DH];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sr = lane >> 4, c = lane & 15;
+    constexpr int KV = LCTX + 1;
+    const float scale = 0.08838834764831845f;
+    const RowDesc rd = a.rows[b];
+    const float4 *qp = (const float4 *)(a.q + (size_t)b * D + h * DH + c * 8);
+    const float4 *up = (const float4 *)(a.bias_u + h * DH + c * 8), *vp = (const float4 *)(a.bias_v + h * DH + c * 8);
+    const float4 q0 = qp[0], q1 = qp[1], u0 = up[0], u1 = up[1], b0 = vp[0], b1 = vp[1];
+    uint4 kk[5], pp[5], vr[5];
+    int jk[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        jk[t] = t * 16 + wave * 4 + sr;
+        const int jc = jk[t] < KV ? jk[t] : 0;
+        pp[t] = *(const uint4 *)((const bf16_t *)a.posproj + (size_t)jc * D + h * DH + c * 8);      // row j + T - 1 - i = j
+    }
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int jc = jk[t] < KV ? jk[t] : 0;
+        int ring = rd.kv_head + jc;
+        if (ring >= KVC) ring -= KVC;
+        if (ring >= KVC) ring -= KVC;
+        const bf16_t *krow = (const bf16_t *)a.kv_pool + (size_t)rd.slot * a.kv_slot_stride + (size_t)ring * D + h * DH + c * 8;
+        kk[t] = *(const uint4 *)krow;
+        vr[t] = *(const uint4 *)(krow + (size_t)KVC * D);
+    }
+    auto pk2 = [](float x, float y) { return (uint32_t)f32_to_bf16(x) | ((uint32_t)f32_to_bf16(y) << 16); };
+    const uint32_t qu8[4] = {pk2(q0.x + u0.x, q0.y + u0.y), pk2(q0.z + u0.z, q0.w + u0.w), pk2(q1.x + u1.x, q1.y + u1.y), pk2(q1.z + u1.z, q1.w + u1.w)};
+    const uint32_t qv8[4] = {pk2(q0.x + b0.x, q0.y + b0.y), pk2(q0.z + b0.z, q0.w + b0.w), pk2(q1.x + b1.x, q1.y + b1.y), pk2(q1.z + b1.z, q1.w + b1.w)};
+    const int valid = rd.valid_len < LCTX ? rd.valid_len : LCTX;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const uint32_t kw[4] = {kk[t].x, kk[t].y, kk[t].z, kk[t].w}, pw[4] = {pp[t].x, pp[t].y, pp[t].z, pp[t].w};
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, qu8[e]), __builtin_bit_cast(attn_bf16x2, kw[e]), s1, false);
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, qv8[e]), __builtin_bit_cast(attn_bf16x2, pw[e]), s1, false);
+        }
+        s1 += dpp_mov<0xB1>(s1);
+        s1 += dpp_mov<0x4E>(s1);
+        s1 += dpp_mov<0x141>(s1);
+        s1 += dpp_mov<0x140>(s1);
+        if (c == 0 && jk[t] < KV) {
+            float v = s1 * scale;
+            if (jk[t] < LCTX - valid) v += -1e9f;
+            sc[jk[t]] = v;
+        }
+    }
+    __syncthreads();
+    const float v0 = lane < KV ? sc[lane] : -INFINITY, v1 = lane + 64 < KV ? sc[lane + 64] : -INFINITY;
+    const float mx = wave_max(fmaxf(v0, v1));
+    const float inv = 1.0f / wave_sum((lane < KV ? __expf(v0 - mx) : 0.0f) + (lane + 64 < KV ? __expf(v1 - mx) : 0.0f));
+    float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const float w = jk[t] < KV ? __expf(sc[jk[t]] - mx) * inv : 0.0f;
+        const uint32_t vw[4] = {vr[t].x, vr[t].y, vr[t].z, vr[t].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            acc8[2 * e] += w * __uint_as_float(vw[e] << 16);
+            acc8[2 * e + 1] += w * __uint_as_float(vw[e] & 0xffff0000u);
+        }
+    }
+    *(float4 *)(pv + (wave * 4 + sr) * DH + c * 8) = make_float4(acc8[0], acc8[1], acc8[2], acc8[3]);
+    *(float4 *)(pv + (wave * 4 + sr) * DH + c * 8 + 4) = make_float4(acc8[4], acc8[5], acc8[6], acc8[7]);
+    __syncthreads();
+    if ((int)threadIdx.x < DH) {
+        const int d = threadIdx.x;
+        float o = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < 16; gI++) o += pv[gI * DH + d];
+        ((bf16_t *)a.ctx_out)[(size_t)b * D + h * DH + d] = f32_to_bf16(o);
+    }
+}
+
 void launch_attention(const AttnParams &p, hipStream_t st) {
     const int TS = p.TS > 0 ? p.TS : p.T;
+    static const bool row1 = !(getenv("NASR_ATTN_ROW1") && atoi(getenv("NASR_ATTN_ROW1")) == 0);
+    if (row1 && p.act_bf16 && p.T == 1 && TS == 1) {
+        hipLaunchKernelGGL(k_attention_row1, dim3(NH, p.B), dim3(256), 0, st, p);
+        return;
+    }
     if (p.act_bf16 && p.T <= 16) {
         const int QB = p.T <= 2 ? 16 : p.T;
         hipLaunchKernelGGL(k_attention_mfma, dim3(NH, p.B, (TS + QB - 1) / QB), dim3(256), 0, st, p);
