@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 vv[u] = *(const uint2 *)(vbase + (size_t)ring * D);
             }
         };
-        if (MMAX == 1) {
-            // One row (T = 1, KV = 71).  The scattered form below (a thread pair per key, 128 contiguous bytes per thread as eight
+        if (MMAX == 1 || (T == 1 && TS == 1)) {
+            // One new row per stream (T = 1 and one chunk per stream, KV = 71; two streams: one after the other).  The scattered form below (a thread pair per key, 128 contiguous bytes per thread as eight
             // 16-byte loads) keeps the CU's address unit busy for 2.5 us before the last of its 35 load instructions per wave has
             // even been issued (stamps: "all loads issued" at 2.57 us; each instruction touches 64 different 64-byte segments).
             // Here a load instruction of a wave covers 4 whole head rows (256 contiguous bytes each): lane = (sub-row sr, chunk
@@ -342,9 +342,11 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
             // bf16 q + bias, as before), the 16 lanes of a row add up on the DPP path, and P.V runs in the same layout (each lane
             // accumulates its 8 dims over its 5 keys).  No q staging through LDS, no softmax barrier: every wave computes the
             // statistics of the 71 scores itself.
-            const RowDesc rd = rds[0];
             const int sr = lane >> 4, c = lane & 15;
-            const float4 *qp = (const float4 *)(a.q + h * DH + c * 8);
+            for (int m = 0; m < M; m++) {
+            const RowDesc rd = m == 0 ? rds[0] : rds[1];
+            float *scm = sc + m * KVC;
+            const float4 *qp = (const float4 *)(a.q + (size_t)m * D + h * DH + c * 8);
             const float4 *up = (const float4 *)(a.bias_u + h * DH + c * 8), *vp = (const float4 *)(a.bias_v + h * DH + c * 8);
             const float4 q0 = qp[0], q1 = qp[1], u0 = up[0], u1 = up[1], b0 = vp[0], b1 = vp[1];
             uint4 kk[5], pp[5], vr[5];
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 const int jc = jk[t] < KV ? jk[t] : 0;
                 pp[t] = *(const uint4 *)((const bf16_t *)a.posproj + (size_t)(jc + T - 1) * D + h * DH + c * 8);
             }
-            issue_weights();
+            if (m == 0) issue_weights();
 #pragma unroll
             for (int t = 0; t < 5; t++) {
                 const int jc = jk[t] < KV ? jk[t] : 0;
@@ -387,18 +389,18 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 if (c == 0 && jk[t] < KV) {
                     float v = s1 * scale;
                     if (jk[t] < LCTX - valid) v += -1e9f;
-                    sc[jk[t]] = v;
+                    scm[jk[t]] = v;
                 }
             }
             STAMP(3);
             __syncthreads();
-            const float v0 = lane < KV ? sc[lane] : -INFINITY, v1 = lane + 64 < KV ? sc[lane + 64] : -INFINITY;
+            const float v0 = lane < KV ? scm[lane] : -INFINITY, v1 = lane + 64 < KV ? scm[lane + 64] : -INFINITY;
             const float mx = wmax_f(fmaxf(v0, v1));
             const float inv = 1.0f / wsum_f((lane < KV ? __expf(v0 - mx) : 0.0f) + (lane + 64 < KV ? __expf(v1 - mx) : 0.0f));
             float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 5; t++) {
-                const float w = jk[t] < KV ? __expf(sc[jk[t]] - mx) * inv : 0.0f;
+                const float w = jk[t] < KV ? __expf(scm[jk[t]] - mx) * inv : 0.0f;
                 const uint32_t vw[4] = {vr[t].x, vr[t].y, vr[t].z, vr[t].w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -416,7 +418,9 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
                 float o = 0.f;
 #pragma unroll
                 for (int gI = 0; gI < 16; gI++) o += pv[gI * DH + d];
-                *(bf16_t *)(panel + ((((d >> 3) ^ 0) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
+                *(bf16_t *)(panel + m * KP * 2 + ((((d >> 3) ^ (m & 15)) << 4) | ((d & 7) << 1))) = f32_to_bf16(o);
+            }
+            if (m + 1 < M) __syncthreads();                              // the next row reuses the P.V scratch
             }
         } else {
         // (a) + (b) for pass 0 / row 0
