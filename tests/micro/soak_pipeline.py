@@ -1,0 +1,86 @@
+"""soak test (GPU): a pipelined engine (option pipeline = 3) against a synchronous one over thousands of calls with random push
+sizes (partial chunks, several chunks at once, ragged groups), random subsets of the streams per call, resets, finalize / collect
+in between -- token streams must be identical.  The parity suite covers each of these once; this looks for the rare ordering bug.
+usage: python tests/micro/soak_pipeline.py [calls] [seed]"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import __graft_entry__ as ge  # noqa: E402
+
+ge.load_package()
+from nemotron_asr_amd import capi, synth  # noqa: E402
+
+
+def main():
+    calls = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    n_layers, B = 4, 5
+    W = synth.make_weights(n_layers=n_layers)
+    engs = []
+    for mode in (0, 3):
+        e = capi.Engine(W, n_layers=n_layers, dtype=capi.DTYPE_BF16, max_streams=B)
+        e.set_option("pipeline", mode)
+        engs.append(e)
+    Rs = [0, 0, 0, 1, 13]
+    streams = [[e.stream(R) for R in Rs] for e in engs]
+    pcm = [synth.make_pcm(500 + b, 900.0) for b in range(B)]
+    pos = [0] * B
+    toks = [[[] for _ in range(B)] for _ in engs]
+    n_tok = 0
+    for c in range(calls):
+        # a group = streams of one right context (the engine batches equal T only)
+        R = int(rng.choice(sorted(set(Rs))))
+        group = [b for b in range(B) if Rs[b] == R and rng.random() < 0.8]
+        if not group:
+            continue
+        piece = synth.shift_samples(R)
+        mode = rng.random()
+        if mode < 0.7:
+            n = [piece] * len(group)                                  # the steady-state shape: one chunk each (graph replay)
+        elif mode < 0.85:
+            n = [int(rng.integers(1, 3 * piece)) for _ in group]      # ragged
+        else:
+            k = int(rng.integers(2, 5))
+            n = [k * piece] * len(group)                              # several chunks per push
+        chunks = []
+        for b, nb in zip(group, n):
+            if pos[b] + nb > pcm[b].size:
+                pos[b] = 0
+            chunks.append(pcm[b][pos[b]:pos[b] + nb])
+            pos[b] += nb
+        for ei, e in enumerate(engs):
+            out = e.step([streams[ei][b] for b in group], chunks)
+            for b, o in zip(group, out):
+                toks[ei][b] += o
+        r = rng.random()
+        if r < 0.01:                                                  # finalize one stream, then reset it
+            b = int(rng.integers(0, B))
+            for ei, e in enumerate(engs):
+                toks[ei][b] += e.finalize([streams[ei][b]])[0]
+                streams[ei][b].reset()
+        elif r < 0.03:                                                # drain the pipeline
+            for ei, e in enumerate(engs):
+                for Rg in sorted(set(Rs)):                            # one call per right context
+                    idx = [b for b in range(B) if Rs[b] == Rg]
+                    for b, o in zip(idx, e.collect([streams[ei][b] for b in idx])):
+                        toks[ei][b] += o
+        if c % 500 == 499:
+            print(f"call {c + 1}: tokens so far {sum(len(t) for t in toks[0])}", flush=True)
+    for ei, e in enumerate(engs):
+        for Rg in sorted(set(Rs)):
+            idx = [b for b in range(B) if Rs[b] == Rg]
+            for b, o in zip(idx, e.finalize([streams[ei][b] for b in idx])):
+                toks[ei][b] += o
+    for b in range(B):
+        assert toks[0][b] == toks[1][b], f"stream {b}: pipelined tokens differ from synchronous ones at index " \
+            f"{next((i for i, (x, y) in enumerate(zip(toks[0][b], toks[1][b])) if x != y), min(len(toks[0][b]), len(toks[1][b])))}"
+        n_tok += len(toks[0][b])
+    print(f"OK: {calls} calls, {n_tok} tokens, pipelined == synchronous on all {B} streams")
+
+
+if __name__ == "__main__":
+    main()

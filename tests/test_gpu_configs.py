@@ -345,3 +345,16 @@ def test_progress_does_not_drain_the_pipeline(W2):
     ref += ost.finalize()
     assert sync + tail == ref and n_before <= len(ref)
     eng.close()
+
+
+def test_pipelined_engine_soak():
+    """tests/micro/soak_pipeline.py, short form: 800 calls with random push sizes (partial chunks, several chunks, ragged groups),
+    random subsets of five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine (three lanes)
+    emits exactly the tokens of a synchronous one."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "soak_pipeline.py"), "800", "11"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "pipelined == synchronous" in r.stdout
