@@ -358,3 +358,33 @@ def test_pipelined_engine_soak():
     r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "soak_pipeline.py"), "800", "11"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "pipelined == synchronous" in r.stdout
+
+
+def test_lanes_option_gives_queues_back_and_keeps_results(W2):
+    """Engine option "lanes": the engine keeps fewer encoder lanes (before or after it has picked them) -- fewer pieces in flight,
+    identical tokens."""
+    R, piece = 0, synth.shift_samples(0)
+    pcm = synth.make_pcm(77, 6.0)
+    res = []
+    for lanes_before, lanes_after in ((None, None), (2, None), (None, 1)):
+        eng = capi.Engine(W2, n_layers=2, dtype=capi.DTYPE_BF16, max_streams=1)
+        if lanes_before:
+            eng.set_option("lanes", lanes_before)
+        eng.set_option("pipeline", 3 if lanes_before or lanes_after else 0)
+        st = eng.stream(R)
+        toks = []
+        for k in range(pcm.size // piece):
+            toks += eng.step([st], [pcm[k * piece:(k + 1) * piece]])[0]
+            if lanes_after and k == 20:
+                eng.set_option("lanes", lanes_after)          # drains the pipeline, destroys the lanes beyond the first
+        toks += eng.finalize([st])[0]
+        res.append(toks)
+        st.destroy()
+        eng.close()
+    assert len(res[0]) > 0 and res[0] == res[1] == res[2]
+    with pytest.raises(capi.NasrError):
+        e = capi.Engine(W2, n_layers=2, dtype=capi.DTYPE_BF16, max_streams=1)
+        try:
+            e.set_option("lanes", 0)
+        finally:
+            e.close()
