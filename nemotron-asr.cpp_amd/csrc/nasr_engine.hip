@@ -929,8 +929,9 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
     // against 1.23 / 1.30 with 2; 24 streams = 48 tiles 1.53 vs 1.50; 32 streams = 64 tiles 1.82 vs 1.68; 64 streams = 112 tiles:
     // 2 splits 2.76, 1 split 2.75, 4 splits 3.03)
     if (!skinny) return tasks <= 40 ? 4 : (tasks < 256 ? 2 : 1);
+    static const int skinny_cap = getenv("NASR_SKINNY_SPLITS_MAX") ? atoi(getenv("NASR_SKINNY_SPLITS_MAX")) : 8;      // experiment knob
     int s = 1;
-    while (s < 8 && tasks * s < 256 && (K / 32) / (s * 2) >= 4) s *= 2;
+    while (s < skinny_cap && tasks * s < 256 && (K / 32) / (s * 2) >= 4) s *= 2;
     return s;
 }
 
