@@ -191,8 +191,9 @@ enum {
  * of step s + 1.  The same tokens come out, E calls later: nasr_engine_step returns what has been decoded so far;
  * nasr_engine_finalize, nasr_engine_collect and every other entry point first complete the steps in flight.  Results are
  * bit-identical to synchronous stepping.  The engine runs at most as many pieces as it finds HIP streams that truly run side
- * by side (it measures which streams share a hardware queue at the first pipelined step: normally 3 lanes + a decode stream,
- * so E = 4 runs as 3; fewer when the process leaves it fewer queues).  Throughput option for callers that push back to back
+ * by side (it measures which streams share a hardware queue at the first pipelined step: normally 4).  The decode graphs run on
+ * the last of these streams: a queue of their own up to E = 3, right behind the fourth piece at E = 4 (worth 1-5 % at 16-64
+ * streams, nothing at one stream); fewer pieces when the process leaves the engine fewer queues.  Throughput option for callers that push back to back
  * (a server draining a backlog, a file); a live stream keeps the default.
  * "lanes" (1..4): keep at most this many encoder lanes and give the other lanes' streams back -- for a process with another GPU
  * client (the diarization side-car): a stream created after this call gets a hardware queue the engine no longer uses.  Not

@@ -148,11 +148,11 @@ struct nasr_engine {
     struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; };
     WS ws[NSLOT];                    // ws[0] = the set the synchronous paths use (mirrored in x, x2, ... below)
     int opt_pipeline = 0;            // 0: synchronous steps; E >= 1: the encoder in E pieces + the decode, each piece one step behind the previous
-    hipStream_t st2 = nullptr;       // decode graphs
     hipStream_t lane[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};   // lane[k]: encoder piece k (lane[0] = st)
-    int n_lanes = 1;                 // lanes that run side by side (each on a hardware queue of its own): the number of pieces is capped by it
+    int n_lanes = 1;                 // streams that run side by side (lane[0 .. n_lanes - 1], each on a hardware queue of its own): a step has at
+                                     // most that many encoder pieces; its decode graph runs on the LAST of these streams -- a queue of its own while
+                                     // the step has fewer pieces than there are streams, else right behind the last piece on that piece's lane
     int max_lanes = MAXSEG;          // option "lanes": the engine keeps at most this many (the others' hardware queues are left to other clients of the process)
-    bool dec_on_last_lane = false;   // no hardware queue left for the decode graphs: they run on the last piece's lane, right behind that piece
     struct Pipe {
         bool ready = false;                               // buffers of this slot allocated
         char *g_desc = nullptr, *gh = nullptr;            // descriptor block of the encoder graphs (device / pinned)
@@ -752,7 +752,6 @@ static void engine_destroy_impl(nasr_engine *e) {
     for (auto *s : e->slots) delete s;
     for (void *p : e->allocs) hipFree(p);
     for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
-    if (e->st2) hipStreamSynchronize(e->st2);
     for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamSynchronize(e->lane[k]);
     for (int p = 0; p < nasr_engine::NSLOT; p++) {
         nasr_engine::Pipe &P = e->pipe[p];
@@ -763,7 +762,6 @@ static void engine_destroy_impl(nasr_engine *e) {
         for (auto ev : P.seg_done) if (ev) hipEventDestroy(ev);
         if (P.dec_done) hipEventDestroy(P.dec_done);
     }
-    if (e->st2) hipStreamDestroy(e->st2);
     for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamDestroy(e->lane[k]);
     if (e->gh) hipHostFree(e->gh);
     if (e->pin) hipHostFree(e->pin);
@@ -1607,28 +1605,22 @@ static int pick_lanes(nasr_engine *e) {
         (ok ? chosen : rejected).push_back(c);
     }
     for (hipStream_t c : rejected) hipStreamDestroy(c);
-    // 4 queues: lanes 0..2 + the decode stream; 3: lanes 0..2, decode behind the last piece; 2: two lanes, decode behind the
-    // second; 1 (GPU_MAX_HW_QUEUES=1): everything on the engine's stream
-    const int n = (int)chosen.size();
+    // 4 queues: up to 3 pieces + the decode graphs on the fourth, or 4 pieces with the decode behind the last one; 3 queues: 2 + decode
+    // or 3 with the decode behind; ... 1 (GPU_MAX_HW_QUEUES=1): everything on the engine's stream
+    if (getenv("NASR_DEC_LANE") && chosen.size() > 1) { hipStreamDestroy(chosen.back()); chosen.pop_back(); }   // experiment knob: one queue fewer
+    e->n_lanes = std::max(1, std::min((int)chosen.size(), (int)nasr_engine::MAXSEG));
     e->lane[0] = e->st;
-    e->n_lanes = std::max(1, std::min(n == 4 ? 3 : n, (int)nasr_engine::MAXSEG));
     for (int k = 1; k < e->n_lanes; k++) e->lane[k] = chosen[(size_t)k];
-    if (n == 4) e->st2 = chosen[3];
-    else e->dec_on_last_lane = true;
-    if (getenv("NASR_DEC_LANE") && e->st2) {       // experiment knob: no decode stream; "4" = its queue becomes a fourth lane
-        if (atoi(getenv("NASR_DEC_LANE")) == 4) { e->lane[3] = e->st2; e->n_lanes = 4; }
-        else hipStreamDestroy(e->st2);
-        e->st2 = nullptr; e->dec_on_last_lane = true;
-    }
-    if (getenv("NASR_STATS")) fprintf(stderr, "nasr: pipelined steps: %d lane(s) side by side, decode %s\n", e->n_lanes, e->dec_on_last_lane ? "behind the last piece" : "on its own queue");
+    if (getenv("NASR_STATS")) fprintf(stderr, "nasr: pipelined steps: %d stream(s) side by side (encoder pieces + decode)\n", e->n_lanes);
     return 0;
 }
 
 static void release_lanes(nasr_engine *e) {
     if (!e->pipe_ready) return;                                // applied when the lanes are picked
-    for (int k = std::max(1, e->max_lanes); k < nasr_engine::MAXSEG; k++)
+    const int keep = std::min((int)nasr_engine::MAXSEG, std::max(1, e->max_lanes) + 1);      // max_lanes pieces + the decode stream
+    for (int k = keep; k < nasr_engine::MAXSEG; k++)
         if (e->lane[k]) { hipStreamSynchronize(e->lane[k]); hipStreamDestroy(e->lane[k]); e->lane[k] = nullptr; }
-    e->n_lanes = std::min(e->n_lanes, std::max(1, e->max_lanes));
+    e->n_lanes = std::min(e->n_lanes, keep);
 }
 
 // streams, events and the buffers of slot p (allocated when first used: E + 1 slots for E encoder pieces)
@@ -1699,7 +1691,7 @@ static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, 
             })) return -1;
     }
     // decode graph on the decode stream
-    hipStream_t cs = e->st2 ? e->st2 : e->lane[nseg - 1];       // where the decode graph is captured (it is replayed on dec_stream())
+    hipStream_t cs = e->lane[e->n_lanes - 1];       // where the decode graph is captured (it is replayed on dec_stream())
     if (capture(cs, "decode", dec_out, [&]() -> int {
             HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, cs));
             DecParams dp;
@@ -1738,7 +1730,8 @@ static int pipe_advance(nasr_engine *e, int p) {
 // finishes the decode eagerly if the graph's iteration budget fell short, queues the tokens.
 // the decode graph runs on the decode stream, or -- when no hardware queue is left for one -- on the lane of the last encoder
 // piece, stream-ordered behind it
-static hipStream_t dec_stream(nasr_engine *e, const nasr_engine::Pipe &P) { return e->dec_on_last_lane ? e->lane[P.nseg - 1] : e->st2; }
+static bool dec_behind_last_piece(const nasr_engine *e, const nasr_engine::Pipe &P) { return P.nseg >= e->n_lanes; }
+static hipStream_t dec_stream(nasr_engine *e, const nasr_engine::Pipe &P) { return e->lane[e->n_lanes - 1]; }
 
 static int pipe_finish_launch(nasr_engine *e, int p) {
     nasr_engine::Pipe &P = e->pipe[p];
@@ -1746,7 +1739,7 @@ static int pipe_finish_launch(nasr_engine *e, int p) {
     while (P.stage < P.nseg)
         if (pipe_advance(e, p)) return -1;
     const int B = (int)P.streams.size();
-    if (!e->dec_on_last_lane) { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[P.nseg - 1])); }
+    if (!dec_behind_last_piece(e, P)) { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[P.nseg - 1])); }
     for (int b = 0; b < B; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[B + b] = P.streams[b]->tok_read; }
     { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], dec_stream(e, P))); }
     HIPCHK(hipEventRecord(P.dec_done, dec_stream(e, P)));
@@ -1802,7 +1795,7 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
     if (ensure_pipe(e, (int)(e->pipe_seq % nasr_engine::NSLOT))) return -1;     // also picks the lanes
-    const int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
+    const int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, e->max_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
     const int64_t seq = e->pipe_seq;
     const int p = (int)(seq % nasr_engine::NSLOT);
     if (ensure_pipe(e, p)) return -1;
@@ -1870,9 +1863,8 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
         if (Q.stage != 0 && Q.seq == seq - k && Q.stage >= Q.nseg) fin[nfin++] = q;
     }
     // decode on the last piece's lane: queue it there before the next step's last piece goes onto that lane
-    if (e->dec_on_last_lane)
-        for (int i = 0; i < nfin; i++)
-            if (pipe_finish_launch(e, fin[i])) return -1;
+    for (int i = 0; i < nfin; i++)
+        if (dec_behind_last_piece(e, e->pipe[fin[i]]) && pipe_finish_launch(e, fin[i])) return -1;
     for (int k = 1; k <= nasr_engine::MAXSEG && k <= seq; k++) {
         const int q = (int)((seq - k) % nasr_engine::NSLOT);
         nasr_engine::Pipe &Q = e->pipe[q];

@@ -643,12 +643,12 @@ print("TOKENS", sum(len(t) for t in res[1]))
     n_fallback = int(stats[1].split("decode fallbacks")[1].split()[0])        # second engine = pipelined
     assert int(stats[2].split("decode fallbacks")[1].split()[0]) > 0           # third = skewed encoder halves too
     assert "pipelined" in stats[1] and n_fallback > 0, stats
-    lanes = [ln for ln in r.stderr.splitlines() if "lane(s) side by side" in ln]
-    assert len(lanes) == 2, r.stderr[-1500:]                                     # the two pipelined engines picked their lanes
-    n_lanes = int(lanes[-1].split("pipelined steps:")[1].split()[0])
+    lanes = [ln for ln in r.stderr.splitlines() if "stream(s) side by side" in ln]
+    assert len(lanes) == 2, r.stderr[-1500:]                                     # the two pipelined engines picked their streams
+    n_streams = int(lanes[-1].split("pipelined steps:")[1].split()[0])           # encoder lanes + the decode stream
     if hw_queues:
-        assert n_lanes <= int(hw_queues) and "behind the last piece" in lanes[-1], lanes
+        assert n_streams <= int(hw_queues), lanes                                # the decode then runs behind the last piece
     elif dec_lane:
-        assert "behind the last piece" in lanes[-1], lanes
+        assert 1 <= n_streams <= 3, lanes                                        # one queue fewer than the runtime offers
     else:
-        assert n_lanes >= 2, lanes
+        assert n_streams >= 3, lanes
