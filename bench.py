@@ -73,10 +73,10 @@ def parse(argv=None):
     ap.add_argument("--sync-steps", action="store_true",
                     help="every step returns its own tokens before the next one starts (engine option pipeline = 0); default: "
                          "pipelined steps, the decode graph of step s runs on a second HIP stream beside the encoder graph of step s + 1")
-    ap.add_argument("--pipeline-depth", type=int, default=3, choices=[1, 2, 3, 4],
+    ap.add_argument("--pipeline-depth", type=int, default=4, choices=[1, 2, 3, 4],
                     help="engine option pipeline = E: the encoder in E pieces of L / E layers, piece k of step s beside piece k + 1 of step "
                          "s - 1 ..., the decode of step s - E beside them (1: only the decode beside the next encoder; the engine runs at most as many "
-                         "pieces as it finds HIP streams that truly overlap: 3 with the runtime's 4 hardware queues)")
+                         "pieces as it finds HIP streams that truly overlap: 4 with the runtime's 4 hardware queues, the decode graphs then run behind the fourth piece)")
     ap.add_argument("--regions", type=int, default=REPEATS, help="timed regions of K steps (the median is reported)")
     ap.add_argument("--no-host-pcm", action="store_true", help="skip the host-PCM (H2D inside the timed region) figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,7 +156,7 @@ _SYMBOL = {"k_fused_ln_gemm": ("k_fused_skinny<0,",), "k_fused_plain_gemm": ("k_
 class Run:
     """one engine + B streams + their PCM in HBM, stepped through the C ABI"""
 
-    def __init__(self, capi, synth, engW, layers, dtype, B, R, device, stream_ids, chunks_per_step=1, pipeline=3, audio_s=60.0):
+    def __init__(self, capi, synth, engW, layers, dtype, B, R, device, stream_ids, chunks_per_step=1, pipeline=4, audio_s=60.0):
         self.capi, self.synth = capi, synth
         self.B, self.R, self.T = B, R, 1 + R
         self.n_step = synth.shift_samples(R) * chunks_per_step
@@ -635,8 +635,9 @@ def main():
                 "pcm": "device-resident", "tokens_emitted": tokens_timed, "chunks": chunks_timed,
                 "steps": "synchronous" if args.sync_steps else
                          ("pipelined, E = 1: decode graph of step s on a second HIP stream beside the encoder graph of step s+1" if args.pipeline_depth == 1 else
-                          f"pipelined, E = {args.pipeline_depth}: the encoder in {args.pipeline_depth} pieces of L/{args.pipeline_depth} layers; piece k of step s-k and the "
-                          f"decode of step s-{args.pipeline_depth} run side by side on {args.pipeline_depth + 1} HIP streams (same kernels, same per-stream order, "
+                          f"pipelined, E = {args.pipeline_depth}: the encoder in {args.pipeline_depth} pieces of consecutive layers; piece k of step s-k and the "
+                          f"decode of step s-{args.pipeline_depth} run side by side on {min(args.pipeline_depth + 1, 4)} HIP streams that the engine measured to be on different hardware queues"
+                          f"{' (the decode graphs behind the fourth piece on its stream)' if args.pipeline_depth == 4 else ''} (same kernels, same per-stream order, "
                           f"bit-identical results; tokens {args.pipeline_depth} calls later)"),
             },
             "host_pcm": host_pcm,

@@ -1092,6 +1092,9 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
             if (q && atoi(q) > 0 && atoi(q) < nLayers) return atoi(q);
         }
         if (nseg == 3 && nLayers >= 6) return k == 1 ? nLayers * 7 / 24 : nLayers * 16 / 24;
+        // four pieces: 6 + 7 + 7 + 4 -- the last lane also runs the decode graphs (64 streams x 80 ms: 0.92 ms per step; 6 + 6 + 7 + 5
+        // 0.95, 6 + 6 + 6 + 6 1.02, 7 + 6 + 6 + 5 1.00, 6 + 7 + 8 + 3 1.00; 64 x 1.12 s 2.67 / 2.68 / - / 2.77 / 2.72)
+        if (nseg == 4 && nLayers >= 8) return k == 1 ? nLayers * 6 / 24 : k == 2 ? nLayers * 13 / 24 : nLayers * 20 / 24;
         return std::max(1, nLayers * k / nseg - shift);
     };
     const int l0 = bound(seg), l1 = bound(seg + 1);
@@ -1156,6 +1159,9 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
                 if (q && atoi(q) > 0 && atoi(q) < 8 * nLayers) return atoi(q);
             }
             if (nseg == 3 && nLayers >= 6 && !bounds_env) return (k == 1 ? 57 : 126) * nLayers / 24;
+            // four pieces: 48 + 56 + 60 + 28 launches (batch 1: 0.426 ms per step; 48 + 56 + 56 + 32 0.437, 50 + 56 + 56 + 30 0.433,
+            // 48 + 54 + 62 + 28 0.434, 48 + 56 + 64 + 24 0.440; three lanes 0.454)
+            if (nseg == 4 && nLayers >= 8 && !bounds_env) return (k == 1 ? 48 : k == 2 ? 104 : 164) * nLayers / 24;
             return 8 * bound(k);
         };
         if (run_layers_fused(e, rows, B, T, G, bound8(seg), bound8(seg + 1))) return -1;
