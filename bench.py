@@ -461,14 +461,15 @@ def main():
     # ---- diarization side-car beside the headline workload (only on request; configs[4] is measured below) --------------
     def diarization_entry(r, n_ov):
         # three encoder lanes + the decode stream occupy all four hardware queues of the runtime: the side-car's stream would
-        # share one of them (measured: 8.1 ms per step against 7.1 ms with two lanes).  The ASR engine gives one lane back BEFORE
-        # the side-car's stream is created (a new stream gets the least-used queue) and runs two lanes here.
+        # share one of them (measured: 8.1 ms per step against 7.1 ms with two lanes).  The ASR engine lends its fourth stream --
+        # a hardware queue of its own -- to the side-car and runs two lanes + the decode stream here.
         side_depth = 0 if args.sync_steps else min(args.pipeline_depth, 2)
         r.drain()
-        r.eng.set_option("lanes", 2)
-        r.eng.set_option("pipeline", side_depth)
         dW = synth.make_diar_weights()
         deng = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * r.B), device=local_rank)
+        if side_depth:
+            deng.set_stream(r.eng.lend_stream())       # the fourth stream's hardware queue goes to the side-car
+        r.eng.set_option("pipeline", side_depth)
         hist = 10080 - 160                                   # samples of history a new 10 ms hop needs
         # the side-car reads the SAME s16 PCM the ASR streams were fed, already resident in HBM
         vad_ptrs = [r.pcm_dev[b] for b in range(r.B)]

@@ -210,6 +210,10 @@ int nasr_engine_profile(nasr_engine *e, int enable); /* enable also resets the c
 int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, int cap); /* returns count */
 /* raw hipStream_t of the engine (for external event timing) */
 void *nasr_engine_hip_stream(nasr_engine *e);
+/* Hands the last of the engine's side-by-side HIP streams -- and with it a hardware queue that no encoder lane will use -- to
+ * another GPU client of the process (nasr_diar_set_stream).  The engine runs one encoder piece fewer at most, still owns the
+ * stream and destroys it in nasr_engine_destroy: the borrower must be destroyed first.  *out receives a hipStream_t. */
+int nasr_engine_lend_stream(nasr_engine *e, void **out);
 /* device malloc/free/copy helpers so a host written without HIP can keep PCM resident */
 int nasr_device_alloc(nasr_engine *e, void **out, int64_t bytes);
 int nasr_device_free(nasr_engine *e, void *p);
@@ -228,6 +232,8 @@ typedef struct nasr_diar nasr_diar;
 int  nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
                       int max_windows, int max_segments);
 void nasr_diar_destroy(nasr_diar *d);
+/* the side-car's work goes onto a stream the caller owns (hipStream_t, e.g. from nasr_engine_lend_stream) until nasr_diar_destroy */
+int  nasr_diar_set_stream(nasr_diar *d, void *hip_stream);
 /* vad_session_run_batch (src/diarize_vad.cpp:490-503) for B buffers in one launch sequence: P(speech) of every 0.63 s
  * window (10 080 samples) of audio[b] at a 10 ms shift (the reference runs each window as its own graph,
  * src/diarize_pipeline.cpp:204-211).  audio: float samples in [-1, 1], or s16 PCM cast to the pointer type with

@@ -25,9 +25,9 @@ EXPORTS = [
     "nasr_stream_create", "nasr_stream_reset", "nasr_stream_reset_ex", "nasr_stream_destroy", "nasr_stream_set_prompt",
     "nasr_stream_get_stats", "nasr_stream_get_progress", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
-    "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_device_alloc", "nasr_device_free",
+    "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_engine_lend_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize",
-    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel",
+    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_set_stream", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
         L.nasr_engine_profile_read.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
         L.nasr_engine_hip_stream.argtypes = [vp]
         L.nasr_engine_hip_stream.restype = vp
+        L.nasr_engine_lend_stream.argtypes = [vp, C.POINTER(vp)]
+        L.nasr_diar_set_stream.argtypes = [vp, vp]
         L.nasr_device_alloc.argtypes = [vp, C.POINTER(vp), C.c_int64]
         L.nasr_device_free.argtypes = [vp, vp]
         L.nasr_device_upload.argtypes = [vp, vp, vp, C.c_int64]
@@ -224,6 +226,10 @@ class Diar:
     def __del__(self):
         self.close()
 
+    def set_stream(self, hip_stream):
+        """run on a stream the caller owns (Engine.lend_stream): a hardware queue no ASR lane uses"""
+        _chk(lib().nasr_diar_set_stream(self.h, C.c_void_p(hip_stream)))
+
     def vad(self, audios: list) -> list:
         """P(speech) of every 0.63 s window (10 ms shift) of each buffer (float32 in [-1, 1], or int16 PCM) -> float32 arrays"""
         B = len(audios)
@@ -303,6 +309,12 @@ class Engine:
 
     def __del__(self):
         self.close()
+
+    def lend_stream(self) -> int:
+        """the last of the engine's side-by-side HIP streams for another GPU client (Diar.set_stream); close that client first"""
+        out = C.c_void_p()
+        _chk(lib().nasr_engine_lend_stream(self.h, C.byref(out)))
+        return out.value
 
     def stream(self, right_context=0, prompt_index=-1) -> Stream:
         return Stream(self, right_context, prompt_index)

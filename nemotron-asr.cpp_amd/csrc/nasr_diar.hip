@@ -46,6 +46,7 @@ const Topo VAD_TOPO[6] = {{11, 1, 1, 80, 128, false, true, false}, {13, 1, 2, 12
 struct nasr_diar {
     int device = 0;
     hipStream_t st = nullptr;
+    bool st_borrowed = false;        // nasr_diar_set_stream: the stream belongs to somebody else
     std::vector<void *> allocs;
     std::map<std::string, std::vector<float>> host;     // tensors by name (only during create)
     bool has_vad = false, has_spk = false;
@@ -258,7 +259,7 @@ static void diar_destroy_impl(nasr_diar *d) {
     if (d->prob) hipFree(d->prob);
     if (d->pin) hipHostFree(d->pin);
     if (d->pin_audio) hipHostFree(d->pin_audio);
-    if (d->st) hipStreamDestroy(d->st);
+    if (d->st && !d->st_borrowed) hipStreamDestroy(d->st);
     delete d;
 }
 
@@ -266,6 +267,21 @@ extern "C" void nasr_diar_destroy(nasr_diar *d) {
     if (!d) return;
     Guard g;
     diar_destroy_impl(d);
+}
+
+// run the side-car on a stream (hipStream_t) the caller owns -- e.g. one the ASR engine has lent (nasr_engine_lend_stream), so that
+// the side-car sits on a hardware queue that no encoder lane uses.  The caller keeps the stream alive until nasr_diar_destroy.
+extern "C" int nasr_diar_set_stream(nasr_diar *d, void *hip_stream) {
+    if (!d || !hip_stream) return failf("null argument");
+    Guard g;
+    hipSetDevice(d->device);
+    if (d->st) {
+        hipStreamSynchronize(d->st);
+        if (!d->st_borrowed) hipStreamDestroy(d->st);
+    }
+    d->st = (hipStream_t)hip_stream;
+    d->st_borrowed = true;
+    return 0;
 }
 
 extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,

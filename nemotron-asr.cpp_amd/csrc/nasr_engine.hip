@@ -152,6 +152,7 @@ struct nasr_engine {
     int n_lanes = 1;                 // streams that run side by side (lane[0 .. n_lanes - 1], each on a hardware queue of its own): a step has at
                                      // most that many encoder pieces; its decode graph runs on the LAST of these streams -- a queue of its own while
                                      // the step has fewer pieces than there are streams, else right behind the last piece on that piece's lane
+    std::vector<hipStream_t> lent;   // streams handed to another client (nasr_engine_lend_stream): still owned, destroyed with the engine
     int max_lanes = MAXSEG;          // option "lanes": the engine keeps at most this many (the others' hardware queues are left to other clients of the process)
     struct Pipe {
         bool ready = false;                               // buffers of this slot allocated
@@ -763,6 +764,7 @@ static void engine_destroy_impl(nasr_engine *e) {
         if (P.dec_done) hipEventDestroy(P.dec_done);
     }
     for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamDestroy(e->lane[k]);
+    for (hipStream_t ls : e->lent) { hipStreamSynchronize(ls); hipStreamDestroy(ls); }
     if (e->gh) hipHostFree(e->gh);
     if (e->pin) hipHostFree(e->pin);
     if (e->ddesc) hipFree(e->ddesc);
@@ -2383,6 +2385,27 @@ extern "C" int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, i
 }
 
 extern "C" void *nasr_engine_hip_stream(nasr_engine *e) { return e ? (void *)e->st : nullptr; }
+
+// hands the LAST of the engine's side-by-side streams (its hardware queue) to another GPU client of the process, e.g. the
+// diarization side-car (nasr_diar_set_stream): the engine keeps one stream fewer (one encoder piece fewer at most) and still
+// owns the stream -- the borrower must be done with it before nasr_engine_destroy
+extern "C" int nasr_engine_lend_stream(nasr_engine *e, void **out) {
+    ApiGuard api_guard;
+    if (!e || !out) return fail("null argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
+    if (!e->pipe_ready) {
+        if (pick_lanes(e)) return -1;
+        e->pipe_ready = true;
+        release_lanes(e);
+    }
+    if (e->n_lanes < 2) return fail("no side-by-side stream to lend (the engine found %d)", e->n_lanes);
+    e->n_lanes--;
+    e->lent.push_back(e->lane[e->n_lanes]);          // destroyed with the engine
+    *out = (void *)e->lane[e->n_lanes];
+    e->lane[e->n_lanes] = nullptr;
+    return 0;
+}
 
 extern "C" int nasr_device_alloc(nasr_engine *e, void **out, int64_t bytes) {
     ApiGuard api_guard;

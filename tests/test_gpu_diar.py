@@ -134,3 +134,36 @@ def test_vad_errors(Wv):
     with pytest.raises(capi.NasrError, match="running_var"):
         capi.Diar(bad)
     eng.close()
+
+
+def test_side_car_on_a_stream_lent_by_the_asr_engine(Wv):
+    """nasr_engine_lend_stream + nasr_diar_set_stream: the side-car runs on the ASR engine's fourth stream (a hardware queue no
+    encoder lane uses) -- same probabilities as on its own stream; the engine keeps stepping (one piece fewer), same tokens."""
+    audios = [_audio(1, 10080 + 160 * 37 + 55), _audio(3, 10080)]
+    d0 = capi.Diar(Wv)
+    ref = d0.vad(audios)
+    d0.close()
+    W = synth.make_weights(n_layers=4)
+    pcm = synth.make_pcm(9, 4.0)
+    piece = synth.shift_samples(0)
+    toks = []
+    for lend in (False, True):
+        eng = capi.Engine(W, n_layers=4, dtype=capi.DTYPE_BF16, max_streams=1)
+        eng.set_option("pipeline", 4)
+        st = eng.stream(0)
+        out = []
+        diar = capi.Diar(Wv)
+        for k in range(pcm.size // piece):
+            out += eng.step([st], [pcm[k * piece:(k + 1) * piece]])[0]
+            if lend and k == 10:
+                diar.set_stream(eng.lend_stream())
+            if k % 8 == 3:
+                got = diar.vad(audios)
+                for g, r in zip(got, ref):
+                    assert g.size == r.size and (r.size == 0 or np.array_equal(g, r))
+        out += eng.finalize([st])[0]
+        toks.append(out)
+        diar.close()                   # the borrower first
+        st.destroy()
+        eng.close()
+    assert len(toks[0]) > 0 and toks[0] == toks[1]
