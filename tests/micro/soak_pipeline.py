@@ -1,4 +1,4 @@
-"""soak test (GPU): a pipelined engine (option pipeline = 3) against a synchronous one over thousands of calls with random push
+"""soak test (GPU): a pipelined engine (option pipeline = 4: four lanes) against a synchronous one over thousands of calls with random push
 sizes (partial chunks, several chunks at once, ragged groups), random subsets of the streams per call, resets, finalize / collect
 in between -- token streams must be identical.  The parity suite covers each of these once; this looks for the rare ordering bug.
 usage: python tests/micro/soak_pipeline.py [calls] [seed]"""
@@ -21,7 +21,7 @@ def main():
     n_layers, B = 4, 5
     W = synth.make_weights(n_layers=n_layers)
     engs = []
-    for mode in (0, 3):
+    for mode in (0, 4):
         e = capi.Engine(W, n_layers=n_layers, dtype=capi.DTYPE_BF16, max_streams=B)
         e.set_option("pipeline", mode)
         engs.append(e)

@@ -349,7 +349,7 @@ def test_progress_does_not_drain_the_pipeline(W2):
 
 def test_pipelined_engine_soak():
     """tests/micro/soak_pipeline.py, short form: 800 calls with random push sizes (partial chunks, several chunks, ragged groups),
-    random subsets of five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine (three lanes)
+    random subsets of five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine (four lanes)
     emits exactly the tokens of a synchronous one."""
     import subprocess
     import sys
