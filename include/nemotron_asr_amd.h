@@ -134,7 +134,8 @@ int nasr_stream_set_prompt(nasr_stream *s, int prompt_index);
 int nasr_stream_get_stats(const nasr_stream *s, nasr_stream_stats *out);
 /* the host-mirror part of the stats only (samples_in, chunks, cache_valid_len, mel_frames_buffered; reserved = tokens decoded
  * but not yet handed over; decode_iterations = tokens = -1): no device synchronisation, no copy, does not complete a
- * pipelined step in flight -- for per-call bookkeeping on a server's hot path */
+ * pipelined step in flight -- for per-call bookkeeping on a server's hot path.  Like every call on a stream it belongs to the
+ * engine's ONE host thread (it reads the host mirrors nasr_engine_step mutates, without a lock) */
 int nasr_stream_get_progress(const nasr_stream *s, nasr_stream_stats *out);
 /* timed_token.frame_idx (src/nemo-ggml.h:383-395; time = frame * 1280 / 16000 s): absolute encoder-frame
  * index of tokens [first, first + count) of this stream, counted from create/reset.  Only the most recent

@@ -689,7 +689,7 @@ void launch_fused_skinny(const FusedParams &p, hipStream_t st) {
     if ((p.pro == PRO_LN || p.pro == PRO_DWCONV) && g.M > 2) lds += (size_t)g.M * D * 4;   // f32 row staging
     const bool fits_u2 = p.pro != PRO_DWCONV || (g.K / 32 / g.splits + 3) / 4 <= 2;   // the one-row dwconv form holds 2 k-tiles per wave
     if (g.M == 1 && fits_u2) launch_fused_m<1>(p, st, lds);
-    else if (g.M == 2) launch_fused_m<2>(p, st, lds);
+    else if (g.M <= 2) launch_fused_m<2>(p, st, lds);      // also one row whose k-slice does not fit the one-row form: the SMALL forms need no row staging
     else launch_fused_m<16>(p, st, lds);
 }
 

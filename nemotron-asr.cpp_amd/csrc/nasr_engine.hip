@@ -187,7 +187,7 @@ struct nasr_engine {
     int16_t *pcm_stage = nullptr; size_t pcm_stage_cap = 0;
     // host PCM hand-over: the streams' buffers are gathered into a pinned block and cross PCIe as ONE copy.  The copy is
     // asynchronous and a pipelined call returns before it has run, so the pinned blocks rotate (a block is reused four
-    // calls later; at most three steps are in flight).
+    // calls later; up to pipeline + 1 = 5 steps are in flight, but the copy sits in piece 0 of its step, and the NEXT call launches piece 1 of that step only after the host has seen piece 0 complete).
     struct { int16_t *p = nullptr; size_t cap = 0; } pcm_pin[4];
     unsigned pcm_pin_next = 0;
     float *mel_stage = nullptr; size_t mel_stage_cap = 0;
@@ -1166,7 +1166,11 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
             if (nseg == 4 && nLayers >= 8 && !bounds_env) return (k == 1 ? 48 : k == 2 ? 104 : 164) * nLayers / 24;
             return 8 * bound(k);
         };
-        if (run_layers_fused(e, rows, B, T, G, bound8(seg), bound8(seg + 1))) return -1;
+        // a boundary between K3 (QKV: appends the step's K/V rows to the rings) and K4 (attention: reads them) would let the lane
+        // of K3 run up to three steps ahead of the lane of K4 on the same ring; keep the two launches of a layer in one piece
+        // (the shipped 24-layer cuts 48 | 104 | 164 and 57 | 126 are not of that kind; other depths can be)
+        auto snap8 = [&](int b) { return b % 8 == 3 && b < 8 * nLayers ? b + 1 : b; };
+        if (run_layers_fused(e, rows, B, T, G, snap8(bound8(seg)), snap8(bound8(seg + 1)))) return -1;
     } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
         if (front) {

@@ -63,7 +63,7 @@ void nemo_free(nemo_context *ctx);
 bool nemo_set_language(nemo_context *ctx, const char *lang);  // default prompt for new streams
 // MI355X extension: pipelined steps (nasr_engine_set_option "pipeline"): the decode of one call runs beside the encoder of the
 // next; nemo_stream_process_incremental then returns each text delta one call later, nemo_stream_finalize returns the rest
-bool nemo_set_pipeline(nemo_context *ctx, int depth);   // 0 off, 1 decode beside the next encoder, 2 / 3: the encoder in 2 / 3 pieces of consecutive steps side by side
+bool nemo_set_pipeline(nemo_context *ctx, int depth);   // 0 off, 1 decode beside the next encoder, 2 / 3 / 4: the encoder in that many pieces of consecutive steps side by side
 
 // ---- streaming (reference src/nemo-stream.h:271-326) -------------------------------------------------
 nemo_stream_context *nemo_stream_init(nemo_context *ctx, const nemo_cache_config *config = nullptr);

@@ -312,7 +312,7 @@ void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_f
 int main(int argc, char **argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E]\n"
-                        "  --pipeline E: consecutive engine calls overlap on the GPU (E = 1..4, 2 is the optimum); a stream's text arrives\n"
+                        "  --pipeline E: consecutive engine calls overlap on the GPU (E = 0..4; 4 pieces on 4 hardware queues is the throughput optimum, 0 the lowest latency); a stream's text arrives\n"
                         "                E calls later while the FIFO is busy and at once when it runs empty\n"
                         "  --devices: one engine + worker per listed GPU; stream s is served by entry s mod count\n", argv[0]);
         return 1;

@@ -16,14 +16,15 @@
 
 static void usage(const char *prog) {
     fprintf(stderr,
-            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline | --pipeline2 | --pipeline3]\n"
+            "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline [E]]\n"
             "  audio: raw s16le, 16 kHz, mono.  right_context in {0, 1, 6, 13} (80 ms .. 1.12 s lookahead)\n"
             "  --read-chunks N: read N chunks of audio per call (default 1 = the reference's read size); a file is\n"
             "                   transcribed fastest with N = 256: same transcript, the chunks of a read share one launch sequence\n"
             "  --timestamps:    print the final transcript again with {seconds} in front of every word\n"
-            "  --pipeline:      decode of one read runs beside the encoder of the next (same transcript; each delta appears one read later)\n"
-            "  --pipeline2:     in addition the two halves of the encoder of consecutive reads run side by side (deltas two reads later)\n"
-            "  --pipeline3:     the encoder in three pieces (deltas three reads later): the fastest way through a file\n"
+            "  --pipeline E:    consecutive reads overlap on the GPU, E = 0..4 (same transcript; each delta appears E reads later).\n"
+            "                   1: decode of one read beside the encoder of the next; 2..4: the encoder in E pieces on E hardware queues\n"
+            "                   (4 = the fastest way through a file).  --pipeline without a number = 1; --pipeline2 / --pipeline3 still work\n"
+            "  --cpu | --cuda | --metal: the reference's backend selectors are accepted and ignored (this build has one backend: MI355X)\n"
             "  --diarize <diarize.gguf> [--rttm <file>] [--speaker-text <file>] [--json <file>] [--num-speakers K] [--sub-shift SEC] [--vad-onset P] [--vad-offset P]\n"
             "                   speaker diarization beside the transcript (speaker-tagged transcript on stdout at EOF)\n", prog);
 }
@@ -46,9 +47,15 @@ int main(int argc, char **argv) {
         else if (a == "--f32") dtype = 0;
         else if (a == "--print-tokens") print_tokens = true;
         else if (a == "--timestamps") timestamps = true;
-        else if (a == "--pipeline") pipeline = 1;
+        else if (a == "--cpu" || a == "--cuda" || a == "--metal")      // reference src/transcribe_stream.cpp:86-88
+            fprintf(stderr, "note: %s ignored -- this build runs on the MI355X HIP engine only\n", a.c_str());
+        else if (a == "--pipeline") {
+            pipeline = 1;
+            if (i + 1 < argc && strlen(argv[i + 1]) == 1 && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '4') pipeline = argv[++i][0] - '0';
+        }
         else if (a == "--pipeline2") pipeline = 2;
         else if (a == "--pipeline3") pipeline = 3;
+        else if (a == "--pipeline4") pipeline = 4;
         else if (a == "--read-chunks" && i + 1 < argc) read_chunks = atoi(argv[++i]);
         else if (a == "--diarize" && i + 1 < argc) diarize_gguf = argv[++i];
         else if (a == "--rttm" && i + 1 < argc) rttm_path = argv[++i];

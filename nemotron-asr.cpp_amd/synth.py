@@ -234,11 +234,14 @@ def default_blank_gain(n_layers: int) -> float:
 
 
 def make_weights(n_layers: int = 24, seed: int = 0xC0FFEE, kernel_size: int = 9,
-                 num_prompts: int = 0, blank_bias: float = None, layers=None) -> dict:
+                 num_prompts: int = 0, blank_bias: float = None, layers=None, margins: str = "random", readout=None) -> dict:
     """name -> float32 ndarray for the whole model (2.4 GB at 24 layers).
 
     `layers`: optional iterable of layer indices to materialise (default: all).
-    `blank_bias`: blank gain of the synthetic joint (default: default_blank_gain(n_layers))."""
+    `blank_bias`: blank gain of the synthetic joint (default: default_blank_gain(n_layers)).
+    `margins`: "random" = the near-tie stress checkpoint (N(0, s^2) logits, top-2 margins of ~1e-3 everywhere);
+               "speech" = same encoder bytes, decoder / joint with a fitted read-out for make_speech_pcm() audio
+               (24 layers only: the fit belongs to the 24-layer encoder), see speech_decoder_tensors()."""
     if blank_bias is None:
         blank_bias = default_blank_gain(n_layers)
     w = {
@@ -251,6 +254,11 @@ def make_weights(n_layers: int = 24, seed: int = 0xC0FFEE, kernel_size: int = 9,
         for suffix, shape, kind, fan_in in layer_tensor_specs(kernel_size):
             name = f"encoder.layers.{l}.{suffix}"
             w[name] = _make(seed, name, shape, kind, fan_in, blank_bias)
+    if margins == "speech":
+        scale_residual_branches(w, SPEECH_RESIDUAL_SCALE)
+        w.update(speech_decoder_tensors(seed, readout))
+    elif margins != "random":
+        raise ValueError(margins)
     return w
 
 
@@ -459,3 +467,196 @@ def make_diar_weights(seed: int = 0xD1A12, vad: bool = True, spk: bool = True) -
         w[d + ".emb_layers.0.1.weight"] = _tensor(seed, d + ".embw", (192, 2 * C), float(np.sqrt(3.0 / (2 * C))))
         w[d + ".emb_layers.0.1.bias"] = _tensor(seed, d + ".embb", (192,), 0.05)
     return w
+
+
+# ---- "speech-like" synthetic workload (round 3): audio with a discrete phone inventory ----------------------------------
+# A trained RNN-T decides with wide top-2 margins because its encoder maps a DISCRETE inventory (phones) to separated
+# clusters.  make_pcm() above is a tone under noise: a random encoder's output for it is a continuum, every decision
+# boundary of any joint network is crossed with the same density, and a 1 % activation error flips 1-3 % of the greedy
+# decisions whatever the logits are scaled to.  The audio below has that discrete structure: a random sequence of N_PHONES
+# "phones" (three formant clusters each, out of 12 candidate centre frequencies, any two phones share at most one)
+# separated by near-silence, with onsets at arbitrary sample positions.
+N_PHONES = 16
+_FORMANTS = np.geomspace(260.0, 6200.0, 12)
+# 16 triples over 12 points, pairwise intersection <= 1 (rows/columns/diagonals of a 4x3 torus arrangement + shifts)
+_PHONE_FORMANTS = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (9, 10, 11), (0, 3, 6), (1, 4, 7), (2, 5, 8), (0, 4, 8),
+                   (1, 5, 6), (2, 3, 7), (0, 5, 9), (1, 3, 10), (2, 4, 11), (0, 7, 10), (1, 8, 11), (2, 6, 9)]
+PHONE_TOKEN_STRIDE, PHONE_TOKEN_BASE = 61, 37
+
+
+def phone_token(k: int) -> int:
+    """vocabulary id of phone k (spread over the 1024 tokens so the arg-max scan is exercised across the row range)"""
+    return (PHONE_TOKEN_BASE + PHONE_TOKEN_STRIDE * k) % BLANK
+
+
+def speech_events(stream: int, seconds: float, seed: int = 0x5BEEC400):
+    """[(phone, onset_sample, end_sample)]: phones of 240-480 ms, gaps of 80-320 ms, never the same phone twice in a row."""
+    n = int(round(seconds * SAMPLE_RATE))
+    u = uniform01(seed + 7919 * stream, 3 * (int(seconds * 4) + 8), 0)
+    ev, pos, prev, i = [], int(0.1 * SAMPLE_RATE + u[0] * 0.2 * SAMPLE_RATE), -1, 1
+    while True:
+        dur = int((0.24 + 0.24 * u[i]) * SAMPLE_RATE)
+        gap = int((0.08 + 0.24 * u[i + 1]) * SAMPLE_RATE)
+        k = int(u[i + 2] * (N_PHONES - 1))
+        if k >= prev >= 0:
+            k += 1                      # uniform over the phones other than the previous one
+        if pos + dur > n:
+            break
+        ev.append((k, pos, pos + dur))
+        pos, prev, i = pos + dur + gap, k, i + 3
+    return ev
+
+
+def make_speech_pcm(stream: int, seconds: float, seed: int = 0x5BEEC400):
+    """int16 mono 16 kHz + its event list.  Phone k = 3 formant clusters (3 partials each, fixed phases) at amplitude 0.25
+    with 10 ms raised-cosine edges; background = white noise of sigma 0.004 everywhere (so log-mel never sits at its floor),
+    plus noise of sigma 0.01 inside phones."""
+    n = int(round(seconds * SAMPLE_RATE))
+    t = np.arange(n, dtype=np.float64) / SAMPLE_RATE
+    u1 = uniform01(seed + 7919 * stream + 1, n, 0)
+    u2 = uniform01(seed + 7919 * stream + 1, n, n)
+    noise = np.sqrt(-2.0 * np.log(np.maximum(u1, 2.0 ** -53))) * np.cos(2.0 * np.pi * u2)
+    x = 0.004 * noise
+    ev = speech_events(stream, seconds, seed)
+    edge = int(0.010 * SAMPLE_RATE)
+    for k, a, b in ev:
+        seg = np.zeros(b - a)
+        tt = t[a:b]
+        for j, fi in enumerate(_PHONE_FORMANTS[k]):
+            fc = _FORMANTS[fi]
+            for m, det in enumerate((0.965, 1.0, 1.04)):
+                seg += np.sin(2.0 * np.pi * fc * det * tt + 0.7 * (3 * j + m) + 0.37 * k) / 9.0
+        env = np.ones(b - a)
+        r = 0.5 - 0.5 * np.cos(np.pi * np.arange(edge) / edge)
+        env[:edge], env[-edge:] = r, r[::-1]
+        x[a:b] += env * (0.75 * seg + 0.01 * noise[a:b])
+    return np.round(np.clip(x, -1.0, 1.0) * 32767.0).astype(np.int16), ev
+
+
+# ---- the "speech" checkpoint: a joint with the margins of a TRAINED one -------------------------------------------------------
+# make_weights(..., margins="speech") keeps every tensor of the default checkpoint's encoder (same seed) except that the
+# output matrices of the residual branches are scaled by SPEECH_RESIDUAL_SCALE (scale_residual_branches), and replaces the
+# decoder / joint by a structured one whose acoustic read-out was FITTED (ridge regression, tests/golden/gen_speech_joint.py)
+# to read the phone of make_speech_pcm() audio off that frozen synthetic encoder:
+#   joint hidden units [0, 17): phone detectors -- row k of joint.enc is the fitted direction w_k (target: 1 on frames of
+#       phone k, 0 elsewhere; unit 16 = "silence"), hidden = relu(w_k . e + b_k - SPEECH_DETECT_FLOOR); the output layer
+#       maps detector k to token k (detector 16 to blank, + SPEECH_BLANK_BIAS) with SPEECH_LOGIT_SCALE logits per target unit;
+#   joint hidden units [17, SPEECH_NA): dense random rows as in the default checkpoint; only the never-emitted tokens' output
+#       rows read them (small random weights under a negative bias);
+#   joint hidden units [SPEECH_NA, 640): refractory -- phone k owns 8 units (its "code"); embed[token k] drives them through
+#       the two LSTM layers (forget gate ~0.003: the state is the LAST token), joint.pred = -SPEECH_PRED_GAIN on those units,
+#       so after emitting k its own logit drops by SPEECH_SUPPRESS target units: one token per phone, as a trained
+#       prediction network would do it.
+# The LSTM / joint.pred matrices keep a dense random part, so their arithmetic is exercised in full.
+SPEECH_NA = 512
+SPEECH_CODE = (JOINT - SPEECH_NA) // N_PHONES          # 8 units per phone
+SPEECH_LOGIT_SCALE = 5.0
+SPEECH_BLANK_BIAS = 0.5
+SPEECH_DETECT_FLOOR = 0.0
+SPEECH_SUPPRESS = 1.0
+SPEECH_PRED_GAIN = 3.0
+SPEECH_EMBED = 3.0
+SPEECH_FORGET_BIAS = -6.0
+SPEECH_DEC_NOISE = 0.05     # amplitude of the dense random part of the LSTM / joint.pred matrices (x sqrt(3/fan_in)); the embedding gain
+                            # and the prediction gain multiply it, so it is 5x smaller than DEC_NOISE of the default checkpoint
+SPEECH_READOUT_FILE = "speech_readout_v1.npz"
+
+
+def load_speech_readout():
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "data" / SPEECH_READOUT_FILE)
+    return z["w"].astype(np.float32), z["b"].astype(np.float32)
+
+
+def speech_decoder_tensors(seed: int, readout=None) -> dict:
+    """decoder + joint tensors of the speech checkpoint.  readout = (w [N_PHONES + 1][1024], b [N_PHONES + 1]) in target
+    units (row N_PHONES = silence); default: the committed fit."""
+    w_fit, b_fit = load_speech_readout() if readout is None else readout
+    ND = N_PHONES + 1
+    assert w_fit.shape == (ND, D_MODEL) and b_fit.shape == (ND,)
+    NA, A = SPEECH_NA, np.float32(SPEECH_LOGIT_SCALE)
+    out = {}
+    code = np.zeros((N_PHONES, JOINT), np.float32)
+    for k in range(N_PHONES):
+        code[k, NA + k * SPEECH_CODE:NA + (k + 1) * SPEECH_CODE] = 1.0
+    toks = [phone_token(k) for k in range(N_PHONES)]
+    # joint.enc: detector rows fitted, the other acoustic rows as in the default checkpoint, refractory rows 20x smaller with bias 1
+    we = _tensor(seed, "joint.enc.weight", (JOINT, D_MODEL), float(np.sqrt(3.0 / D_MODEL)))
+    be = _tensor(seed, "joint.enc.bias", (JOINT,), 0.05)
+    we[:ND] = w_fit
+    be[:ND] = b_fit - np.float32(SPEECH_DETECT_FLOOR)
+    we[NA:] *= np.float32(0.05)
+    be[NA:] += np.float32(1.0)
+    out["joint.enc.weight"], out["joint.enc.bias"] = we, be
+    # joint.pred: dense random part (not on the detector units) + -gain * I on the refractory units
+    wp = _tensor(seed, "joint.pred.weight", (JOINT, HIDDEN), float(np.sqrt(3.0 / HIDDEN)) * SPEECH_DEC_NOISE)
+    wp[:ND] = 0.0
+    wp[NA:, NA:] -= np.float32(SPEECH_PRED_GAIN) * np.eye(JOINT - NA, dtype=np.float32)
+    bp = _tensor(seed, "joint.pred.bias", (JOINT,), 0.05)
+    bp[:ND] = 0.0
+    out["joint.pred.weight"], out["joint.pred.bias"] = wp, bp
+    # output layer: the never-emitted tokens read the random acoustic units (small weights, negative bias); phone k reads
+    # detector k and its refractory code, blank reads the silence detector
+    wo = (0.25 * _jout_random(seed)).astype(np.float32)
+    wo[:, :ND] = 0.0
+    bo = _tensor(seed, "joint.joint_net.2.bias", (VOCAB,), 0.05) - np.float32(1.5) * A
+    gamma = np.float32(SPEECH_SUPPRESS) * A / np.float32(SPEECH_CODE)
+    for k, v in enumerate(toks):
+        wo[v] = 0.0
+        wo[v, k] = A
+        wo[v, NA:] = gamma * code[k, NA:]
+        bo[v] = A * np.float32(SPEECH_DETECT_FLOOR) - gamma * np.float32(SPEECH_CODE)     # un-suppressed: the refractory units add gamma * 8 back
+    wo[BLANK] = 0.0
+    wo[BLANK, N_PHONES] = A
+    bo[BLANK] = A * np.float32(SPEECH_DETECT_FLOOR + SPEECH_BLANK_BIAS)
+    out["joint.joint_net.2.weight"], out["joint.joint_net.2.bias"] = wo, bo
+    # embedding: the token's code on the refractory dims, small random elsewhere; blank = padding row
+    em = _tensor(seed, "decoder.prediction.embed.weight", (VOCAB, HIDDEN), 0.05)
+    for k, v in enumerate(toks):
+        em[v] += np.float32(SPEECH_EMBED) * code[k]
+    em[BLANK] = 0.0
+    out["decoder.prediction.embed.weight"] = em
+    # LSTM x 2: g-gate = identity on the input, input / output gates open, forget gate nearly closed
+    for l in (0, 1):
+        p = "decoder.prediction.dec_rnn.lstm."
+        for kind in ("ih", "hh"):
+            name = p + f"weight_{kind}_l{l}"
+            w = _tensor(seed, name, (4 * HIDDEN, HIDDEN), float(np.sqrt(3.0 / HIDDEN)) * SPEECH_DEC_NOISE)
+            if kind == "ih":
+                w[2 * HIDDEN:3 * HIDDEN] += np.eye(HIDDEN, dtype=np.float32)
+            out[name] = w
+        for kind in ("ih", "hh"):
+            name = p + f"bias_{kind}_l{l}"
+            b = _tensor(seed, name, (4 * HIDDEN,), 0.01)     # (the prediction gain multiplies what the g-gate bias leaks into h)
+            if kind == "ih":
+                b[0:HIDDEN] += np.float32(GATE_OPEN)
+                b[HIDDEN:2 * HIDDEN] += np.float32(SPEECH_FORGET_BIAS)
+                b[3 * HIDDEN:4 * HIDDEN] += np.float32(GATE_OPEN)
+            out[name] = b
+    return out
+
+
+RESIDUAL_BRANCH_OUT = ("feed_forward1.linear2.weight", "self_attn.linear_out.weight", "conv.pointwise_conv2.weight",
+                       "feed_forward2.linear2.weight")
+SPEECH_RESIDUAL_SCALE = 0.1
+
+
+def scale_residual_branches(W: dict, alpha: float) -> dict:
+    """multiplies the output matrix of every residual branch (FFN x 2, attention, conv module) of every layer by alpha, in
+    place.  With variance-1/fan_in matrices every branch adds as much as the stream carries, each layer re-mixes the frame
+    with its 70-frame context at full strength and after 24 layers nothing of the frame's own content is linearly readable
+    (measured, held-out frame accuracy of a ridge read-out of the phone at 24 layers: alpha 1: 30 %, 0.5: 34 %, 0.3: 92 %,
+    0.2: 98 %, 0.1: 99.6 %; gpurun_out/speech/speech_alpha_scan.json of round 3).  A trained
+    network's branches are small updates of the stream; alpha < 1 gives the synthetic encoder that property."""
+    a = np.float32(alpha)
+    for name in W:
+        if name.startswith("encoder.layers.") and name.endswith(RESIDUAL_BRANCH_OUT):
+            W[name] = (W[name] * a).astype(np.float32)
+    return W
+
+
+def apply_speech_decoder(W: dict, seed: int = 0xC0FFEE, readout=None) -> dict:
+    """a copy of the checkpoint dict with the decoder / joint tensors of the speech checkpoint (encoder tensors shared)"""
+    W2 = dict(W)
+    W2.update(speech_decoder_tensors(seed, readout))
+    return W2

@@ -445,3 +445,23 @@ def ref_greedy(weights, enc) -> list:
     toks = np.zeros(cap, np.int32)
     n = ref().ref_greedy(arr, _f(enc), enc.shape[0], toks.ctypes.data_as(_ip), cap)
     return toks[:n].tolist()
+
+
+def token_timing_report(log: dict, ref_tokens, ref_frames, got_tokens, got_frames):
+    """Token-for-token comparison of an engine's greedy output with the oracle's, with the oracle decision behind every
+    difference.  Returns dict(tokens_equal, n_ref, n_got, shifts=[...], first_divergence): `shifts` lists the tokens that
+    are the same id at another frame (only meaningful when the id sequences are equal): the oracle decision at which the
+    engine chose differently -- the oracle's emission (engine later) or the oracle's blank at the engine's frame (engine
+    earlier) -- and its top-2 margin."""
+    out = dict(tokens_equal=list(ref_tokens) == list(got_tokens), n_ref=len(ref_tokens), n_got=len(got_tokens), shifts=[],
+               first_divergence=first_divergence(log, ref_tokens, ref_frames, got_tokens, got_frames))
+    if not out["tokens_equal"]:
+        return out
+    for i, (fr, fg) in enumerate(zip(ref_frames, got_frames)):
+        if fr == fg:
+            continue
+        frame = fg if fg < fr else fr
+        sel = np.nonzero((log["frame"] == frame) & (log["ntok_before"] == i))[0]
+        margin = float(log["margin"][int(sel[0])]) if sel.size == 1 else float("nan")
+        out["shifts"].append(dict(index=i, token=int(ref_tokens[i]), ref_frame=int(fr), got_frame=int(fg), margin=margin))
+    return out

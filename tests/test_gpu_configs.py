@@ -225,6 +225,82 @@ def test_q8_0_token_agreement_vs_ggml_q8_semantics(Q24):
         assert d is None or (d["decision"] >= 0 and d["margin"] < EPS_MARGIN), r
 
 
+def _shipped_pipeline_identity(eng, R, pcms, n_steps, ragged_at, L, spot_streams):
+    """steps `pcms` through `eng` with pipeline = 0..4 and returns per mode: tokens, token frames, encoder-out taps at three
+    points of the run, decoder state, K / V / conv caches of every layer for the spot streams, per-stream counters"""
+    B, n = len(pcms), synth.shift_samples(R)
+    res = {}
+    for mode in (0, 1, 2, 3, 4):
+        eng.set_option("pipeline", mode)
+        sts = [eng.stream(R) for _ in range(B)]
+        toks, encs = [[] for _ in range(B)], []
+        for k in range(n_steps):
+            if k == ragged_at:            # a ragged push (two uneven parts): not graph-eligible, lands mid-pipeline
+                cuts = (slice(k * n, k * n + 777), slice(k * n + 777, (k + 1) * n))
+            else:
+                cuts = (slice(k * n, (k + 1) * n),)
+            for c in cuts:
+                for b, t in enumerate(eng.step(sts, [p[c] for p in pcms])):
+                    toks[b] += t
+            if k in (n_steps // 3, 2 * n_steps // 3):     # a tap in the middle of the run (completes what is in flight)
+                encs.append(np.stack([sts[b].tap(capi.TAP_ENCODER_OUT) for b in spot_streams]))
+        for b, t in enumerate(eng.finalize(sts)):
+            toks[b] += t
+        encs.append(np.stack([sts[b].tap(capi.TAP_ENCODER_OUT) for b in spot_streams]))
+        dec = np.stack([s.tap(capi.TAP_DEC_STATE) for s in sts])
+        caches = np.stack([np.concatenate([sts[b].tap(capi.TAP_K_CACHE, l, cap=70 * 1024), sts[b].tap(capi.TAP_V_CACHE, l, cap=70 * 1024),
+                                           sts[b].tap(capi.TAP_CONV_CACHE, l, cap=8 * 1024)]) for b in spot_streams for l in range(L)])
+        counters = [(s.stats().chunks, s.stats().decode_iterations, s.stats().tokens, s.stats().cache_valid_len) for s in sts]
+        frames = [s.token_frames() for s in sts]
+        res[mode] = (toks, frames, encs, dec, caches, counters)
+        for s in sts:
+            s.destroy()
+    return res
+
+
+def _assert_modes_identical(res):
+    toks0, frames0, encs0, dec0, caches0, counters0 = res[0]
+    assert sum(len(t) for t in toks0) > 0
+    for mode in (1, 2, 3, 4):
+        toks, frames, encs, dec, caches, counters = res[mode]
+        assert toks == toks0 and frames == frames0, mode
+        assert counters == counters0, mode
+        assert all(np.array_equal(a, b) for a, b in zip(encs, encs0)), mode
+        assert np.array_equal(dec, dec0), mode
+        assert np.array_equal(caches, caches0), mode
+
+
+def test_shipped_pipeline_bit_identity_batch1_R0_24_layers(W24):
+    """What bench.py times at configs[1]: 24 layers, bf16, ONE stream x 80 ms, the fused 8-launch layer, pieces cut at
+    launch granularity (E = 3: launches 57 | 126; E = 4: 48 | 104 | 164 of 192).  160 steps (+ a ragged push in the middle)
+    with pipeline = 1, 2, 3, 4 == synchronous stepping: tokens, token frames, encoder output at three points of the run,
+    decoder state, the K / V / conv cache of every layer, the counters -- bit for bit."""
+    L, R = 24, 0
+    n_steps = 160
+    pcm = synth.make_pcm(31, n_steps * 0.08 + 0.01)[:n_steps * 1280]
+    eng = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=2)
+    res = _shipped_pipeline_identity(eng, R, [pcm], n_steps, 81, L, (0,))
+    eng.close()
+    assert res[0][5][0][0] >= n_steps - 1
+    _assert_modes_identical(res)
+
+
+def test_shipped_pipeline_bit_identity_b64_R13_q8_0_24_layers(Q24):
+    """What bench.py times at configs[2]: 24 layers, Q8_0 tensors -> bf16 engine, 64 streams x 1.12 s (M = 896: tiled GEMMs,
+    split-K, XCD remap), pieces of 6 + 7 + 7 + 4 layers.  150 steps (+ a ragged push) with pipeline = 1, 2, 3, 4 ==
+    synchronous stepping, bit for bit (caches of 4 spot streams x 24 layers)."""
+    engW, _, _ = Q24
+    L, R, B = 24, 13, 64
+    n_steps, n = 150, synth.shift_samples(13)
+    base = [synth.make_pcm(800 + b, 25 * n / 16000 + 0.01)[:25 * n] for b in range(B)]
+    pcms = [np.tile(p, n_steps // 25) for p in base]        # bit-identity does not care that the audio repeats every 28 s
+    eng = capi.Engine(engW, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    res = _shipped_pipeline_identity(eng, R, pcms, n_steps, 75, L, (0, 21, 42, 63))
+    eng.close()
+    assert res[0][5][0][0] >= n_steps - 1
+    _assert_modes_identical(res)
+
+
 def test_reset_reference_mode_keeps_what_the_reference_keeps(W2):
     """nemo_stream_reset as coded (src/nemo-stream.cpp:95-115): conv cache and preprocessor carry survive, K/V contents
     survive but are masked.  Engine (f32) == oracle twin token for token and on the encoder output; and the quirk is

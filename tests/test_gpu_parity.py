@@ -230,7 +230,7 @@ def test_pipelined_steps_equal_synchronous_steps(W, om32, dtype, R, B):
             for s in grp[g]:
                 s.destroy()
     assert sum(len(t) for t in res[0][0]) > 0 and res[0][3][0][0] > 5
-    for mode in (1, 2, 4):    # 1: decode beside the next encoder; E: the encoder in E pieces, pieces of consecutive steps side by side
+    for mode in (1, 2, 3, 4):    # 1: decode beside the next encoder; E: the encoder in E pieces, pieces of consecutive steps side by side
         assert res[mode][0] == res[0][0], mode
         # encoder-out tap: valid until the next chunk step of the engine touches its workspace -- the group stepped last
         assert np.array_equal(res[mode][1][B:], res[0][1][B:]) and np.array_equal(res[mode][2], res[0][2]), mode
