@@ -550,7 +550,7 @@ def make_speech_pcm(stream: int, seconds: float, seed: int = 0x5BEEC400):
 # The LSTM / joint.pred matrices keep a dense random part, so their arithmetic is exercised in full.
 SPEECH_NA = 512
 SPEECH_CODE = (JOINT - SPEECH_NA) // N_PHONES          # 8 units per phone
-SPEECH_LOGIT_SCALE = 5.0
+SPEECH_LOGIT_SCALE = 8.0
 SPEECH_BLANK_BIAS = 0.5
 SPEECH_DETECT_FLOOR = 0.0
 SPEECH_SUPPRESS = 1.0

@@ -24,8 +24,9 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 # score noise of the bf16 path on this checkpoint, measured (profiles/r3_speech_fit_report.json): 0.003 target units rms, 0.013
-# max, x SPEECH_LOGIT_SCALE = 5 -> 0.015 logits rms / 0.065 max on a logit, x sqrt(2) on a margin.
-EPS_MARGIN = 0.1
+# max, x SPEECH_LOGIT_SCALE = 8 -> 0.024 logits rms on a logit.  Timing shifts measured at 24 layers (64 streams x 13 s from
+# Q8_0): 3 of 1505 tokens, at oracle margins 0.014-0.037.
+EPS_MARGIN = 0.05
 
 
 def _report(name, payload):
