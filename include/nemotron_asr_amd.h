@@ -198,8 +198,14 @@ enum {
  * (a server draining a backlog, a file); a live stream keeps the default.
  * "lanes" (1..4): keep at most this many encoder lanes and give the other lanes' streams back -- for a process with another GPU
  * client (the diarization side-car): a stream created after this call gets a hardware queue the engine no longer uses.  Not
- * reversible for the engine's lifetime. */
+ * reversible for the engine's lifetime.
+ * "graph_cache" (>= 1, default 16): step shapes (streams in the call, lookahead, chunks per push, pieces) whose hipGraphs are kept;
+ * beyond it the least recently used shape is dropped and re-captured when it comes back -- a server whose batch size changes from
+ * call to call (reference: one stream per call, src/nemo-server.cpp:192-271) holds a bounded number of graph execs. */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
+/* diagnostics: "graph_execs" (hipGraphExec objects alive), "graph_shapes" (distinct cached step shapes), "graph_evictions",
+ * "graph_replays", "eager_steps", "pipelined_steps".  Returns 0, or -1 for an unknown name. */
+int nasr_engine_get_counter(const nasr_engine *e, const char *name, int64_t *value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);
 /* returns the number of floats written (<= cap) or <0 */

@@ -26,7 +26,7 @@ EXPORTS = [
     "nasr_stream_get_stats", "nasr_stream_get_progress", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_engine_lend_stream", "nasr_device_alloc", "nasr_device_free",
-    "nasr_device_upload", "nasr_engine_synchronize",
+    "nasr_device_upload", "nasr_engine_synchronize", "nasr_engine_get_counter",
     "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_set_stream", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel",
 ]
 
@@ -101,6 +101,7 @@ def lib():
         L.nasr_device_free.argtypes = [vp, vp]
         L.nasr_device_upload.argtypes = [vp, vp, vp, C.c_int64]
         L.nasr_engine_synchronize.argtypes = [vp]
+        L.nasr_engine_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -324,6 +325,11 @@ class Engine:
 
     def set_debug(self, on=True):
         _chk(lib().nasr_engine_set_debug(self.h, int(on)))
+
+    def counter(self, name: str) -> int:
+        v = C.c_int64()
+        _chk(lib().nasr_engine_get_counter(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     # ---- batched calls ---------------------------------------------------------------
     @staticmethod

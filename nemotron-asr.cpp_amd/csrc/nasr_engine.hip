@@ -132,6 +132,9 @@ struct nasr_engine {
     // workspace (sized for max_streams x TMAX rows)
     float *x, *x2, *part, *q, *glu, *encproj, *sub_a, *hfuse;
     bool opt_fused = true, opt_graph = true;
+    int opt_graph_cache = 16;        // option "graph_cache": step shapes (B, T, G, E) whose hipGraphs are kept, per slot; least recently used goes first
+    std::map<int64_t, int64_t> graph_used;   // shape key -> tick of its last use
+    int64_t graph_tick = 0, graph_evictions = 0;
     // hipGraph replay of the steady-state step: fixed descriptor buffers + one exec per (B, T)
     std::map<int64_t, hipGraphExec_t> graphs;
     int w_rows = 0;                  // workspace rows = max(max_streams x TMAX, MAXNEW)
@@ -1460,6 +1463,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     if (!e || !key) return fail("null argument");
     if (!strcmp(key, "fused")) e->opt_fused = value != 0;
     else if (!strcmp(key, "graph")) e->opt_graph = value != 0;
+    else if (!strcmp(key, "graph_cache")) { if (value < 1) return fail("graph_cache must be >= 1"); e->opt_graph_cache = value; }
     else if (!strcmp(key, "multichunk")) e->opt_multichunk = value != 0;
     else if (!strcmp(key, "pipeline")) {
         ApiGuard api_guard;
@@ -1815,9 +1819,24 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
     if (pipe_finish(e, p)) return -1;                      // the slot's previous occupant (NSLOT steps ago): done in steady state
     const int64_t key = ((int64_t)B << 40) | ((int64_t)T << 24) | ((int64_t)G << 8) | (int64_t)nseg;
     auto ge = P.seg_graphs[0].find(key);
+    e->graph_used[key | ((int64_t)1 << 62)] = ++e->graph_tick;
     if (ge == P.seg_graphs[0].end()) {
         if (pipe_drain(e)) return -1;
         HIPCHK(hipStreamSynchronize(e->st));
+        // bounded cache: a server whose batch size changes from call to call would otherwise keep NSLOT x (E + 1) graph execs per
+        // shape it has ever seen.  Nothing is in flight here (drained above): the slot's least recently used shape goes.
+        while ((int)P.seg_graphs[0].size() >= e->opt_graph_cache) {
+            int64_t victim = 0, oldest = INT64_MAX;
+            for (auto &kv : P.seg_graphs[0]) {
+                auto u = e->graph_used.find(kv.first | ((int64_t)1 << 62));
+                const int64_t t = u == e->graph_used.end() ? 0 : u->second;
+                if (t < oldest) { oldest = t; victim = kv.first; }
+            }
+            for (auto &m : P.seg_graphs) { auto f = m.find(victim); if (f != m.end()) { if (f->second) hipGraphExecDestroy(f->second); m.erase(f); } }
+            auto f = P.dec_graphs.find(victim);
+            if (f != P.dec_graphs.end()) { if (f->second) hipGraphExecDestroy(f->second); P.dec_graphs.erase(f); }
+            e->graph_evictions++;
+        }
         hipGraphExec_t gs[nasr_engine::MAXSEG] = {nullptr, nullptr, nullptr, nullptr}, dec = nullptr;
         {
             CaptureExclusive alone;
@@ -1920,8 +1939,21 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
     if (pipe_drain(e)) return -1;
     const int64_t key = ((int64_t)B << 32) | ((int64_t)T << 16) | (int64_t)G;
     auto it = e->graphs.find(key);
+    e->graph_used[key] = ++e->graph_tick;
     if (it == e->graphs.end()) {
         HIPCHK(hipStreamSynchronize(e->st));
+        while ((int)e->graphs.size() >= e->opt_graph_cache) {          // bounded cache, least recently used shape first
+            int64_t victim = 0, oldest = INT64_MAX;
+            for (auto &kv : e->graphs) {
+                auto u = e->graph_used.find(kv.first);
+                const int64_t t = u == e->graph_used.end() ? 0 : u->second;
+                if (t < oldest) { oldest = t; victim = kv.first; }
+            }
+            hipGraphExecDestroy(e->graphs[victim]);
+            e->graphs.erase(victim);
+            e->graph_used.erase(victim);
+            e->graph_evictions++;
+        }
         hipGraphExec_t ex = nullptr;
         {
             CaptureExclusive alone;
@@ -2257,6 +2289,25 @@ extern "C" int nasr_stream_get_token_frames(const nasr_stream *s, int64_t first,
 }
 
 // host mirror only: no pipeline drain, no stream synchronisation, no copy (the per-call path of a server)
+extern "C" int nasr_engine_get_counter(const nasr_engine *e, const char *name, int64_t *value) {
+    if (!e || !name || !value) return fail("null argument");
+    int64_t execs = (int64_t)e->graphs.size(), shapes = (int64_t)e->graphs.size();
+    std::map<int64_t, int> keys;
+    for (int p = 0; p < nasr_engine::NSLOT; p++) {
+        for (auto &m : e->pipe[p].seg_graphs) for (auto &kv : m) { execs += kv.second != nullptr; keys[kv.first] = 1; }
+        for (auto &kv : e->pipe[p].dec_graphs) execs += kv.second != nullptr;
+    }
+    shapes += (int64_t)keys.size();
+    if (!strcmp(name, "graph_execs")) *value = execs;
+    else if (!strcmp(name, "graph_shapes")) *value = shapes;
+    else if (!strcmp(name, "graph_evictions")) *value = e->graph_evictions;
+    else if (!strcmp(name, "graph_replays")) *value = e->graph_replays;
+    else if (!strcmp(name, "eager_steps")) *value = e->eager_steps;
+    else if (!strcmp(name, "pipelined_steps")) *value = e->pipe_steps;
+    else return fail("unknown counter '%s'", name);
+    return 0;
+}
+
 extern "C" int nasr_stream_get_progress(const nasr_stream *s, nasr_stream_stats *out) {
     if (!s || !out) return fail("null argument");
     memset(out, 0, sizeof(*out));

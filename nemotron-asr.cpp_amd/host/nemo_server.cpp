@@ -131,6 +131,7 @@ void worker_loop(Lane *lane) {
     nemo_context *model = lane->model;
     std::map<uint32_t, Session> sessions;
     uint64_t n_batches = 0, n_batched_streams = 0;
+    std::map<int, uint64_t> b_hist;               // streams per engine call -> calls (printed at exit: tests/server_load.py reads it)
     std::set<uint32_t> in_flight;               // --pipeline: sessions whose last steps may still be on the GPU
     auto drain = [&]() {                         // complete the steps in flight and send their text (FIFO empty, END, LANG)
         if (in_flight.empty()) return;
@@ -166,7 +167,7 @@ void worker_loop(Lane *lane) {
                 sc[(size_t)b] = s.sctx; pcm[(size_t)b] = s.pending.data(); ns[(size_t)b] = (int)s.pending.size();
             }
             const bool ok = nemo_stream_process_batch(sc.data(), B, pcm.data(), ns.data(), out.data());
-            n_batches++; n_batched_streams += (uint64_t)B;
+            n_batches++; n_batched_streams += (uint64_t)B; b_hist[B]++;
             for (int b = 0; b < B; b++) {
                 Session &s = sessions[g.second[(size_t)b]];
                 s.pending.clear();
@@ -239,6 +240,9 @@ void worker_loop(Lane *lane) {
     for (auto &kv : sessions) nemo_stream_free(kv.second.sctx);
     fprintf(stderr, "worker: %llu engine calls, %.2f streams per call\n", (unsigned long long)n_batches,
             n_batches ? (double)n_batched_streams / (double)n_batches : 0.0);
+    std::string h = "worker: B histogram";
+    for (auto &kv : b_hist) h += " " + std::to_string(kv.first) + ":" + std::to_string(kv.second);
+    fprintf(stderr, "%s\n", h.c_str());
 }
 
 bool recv_full(int fd, uint8_t *buf, size_t n) {

@@ -301,6 +301,57 @@ def test_shipped_pipeline_bit_identity_b64_R13_q8_0_24_layers(Q24):
     _assert_modes_identical(res)
 
 
+def test_graph_cache_is_bounded_over_10000_calls_with_random_batches(W2):
+    """A server's batch size changes from call to call (tests/server_load.py: 1 .. 63 streams per engine call with 64 live
+    streams).  With option graph_cache = 4 the engine keeps at most 4 step shapes per slot: over 10 000 pipelined calls with a
+    random subset of 12 streams each, the number of live hipGraphExec objects stays under its bound (and is the same at call
+    2 000 as at call 10 000), shapes are evicted and re-captured, and every stream's tokens equal those of an engine that never
+    evicts; three streams are checked against the oracle."""
+    L, R, S, N = 2, 0, 12, 10000
+    rng = np.random.default_rng(1234)
+    plan = [rng.permutation(S)[:rng.integers(1, S + 1)] for _ in range(N)]
+    pushes = np.zeros(S, np.int64)
+    for sel in plan:
+        pushes[sel] += 1
+    base = [synth.make_pcm(900 + b, 30.0)[:375 * 1280] for b in range(S)]
+    pcms = [np.tile(base[b], int(pushes[b]) // 375 + 1) for b in range(S)]
+    res, counters = {}, {}
+    for cap in (4, 64):
+        eng = capi.Engine(W2, n_layers=L, dtype=capi.DTYPE_F32, max_streams=S)
+        eng.set_option("pipeline", 4)
+        eng.set_option("graph_cache", cap)
+        sts = [eng.stream(R) for _ in range(S)]
+        toks, pos, mid = [[] for _ in range(S)], np.zeros(S, np.int64), None
+        for i, sel in enumerate(plan):
+            out = eng.step([sts[b] for b in sel], [pcms[b][pos[b] * 1280:(pos[b] + 1) * 1280] for b in sel])
+            for b, t in zip(sel, out):
+                toks[b] += t
+            pos[sel] += 1
+            if i == 2000:
+                mid = eng.counter("graph_execs")
+        for b, t in enumerate(eng.finalize(sts)):
+            toks[b] += t
+        counters[cap] = dict(execs_mid=mid, execs_end=eng.counter("graph_execs"), shapes=eng.counter("graph_shapes"),
+                             evictions=eng.counter("graph_evictions"), frames=[s.token_frames() for s in sts[:3]])
+        res[cap] = toks
+        eng.close()
+    _report("graph_cache", {str(k): {kk: vv for kk, vv in v.items() if kk != "frames"} for k, v in counters.items()})
+    c4, c64 = counters[4], counters[64]
+    assert c4["evictions"] > 100 and c64["evictions"] == 0
+    per_shape = 5 * (min(4, L) + 1)                     # NSLOT slots x (encoder pieces: one per layer at most + the decode graph)
+    assert c4["execs_end"] <= 4 * per_shape and c4["execs_mid"] == c4["execs_end"]      # bounded, and flat from call 2 000 to call 10 000
+    assert c64["shapes"] == S and c64["execs_end"] == S * per_shape
+    assert res[4] == res[64] and sum(len(t) for t in res[4]) > 100
+    om = ob.OracleModel(W2, L)
+    for b in range(3):                                    # the first 40 s of three streams against the oracle
+        ost = ob.OracleStream(om, R)
+        ref = ost.process(pcms[b][:500 * 1280])
+        rf = ost.token_frames()
+        n = sum(1 for f in rf if f < 480)
+        got = [t for t, f in zip(res[4][b], c4["frames"][b]) if f < 480]
+        assert got == ref[:n] and n > 0, b
+
+
 def test_reset_reference_mode_keeps_what_the_reference_keeps(W2):
     """nemo_stream_reset as coded (src/nemo-stream.cpp:95-115): conv cache and preprocessor carry survive, K/V contents
     survive but are masked.  Engine (f32) == oracle twin token for token and on the encoder output; and the quirk is

@@ -1,0 +1,50 @@
+"""The product surface of the reference is its multi-stream server (src/nemo-server.cpp:192-271).  tests/server_load.py drives
+nemo-server-amd --pipeline 4 with 16 live streams (real-time paced) and with a burst, on a 24-layer Q8_0 GGUF of the speech
+checkpoint: every stream's transcript must be the phone sequence of its audio (= the oracle's transcript,
+tests/test_speech_checkpoint.py), three of them are checked against the F32 oracle directly, and the report carries aggregate
+RTFx, token latency and the histogram of streams per engine call."""
+import json
+import os
+from pathlib import Path
+
+import pytest
+
+from nemotron_asr_amd import gguf_io, synth
+from oracle import binding as ob
+from tests import server_load as sl
+
+pytestmark = pytest.mark.gpu
+
+
+def test_server_under_load_16_streams(tmp_path):
+    model = sl.write_model(tmp_path / "speech-q8_0.gguf", 24, "q8_0")
+    reports = {}
+    for mode, seconds, R in (("realtime", 8.0, 0), ("burst", 12.0, 13)):
+        sock = str(tmp_path / f"asr-{mode}.sock")
+        proc = sl.start_server(model, sock, 16, 4)
+        try:
+            rep = sl.run_load(sock, 16, seconds, R, mode, n_conns=4)
+        finally:
+            srv, err = sl.stop_server(proc)
+        rep["server"] = srv
+        reports[mode] = rep
+        assert not rep["errors"], rep
+        assert rep["transcripts_correct"] == 16, rep
+        assert srv["engine_calls"] > 0 and sum(srv["b_histogram"].values()) == srv["engine_calls"]
+    assert reports["realtime"]["token_latency_ms"]["p99"] < 250.0, reports["realtime"]       # live streams: text within a quarter second of the audio
+    assert reports["burst"]["aggregate_rtfx"] > 200.0, reports["burst"]
+    d = os.environ.get("NASR_REPORT_DIR")
+    if d:
+        Path(d).mkdir(parents=True, exist_ok=True)
+        (Path(d) / "server_load.json").write_text(json.dumps(reports, indent=1))
+    # three streams against the F32 oracle on the dequantised weights (R = 13: the burst run's lookahead)
+    W = synth.make_weights(24, margins="speech")
+    _, deq = synth.quantize_weights(W, "q8_0")
+    om = ob.OracleModel(deq, 24)
+    vocab = gguf_io.synthetic_vocab()
+    for b in range(3):
+        pcm, ev = synth.make_speech_pcm(b, 12.0)
+        ost = ob.OracleStream(om, 13)
+        ref = ost.process(pcm) + ost.finalize()
+        text = "".join((" " + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t] for t in ref)
+        assert text == sl.expected_text(ev)[0]
