@@ -379,6 +379,12 @@ def main():
     if world > 1 or os.environ.get("NASR_BENCH_FORCE_DIST"):      # the knob exercises the RCCL plumbing on a 1-GPU box
         import torch
         import torch.distributed as dist
+        if "RANK" not in os.environ:                               # the knob without a torchrun environment: a world of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                free_port = sk.getsockname()[1]
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port))
         if args.stub_engine:
             dist.init_process_group("gloo")
         else:
