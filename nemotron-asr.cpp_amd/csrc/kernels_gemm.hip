@@ -613,9 +613,71 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmParams p) {
     }
 }
 
+// The f32 engine at one to four rows (a live stream, a handful of streams): k_gemm_f32 above puts 64 weight rows into a
+// workgroup, i.e. 16-64 workgroups walk 8-16 MB of f32 weights 8 KiB at a time -- 52 ms per 24-layer step at batch 1.  This form
+// gives a workgroup 4 weight rows (256-1024 workgroups), streams them through LDS 1008 k at a time with the next chunk's loads in
+// flight under the current chunk's arithmetic, and keeps k_gemm_f32's arithmetic EXACTLY: every output is one chain
+// acc = fmaf(a[k], w[k], acc) over ascending k from 0.f -- bit-identical results (the f32 engine is the configuration whose
+// tokens and frames equal the oracle's), one lane per (row, weight row).
+constexpr int F32R_NR = 4, F32R_KC = 1008, F32R_PAD = 4, F32R_MMAX = 4;     // 2 x 8 rows x 1012 floats = 64 768 B of static LDS
+constexpr int F32R_LDS = 2 * (F32R_NR + F32R_MMAX) * (F32R_KC + F32R_PAD);
+__global__ __launch_bounds__(256) void k_gemm_f32_rows(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float f32r_lds[F32R_LDS];
+    constexpr int LD = F32R_KC + F32R_PAD;
+    const int tid = threadIdx.x, n0 = blockIdx.x * F32R_NR, M = p.M;
+    const float *W = (const float *)p.W;
+    auto Ws = [&](int buf, int r) { return f32r_lds + (size_t)(buf * (F32R_NR + F32R_MMAX) + r) * LD; };
+    auto As = [&](int buf, int m) { return f32r_lds + (size_t)(buf * (F32R_NR + F32R_MMAX) + F32R_NR + m) * LD; };
+    const int n_chunks = (p.K + F32R_KC - 1) / F32R_KC;
+    float4 wreg[F32R_NR], areg[F32R_MMAX];
+    auto fetch = [&](int c) {
+        const int k = c * F32R_KC + tid * 4;
+        const bool in = tid * 4 < F32R_KC && k < p.K;
+#pragma unroll
+        for (int r = 0; r < F32R_NR; r++) wreg[r] = in ? *(const float4 *)(W + (size_t)(n0 + r) * p.K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < F32R_MMAX; m++)
+            areg[m] = (in && m < M) ? *(const float4 *)((const float *)a_row_ptr(p, m, 4) + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int buf) {
+        if (tid * 4 >= F32R_KC) return;
+#pragma unroll
+        for (int r = 0; r < F32R_NR; r++) *(float4 *)(Ws(buf, r) + tid * 4) = wreg[r];
+#pragma unroll
+        for (int m = 0; m < F32R_MMAX; m++) *(float4 *)(As(buf, m) + tid * 4) = areg[m];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int r = tid & 3, m = tid >> 2;
+    const bool active = tid < 4 * M;
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; c++) {
+        if (c + 1 < n_chunks) fetch(c + 1);
+        if (active) {
+            const int len = min(F32R_KC, p.K - c * F32R_KC);
+            const float4 *w4 = (const float4 *)Ws(c & 1, r), *a4 = (const float4 *)As(c & 1, m);
+#pragma unroll 4
+            for (int k4 = 0; k4 < len / 4; k4++) {
+                const float4 w = w4[k4], a = a4[k4];
+                acc = fmaf(a.x, w.x, acc); acc = fmaf(a.y, w.y, acc); acc = fmaf(a.z, w.z, acc); acc = fmaf(a.w, w.w, acc);
+            }
+        }
+        if (c + 1 < n_chunks) stash((c + 1) & 1);
+        __syncthreads();
+    }
+    const float vp = __shfl_xor(acc, 1);
+    if (active) epi_elem_f32(p, m, n0 + r, acc, vp);
+}
+
 void launch_gemm_f32(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     p.splits = 1;
+    static const bool rows_off = getenv("NASR_F32_ROWS_OFF") != nullptr;      // diagnostic: the 64-row form at every M
+    if (!rows_off && p.M <= F32R_MMAX && p.N % F32R_NR == 0 && p.K % 4 == 0 && p.lda % 4 == 0) {
+        hipLaunchKernelGGL(k_gemm_f32_rows, dim3(p.N / F32R_NR), dim3(256), 0, st, p);
+        return;
+    }
     dim3 grid(p.N / 64, (p.M + 15) / 16);
     hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, st, p);
 }

@@ -168,6 +168,42 @@ def _recv(sock):
 
 
 @pytest.mark.gpu
+def test_cli_runs_the_reference_invocations_unchanged(tmp_path):
+    """A script written for the reference binary keeps working: the invocations of the reference's README.md:14-21 and usage
+    text (src/transcribe_stream.cpp:55-63) -- file and stdin input, chunk_ms 70 / 80, the --cpu / --cuda / --metal backend
+    selectors (accepted, one stderr note each, no effect) -- give the same transcript; --pipeline N (0..4) too."""
+    n_layers = 2
+    W = synth.make_weights(n_layers=n_layers)
+    model = tmp_path / "model.gguf"
+    gguf_io.write_gguf(model, W, gguf_io.default_hparams(n_layers=n_layers), gguf_io.synthetic_vocab())
+    pcm = synth.make_pcm(9, 4.0)
+    audio = tmp_path / "raw-audio.pcm"
+    pcm.tofile(audio)
+    cli = str(BIN / "nemotron-asr-amd")
+
+    def run(args, stdin=None):
+        r = subprocess.run([cli, str(model)] + args, input=stdin, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        return r.stdout.decode(), r.stderr.decode()
+
+    base, _ = run([str(audio), "70", "13", "--f32"])                      # README: ./nemotron-asr.cpp model.gguf raw-audio.pcm 70 13
+    assert len(base.strip()) > 0
+    out, _ = run(["-", "70", "13", "--f32"], stdin=pcm.tobytes())         # README: ffmpeg ... - | ./nemotron-asr.cpp model.gguf - 70 13
+    assert out == base
+    ref80, _ = run([str(audio), "80", "0", "--f32"])                      # usage: model.gguf audio.pcm 80 0
+    for flag in ("--cuda", "--cpu", "--metal"):                           # usage: model.gguf audio.pcm 80 0 --cuda
+        out, err = run([str(audio), "80", "0", flag, "--f32"])
+        assert out == ref80 and f"{flag} ignored" in err
+    for depth in ("0", "1", "2", "3", "4"):
+        out, _ = run([str(audio), "80", "0", "--f32", "--pipeline", depth])
+        assert out == ref80, depth
+    out, _ = run([str(audio), "80", "0", "--pipeline", "--f32"])          # round-2 spelling: a bare --pipeline is depth 1
+    assert out == ref80
+    r = subprocess.run([cli, str(model), str(audio), "80", "0", "--vulkan"], capture_output=True)
+    assert r.returncode == 1 and b"Unknown flag" in r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype_flag,pipeline", [("--f32", 0), (None, 0), ("--f32", 3)])
 def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
     """Wire protocol of the reference server (src/server-protocol.h:24-41) served by the batch-forming worker:
