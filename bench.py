@@ -147,11 +147,11 @@ class _StubEngine:
 
 def pmc_traffic(kernel_symbol_part, tag):
     """HBM bytes per launch of a kernel from the rocprofv3 --pmc passes committed under profiles/ for THIS build
-    (profiles/r2_pmc_traffic_<tag>.json, written by tests/prof_r2.sh: FETCH_SIZE x 2 + WRITE_SIZE as
+    (profiles/r3_pmc_traffic_<tag>.json, written by tests/prof_r3.sh: FETCH_SIZE x 2 + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside this process; null when no
     summary for the configuration / kernel is committed."""
-    f = ROOT / "profiles" / f"r2_pmc_traffic_{tag}.json"
-    if not f.exists():
+    f = next((c for c in (ROOT / "profiles" / f"r3_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r2_pmc_traffic_{tag}.json") if c.exists()), None)
+    if f is None:
         return None
     try:
         ks = json.loads(f.read_text())["kernels"]
@@ -463,8 +463,10 @@ def main():
     run.drain()
     tokens_timed, chunks_timed = run.tokens, run.streams[0].progress().chunks
     head = summarize(regions, args.steps, run.audio_per_step, world)
-    cold = summarize(timed_regions(run, args.steps, barrier, max_over_ranks, repeats=min(3, args.regions), prime=0), args.steps, run.audio_per_step, world)
-    run.drain()
+    cold = head                                # synchronous steps: a region is idle-to-idle already
+    if prime:
+        cold = summarize(timed_regions(run, args.steps, barrier, max_over_ranks, repeats=min(3, args.regions), prime=0), args.steps, run.audio_per_step, world)
+        run.drain()
     host_pcm = None
     if not args.no_host_pcm:
         host_regions = timed_regions(run, args.steps, barrier, max_over_ranks, host=True, repeats=min(3, args.regions), prime=prime)
