@@ -1823,27 +1823,34 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
     if (ge == P.seg_graphs[0].end()) {
         if (pipe_drain(e)) return -1;
         HIPCHK(hipStreamSynchronize(e->st));
-        // bounded cache: a server whose batch size changes from call to call would otherwise keep NSLOT x (E + 1) graph execs per
-        // shape it has ever seen.  Nothing is in flight here (drained above): the slot's least recently used shape goes.
-        while ((int)P.seg_graphs[0].size() >= e->opt_graph_cache) {
-            int64_t victim = 0, oldest = INT64_MAX;
-            for (auto &kv : P.seg_graphs[0]) {
-                auto u = e->graph_used.find(kv.first | ((int64_t)1 << 62));
-                const int64_t t = u == e->graph_used.end() ? 0 : u->second;
-                if (t < oldest) { oldest = t; victim = kv.first; }
+        // A new step shape: capture it for EVERY slot now, in one drained, exclusive section (a step uses the slots in turn: captured
+        // lazily, the next NSLOT - 1 calls would each drain the pipeline and hold the API lock again).
+        // Bounded cache: a server whose batch size changes from call to call would otherwise keep NSLOT x (E + 1) graph execs per
+        // shape it has ever seen.  Nothing is in flight here: the least recently used shape of a full slot goes.
+        for (int q = 0; q < nasr_engine::NSLOT; q++) {
+            if (ensure_pipe(e, q)) return -1;
+            nasr_engine::Pipe &Q = e->pipe[q];
+            if (Q.seg_graphs[0].count(key)) continue;
+            while ((int)Q.seg_graphs[0].size() >= e->opt_graph_cache) {
+                int64_t victim = 0, oldest = INT64_MAX;
+                for (auto &kv : Q.seg_graphs[0]) {
+                    auto u = e->graph_used.find(kv.first | ((int64_t)1 << 62));
+                    const int64_t t = u == e->graph_used.end() ? 0 : u->second;
+                    if (t < oldest) { oldest = t; victim = kv.first; }
+                }
+                for (auto &m : Q.seg_graphs) { auto f = m.find(victim); if (f != m.end()) { if (f->second) hipGraphExecDestroy(f->second); m.erase(f); } }
+                auto f = Q.dec_graphs.find(victim);
+                if (f != Q.dec_graphs.end()) { if (f->second) hipGraphExecDestroy(f->second); Q.dec_graphs.erase(f); }
+                if (q == p) e->graph_evictions++;
             }
-            for (auto &m : P.seg_graphs) { auto f = m.find(victim); if (f != m.end()) { if (f->second) hipGraphExecDestroy(f->second); m.erase(f); } }
-            auto f = P.dec_graphs.find(victim);
-            if (f != P.dec_graphs.end()) { if (f->second) hipGraphExecDestroy(f->second); P.dec_graphs.erase(f); }
-            e->graph_evictions++;
+            hipGraphExec_t gs[nasr_engine::MAXSEG] = {nullptr, nullptr, nullptr, nullptr}, dec = nullptr;
+            {
+                CaptureExclusive alone;
+                if (build_pipe_graphs(e, q, B, T, R, G, nseg, gs, &dec)) return -1;
+            }
+            for (int k = 0; k < nseg; k++) Q.seg_graphs[k][key] = gs[k];
+            Q.dec_graphs[key] = dec;
         }
-        hipGraphExec_t gs[nasr_engine::MAXSEG] = {nullptr, nullptr, nullptr, nullptr}, dec = nullptr;
-        {
-            CaptureExclusive alone;
-            if (build_pipe_graphs(e, p, B, T, R, G, nseg, gs, &dec)) return -1;
-        }
-        for (int k = 0; k < nseg; k++) P.seg_graphs[k][key] = gs[k];
-        P.dec_graphs[key] = dec;
         ge = P.seg_graphs[0].find(key);
     }
     const GraphDescLayout L = graph_desc_layout(B, G);
