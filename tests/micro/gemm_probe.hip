@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
@@ -386,11 +387,166 @@ __global__ __launch_bounds__(1024) void k_probe_roles(GemmParams p, int n_groups
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of chunk i complete before the barrier frees its slot
         }
     }
+    if (p.T == 777) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) sum += acc[j][mt][0] + acc[j][mt][1] + acc[j][mt][2] + acc[j][mt][3];
+        if (sum == 12345.678f) p.out_f32[threadIdx.x] = sum;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
             epi_quad<true>(p, split, m0 + (mh * 4 + mt) * 16 + r, (ntile0 + j) * 16 + q * 4, acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+}
+// mode 10 (round 3): 8 loader waves as in mode 7, but FOUR consumer waves (one per SIMD), each a 64 n x 64 m sub-tile on
+// v_mfma_f32_32x32x16_bf16.  Mode 7's eight consumers (32 n x 64 m on 16x16x32) read 12 KiB of fragments per wave and chunk =
+// 96 KiB per CU; four 64 x 64 sub-tiles read 16 KiB each = 64 KiB, one ds_read_b128 per MFMA (MI355X_MICROARCH.md, LDS: two per
+// 32x32x16 gap are free), and the reads of k-step s + 1 are issued in front of the MFMAs of k-step s, so the loop is bound by its
+// 16 MFMAs per chunk.  Same LDS image (weights in 16 x 32 fragment tiles, activation panel XOR-swizzled): a 32 x 16 operand is
+// assembled from it conflict-free (lanes 0-15 / 16-31 read two neighbouring 16-row tiles, lanes 32-63 the next 8 k).
+__global__ __launch_bounds__(768) void k_probe_roles32(GemmParams p, int n_groups, int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    const int wave12 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool loader = wave12 >= 4;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * split / p.splits), c1 = (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = c1 - c0, m0 = mc * TM;
+    if (loader) {
+        const int wave = wave12 - 4, ng4 = wave & 3, mh = wave >> 2, ntile0 = (ng * 4 + ng4) * 2;
+        const uint4 *wpd = (const uint4 *)p.W + (size_t)(ntile0 + mh) * KT * 64 + lane;
+        const int prow = lane >> 3, pc = lane & 7;
+        const char *asrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = wave * 16 + i * 8 + prow;
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+        }
+        const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+        auto issue = [&](int kc, int slot) {
+            const unsigned sb = ring_base + slot * G2_SLOT;
+#pragma unroll
+            for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+            const unsigned wb = sb + 16384 + ng4 * 4096 + mh * 2048;
+            glds16(wpd + (size_t)(2 * kc) * 64, wb);
+            glds16(wpd + (size_t)(2 * kc + 1) * 64, wb + 1024);
+        };
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (i < nchunks) issue(c0 + i, i);
+        for (int i = 0; i <= nchunks; i++) {
+            if (i < nchunks) {
+                const int rem = nchunks - 1 - i < 2 ? nchunks - 1 - i : 2;
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (i + 3 < nchunks) issue(c0 + i + 3, (i + 3) & 3);
+        }
+        return;
+    }
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    const int nh = wave12 & 1, mh2 = wave12 >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[g][h][v] = 0.f;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    const unsigned w_base = lds0 + 16384 + 2 * nh * 4096 + ((lane >> 4) & 1) * 2048 + hi * 256 + (lane & 15) * 16;
+    const int sw = (l31 >> 1) & 7;
+    unsigned a_base[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) a_base[s] = lds0 + (64 * mh2 + l31) * 128 + (((2 * s + hi) ^ sw) << 4);
+    uint4 X[4], Y[4];           // {W g0, W g1, A h0, A h1} of one 16-deep k-step
+#define RD4(S, wofs0, wofs1, ab)                                      \
+    LDS_RD(S[0], wa, wofs0); LDS_RD(S[1], wa, wofs1);                 \
+    LDS_RD(S[2], ab, 0); LDS_RD(S[3], ab, 4096);
+    auto mm = [&](uint4 (&f)[4]) {
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                acc[g][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[g]), __builtin_bit_cast(bf16x8, f[2 + h]), acc[g][h], 0, 0, 0);
+    };
+    for (int i = 0; i <= nchunks; i++) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned so = (unsigned)(i & 3) * G2_SLOT;
+        const unsigned wa = w_base + so;
+        if (i < nchunks) { const unsigned ab = a_base[0] + so; RD4(X, 0, 4096, ab); }          // k-step 0 -> X
+        __builtin_amdgcn_sched_barrier(0);
+        if (i > 0) mm(Y);                                                                       // k-step 3 of chunk i - 1 (arrived before the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < nchunks) {
+            { const unsigned ab = a_base[1] + so; RD4(Y, 512, 4608, ab); }                      // k-step 1 -> Y
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mm(X);
+            __builtin_amdgcn_sched_barrier(0);
+            { const unsigned ab = a_base[2] + so; RD4(X, 1024, 5120, ab); }                     // k-step 2 -> X
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mm(Y);
+            __builtin_amdgcn_sched_barrier(0);
+            { const unsigned ab = a_base[3] + so; RD4(Y, 1536, 5632, ab); }                     // k-step 3 -> Y
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mm(X);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of chunk i complete before the barrier frees its slot
+        }
+    }
+    if (p.T == 777) {         // loop only: one store that never happens keeps the accumulators alive
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) sum += acc[g][h][v];
+        if (sum == 12345.678f) p.out_f32[threadIdx.x] = sum;
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                epi_quad<true>(p, split, m0 + 64 * mh2 + 32 * h + l31, ng * 128 + 64 * nh + 32 * g + 8 * b + 4 * hi,
+                               acc[g][h][4 * b], acc[g][h][4 * b + 1], acc[g][h][4 * b + 2], acc[g][h][4 * b + 3]);
+}
+static double run_roles32(const GemmParams &p0, hipStream_t st, int reps) {
+    GemmParams p = p0;
+    const int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+    const dim3 grid(n_groups * m_chunks * p.splits);
+    hipFuncSetAttribute((const void *)k_probe_roles32, hipFuncAttributeMaxDynamicSharedMemorySize, G2_NS * G2_SLOT);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_probe_roles32, grid, dim3(768), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    hipEventRecord(a, st);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_roles32, grid, dim3(768), G2_NS * G2_SLOT, st, p, n_groups, m_chunks);
+    hipEventRecord(b, st);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return 1e3 * ms / reps;
 }
 static size_t g_cold_stride = 0;     // > 0: every launch reads its weights from a different part of the pool (cold: from HBM)
 static double run_roles(const GemmParams &p0, hipStream_t st, int reps) {
@@ -438,6 +594,41 @@ int main() {
     char *wpool; hipMalloc(&wpool, pool); hipMemset(wpool, 0x11, pool);
     char *A; hipMalloc(&A, (size_t)M * 4096 * 2); hipMemset(A, 0x22, (size_t)M * 4096 * 2);
     char *out; hipMalloc(&out, (size_t)8 * M * 4096 * 4);
+    if (getenv("PROBE32")) {
+        // exact-arithmetic check of mode 10 against mode 7 (small-integer bf16 operands: every partial sum is exact), then timing
+        std::vector<unsigned short> ha((size_t)M * 4096), hw((size_t)4096 * 4096);
+        unsigned rs = 777;
+        auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; const int v = (int)((rs >> 24) % 7) - 3; float f = (float)v; unsigned u; memcpy(&u, &f, 4); return (unsigned short)(u >> 16); };
+        for (auto &v : ha) v = rnd();
+        for (auto &v : hw) v = rnd();
+        hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(wpool, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+        char *out2; hipMalloc(&out2, (size_t)8 * M * 4096 * 4);
+        for (const Shape &s : shapes) {
+            GemmParams p;
+            memset(&p, 0, sizeof(p));
+            p.A = A; p.W = wpool; p.M = M; p.N = s.N; p.K = s.K; p.lda = s.K; p.splits = s.splits; p.epi = EPI_PART_F32;
+            p.out_f32 = (float *)out; p.ldo = s.N; p.out_act = out; p.ldo_act = s.N;
+            const size_t n_out = (size_t)s.splits * M * s.N;
+            hipMemset(out, 0, n_out * 4); hipMemset(out2, 0xff, n_out * 4);
+            run_roles(p, st, 1);
+            GemmParams p2 = p; p2.out_f32 = (float *)out2;
+            run_roles32(p2, st, 1);
+            std::vector<float> r1(n_out), r2(n_out);
+            hipMemcpy(r1.data(), out, n_out * 4, hipMemcpyDeviceToHost); hipMemcpy(r2.data(), out2, n_out * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0; double mx = 0;
+            for (size_t i = 0; i < n_out; i++) { if (r1[i] != r2[i]) bad++; mx = fabs(r1[i]) > mx ? fabs(r1[i]) : mx; }
+            p.epi = s.epi; p2.epi = s.epi;
+            const double flops = 2.0 * M * s.N * s.K;
+            const double t7 = run_roles(p, st, 200), t10 = run_roles32(p2, st, 200);
+            p.T = 777; p2.T = 777;
+            const double t7n = run_roles(p, st, 200), t10n = run_roles32(p2, st, 200);
+            printf("%-28s loop only (no stores): 8 consumers %6.2f us | 4 consumers (32x32x16) %6.2f us\n", s.name, t7n, t10n);
+            printf("%-28s mismatches %zu of %zu (max |value| %.0f) | loader + 8 consumers (16x16x32) %6.2f us (%5.0f TFLOP/s) | loader + 4 consumers (32x32x16) %6.2f us (%5.0f TFLOP/s)\n",
+                   s.name, bad, n_out, mx, t7, flops / t7 * 1e-6, t10, flops / t10 * 1e-6);
+        }
+        return 0;
+    }
     for (const Shape &s : shapes) {
         GemmParams p;
         memset(&p, 0, sizeof(p));
