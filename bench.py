@@ -518,15 +518,21 @@ def main():
 
     # ---- diarization side-car beside the ASR engine (configs[4]) ---------------------------------------------------------
     def diarization_entry(r, n_ov):
-        # three encoder lanes + the decode stream occupy all four hardware queues of the runtime: the side-car's stream would
-        # share one of them (measured: 8.1 ms per step against 7.1 ms with two lanes).  The ASR engine lends its fourth stream --
-        # a hardware queue of its own -- to the side-car and runs two lanes + the decode stream here.
+        # The ASR engine and the side-car share the runtime's four hardware queues.  The side-car's two networks are independent
+        # of each other (VAD on every 10 ms window, TitaNet-L on 1.5 s sub-segments), so each gets a queue of its own, lent by the
+        # ASR engine (nasr_engine_lend_stream x 2), and a host thread of its own; the ASR engine keeps two lanes (two encoder
+        # pieces, the decode behind the second).  Measured against ONE side-car stream running VAD then embeddings beside three ASR
+        # streams (round 2): 7.1 ms per step -> see `split_streams` in bench_details.json.
+        split = os.environ.get("NASR_DIAR_SPLIT", "1") != "0" and not args.sync_steps
         side_depth = 0 if args.sync_steps else min(args.pipeline_depth, 2)
         r.drain()
         dW = synth.make_diar_weights()
-        deng = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * r.B), device=local_rank)
+        dvad = capi.Diar(dW, dtype=capi.DTYPE_BF16 | (0 if os.environ.get("NASR_DIAR_VAD_F32") else capi.DIAR_VAD_BF16), max_segments=max(8, 2 * r.B), device=local_rank)
+        demb = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * r.B), device=local_rank) if split else dvad
         if side_depth:
-            deng.set_stream(r.eng.lend_stream())       # the fourth stream's hardware queue goes to the side-car
+            dvad.set_stream(r.eng.lend_stream())       # a hardware queue the ASR engine no longer uses
+            if split:
+                demb.set_stream(r.eng.lend_stream())
         r.eng.set_option("pipeline", side_depth)
         hist = 10080 - 160                                   # samples of history a new 10 ms hop needs
         # the side-car reads the SAME s16 PCM the ASR streams were fed, already resident in HBM
@@ -534,33 +540,37 @@ def main():
         vad_n = [hist + r.n_step] * r.B
         n_seg = max(1, int(round(r.B * (r.n_step / synth.SAMPLE_RATE) / 0.75)))                          # sub-segment shift 0.75 s
         seg_ptrs = [r.pcm_dev[i % r.B] + 2 * 12000 * (i // r.B) for i in range(n_seg)]
-        deng.vad_device_s16(vad_ptrs, vad_n); deng.embed_device_s16(seg_ptrs)
+        dvad.vad_device_s16(vad_ptrs, vad_n); demb.embed_device_s16(seg_ptrs)
         reps = 10
         r.eng.synchronize()
         tq = time.perf_counter()
         for _ in range(reps):
-            pv = deng.vad_device_s16(vad_ptrs, vad_n)
+            pv = dvad.vad_device_s16(vad_ptrs, vad_n)
         t_vad = (time.perf_counter() - tq) / reps
         tq = time.perf_counter()
         for _ in range(reps):
-            deng.embed_device_s16(seg_ptrs)
+            demb.embed_device_s16(seg_ptrs)
         t_spk = (time.perf_counter() - tq) / reps
-        # the same work overlapped: the side-car runs on its own HIP stream from a second host thread while the ASR
-        # step of the same audio runs on the engine's stream (ctypes releases the GIL during both calls)
+        # the same work overlapped: the side-car's calls come from their own host threads while the ASR step of the same audio
+        # runs on the engine's streams (ctypes releases the GIL during all of them)
         import threading
-        gate_go, gate_done = threading.Barrier(2), threading.Barrier(2)
+        n_side = 2 if split else 1
+        gate_go, gate_done = threading.Barrier(1 + n_side), threading.Barrier(1 + n_side)
 
-        def side_car():
+        def side_car(which):
             for _ in range(n_ov):
                 gate_go.wait()
-                deng.vad_device_s16(vad_ptrs, vad_n)
-                deng.embed_device_s16(seg_ptrs)
+                if which in (0, 2):
+                    dvad.vad_device_s16(vad_ptrs, vad_n)
+                if which in (1, 2):
+                    demb.embed_device_s16(seg_ptrs)
                 gate_done.wait()
 
         ovs = []
         for _ in range(REPEATS):
-            th = threading.Thread(target=side_car)
-            th.start()
+            ths = [threading.Thread(target=side_car, args=(w,)) for w in ((0, 1) if split else (2,))]
+            for th in ths:
+                th.start()
             r.eng.synchronize()
             tq = time.perf_counter()
             for _ in range(n_ov):
@@ -569,17 +579,20 @@ def main():
                 gate_done.wait()
             r.eng.synchronize()
             ovs.append((time.perf_counter() - tq) / n_ov)
-            th.join()
+            for th in ths:
+                th.join()
         r.drain()
         r.eng.set_option("pipeline", depth)
         t_ov = statistics.median(ovs)
         d = dict(value=round(r.audio_per_step / t_ov, 1), ms_per_step=round(1e3 * t_ov, 3), vad_ms=round(1e3 * t_vad, 3), embed_ms=round(1e3 * t_spk, 3))
         details["diarize"] = dict(runs_ms_per_step=[round(1e3 * x, 3) for x in ovs], steps_per_region=n_ov, vad_windows_per_step=int(sum(x.size for x in pv)),
-                                  embeddings_per_step=n_seg, asr_pipeline_depth=side_depth,
+                                  embeddings_per_step=n_seg, asr_pipeline_depth=side_depth, split_streams=split,
                                   note="side-car (MarbleNet VAD on every 10 ms window + TitaNet-L embeddings of 1.5 s sub-segments at a 0.75 s shift, random-init "
-                                       "weights) on the streams' own s16 PCM, device-resident, on its own HIP stream from a second host thread beside the ASR step; "
-                                       "vad_ms / embed_ms: each call run alone")
-        deng.close()
+                                       "weights) on the streams' own s16 PCM, device-resident; VAD and embeddings each on a HIP stream lent by the ASR engine, "
+                                       "each from its own host thread, beside the ASR step; vad_ms / embed_ms: each call run alone")
+        dvad.close()
+        if split:
+            demb.close()
         return d
 
     diar = None

@@ -235,7 +235,10 @@ int nasr_engine_synchronize(nasr_engine *e);
  * nemotron-asr.cpp_amd/host/diarize_pipeline_amd.h, diarize_cluster_amd.h. */
 typedef struct nasr_diar nasr_diar;
 /* dtype: NASR_DTYPE_BF16 = TitaNet's pointwise convolutions on the bf16 MFMA (f32 accumulate), NASR_DTYPE_F32 = all f32;
- * MarbleNet is always f32.  max_windows / max_segments size the scratch (larger calls are tiled). */
+ * MarbleNet is f32 (P(speech) within 2e-5 of the reference arithmetic) unless NASR_DIAR_VAD_BF16 is OR'ed in: then its pointwise
+ * convolutions run on the bf16 MFMA with bf16 activation planes (3 workgroups per CU instead of 1; P(speech) within a few 1e-3).
+ * max_windows / max_segments size the scratch (larger calls are tiled). */
+#define NASR_DIAR_VAD_BF16 0x100
 int  nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
                       int max_windows, int max_segments);
 void nasr_diar_destroy(nasr_diar *d);

@@ -6,6 +6,7 @@
 // LDS (three [64][129] f32 planes = 97 KiB of the CU's 160 KiB) and the launch covers every window of every stream:
 // the sliding window is a batch dimension.  Activations are [T][C], channels innermost, as the reference feeds ggml.
 #include "nasr_internal.h"
+#include "nasr_epilogue.h"
 #include "nasr_wave.h"
 
 namespace nasr {
@@ -182,6 +183,202 @@ __global__ __launch_bounds__(256) void k_vad_marblenet(VadNet net, const float *
         const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx);
         prob[w] = e1 / (e0 + e1);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MarbleNet on the bf16 MFMA (round 3; nasr_diar_create with NASR_DIAR_VAD_BF16).  The f32 form above is bound by what it
+// issues around its MFMAs (v_mfma_f32_16x16x4_f32 covers 4 k per instruction: 13 instructions per MFMA, 101 KiB of f32 planes =
+// ONE workgroup of four waves per CU, every phase's global weight fetch exposed).  Here the three activation planes are bf16
+// ([64][136]: 52 KiB -> three workgroups per CU), a pointwise conv is v_mfma_f32_16x16x32_bf16 (32 k per instruction, one
+// ds_read_b128 per operand fragment, f32 accumulate, BN / residual / ReLU in f32, rounded to bf16 once per layer output), the
+// depthwise convs accumulate in f32 in the reference's term order.  Same masking semantics (rows >= lens read as zero).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int VPH = VC + 8;        // bf16 elements per LDS row: 272 B, rows 16-byte aligned, 16 consecutive rows on distinct banks
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_d;
+
+template <int K, int DIL, int NF>
+__device__ __forceinline__ void vad_depthwise_h(const bf16_t *x, bf16_t *y, const float *dw, int C, int lens) {
+    constexpr int PAD = DIL * (K - 1) / 2, NIN = NF + (K - 1) * DIL;
+    const int c = threadIdx.x % C, part = threadIdx.x / C;
+    if (part >= VT / NF) return;
+    float wk[K], in[NIN];
+#pragma unroll
+    for (int i = 0; i < K; i++) wk[i] = dw[i * C + c];
+    const int t_lo = part * NF;
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+        const int tt = t_lo + j - PAD;
+        // the row index is clamped BEFORE the load: the planes are reached through flat pointers, and a speculated (if-converted) load of
+        // a row outside the plane would leave the LDS aperture and fault as a global access
+        const int tc = min(max(tt, 0), VT - 1);
+        const float xv = bf16_to_f32(x[tc * VPH + c]);
+        in[j] = (tt >= 0 && tt < lens) ? xv : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < NF; u++) {
+        float acc = in[u] * wk[0];
+#pragma unroll
+        for (int i = 1; i < K; i++) acc += in[u + i * DIL] * wk[i];
+        y[(t_lo + u) * VPH + c] = f32_to_bf16(acc);
+    }
+}
+// the 29-tap, dilation-2 layer: 72 input rows per thread in registers would cost a workgroup its third co-resident partner, so the
+// inputs are read from LDS tap by tap (464 two-byte reads per thread in this ONE phase; taps in registers, same term order)
+template <int K, int DIL, int NF>
+__device__ __forceinline__ void vad_depthwise_wide_h(const bf16_t *x, bf16_t *y, const float *dw, int C, int lens) {
+    constexpr int PAD = DIL * (K - 1) / 2;
+    const int c = threadIdx.x % C, part = threadIdx.x / C;
+    if (part >= VT / NF) return;
+    float wk[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) wk[i] = dw[i * C + c];
+    const int t_lo = part * NF;
+#pragma unroll 2
+    for (int u = 0; u < NF; u++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            const int tt = t_lo + u + i * DIL - PAD;
+            const int tc = min(max(tt, 0), VT - 1);
+            const float xv = bf16_to_f32(x[tc * VPH + c]);
+            acc = fmaf((tt >= 0 && tt < lens) ? xv : 0.0f, wk[i], acc);
+        }
+        y[(t_lo + u) * VPH + c] = f32_to_bf16(acc);
+    }
+}
+__device__ __forceinline__ void vad_depthwise_hh(const bf16_t *x, bf16_t *y, const VadSub &s, int lens) {
+    const int C = s.cin;
+    if (s.kernel == 11) vad_depthwise_h<11, 1, 32>(x, y, s.dw, C, lens);
+    else if (s.kernel == 13 && C == 128) vad_depthwise_h<13, 1, 32>(x, y, s.dw, C, lens);
+    else if (s.kernel == 13) vad_depthwise_h<13, 1, 16>(x, y, s.dw, C, lens);
+    else if (s.kernel == 15) vad_depthwise_h<15, 1, 16>(x, y, s.dw, C, lens);
+    else if (s.kernel == 17) vad_depthwise_h<17, 1, 16>(x, y, s.dw, C, lens);
+    else vad_depthwise_wide_h<29, 2, 16>(x, y, s.dw, C, lens);
+}
+
+// D[o][t] = sum_i W[o][i] * mask(t) x[t][i]; weights packed at upload in 16 x 32 A-fragment order (tile (nt, kt): lane q*16+r holds
+// W[nt*16+r][kt*32+q*8 .. +8), K zero-padded to a multiple of 32: the 80 mel channels become 96, the plane's columns 80..95 are zero)
+template <bool ADD, bool RELU, int KT, int NTW>
+__device__ __forceinline__ void vad_pointwise_h(const bf16_t *x, bf16_t *y, const VadSub &s, int lens) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    const bf16_t *xb = x + r * VPH + q * 8;
+#pragma unroll
+    for (int j = 0; j < NTW; j++) {
+        const int nt = wave * NTW + j;
+        const uint4 *wt = (const uint4 *)s.pw16 + (size_t)nt * KT * 64 + lane;
+        const int o = nt * 16 + q * 4;
+        uint4 wv[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) wv[kt] = wt[(size_t)kt * 64];
+        const float4 sc = *(const float4 *)(s.scale + o), bi = *(const float4 *)(s.bias + o);
+        f32x4_d acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[mt] = (f32x4_d){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                uint4 xv = *(const uint4 *)(xb + mt * 16 * VPH + kt * 32);
+                if (mt * 16 + r >= lens) xv = make_uint4(0u, 0u, 0u, 0u);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_d, wv[kt]), __builtin_bit_cast(bf16x8_d, xv), acc[mt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            bf16_t *dst = y + (mt * 16 + r) * VPH + o;
+            float4 v = make_float4(acc[mt][0] * sc.x + bi.x, acc[mt][1] * sc.y + bi.y, acc[mt][2] * sc.z + bi.z, acc[mt][3] * sc.w + bi.w);
+            if (ADD) {
+                const uint2 old = *(const uint2 *)dst;
+                v.x += __uint_as_float(old.x << 16); v.y += __uint_as_float(old.x & 0xffff0000u);
+                v.z += __uint_as_float(old.y << 16); v.w += __uint_as_float(old.y & 0xffff0000u);
+            }
+            if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            *(uint2 *)dst = pack4_bf16(v.x, v.y, v.z, v.w);
+        }
+    }
+}
+template <bool ADD, bool RELU>
+__device__ __forceinline__ void vad_pointwise_hh(const bf16_t *x, bf16_t *y, const VadSub &s, int lens) {
+    if (s.cin == 80) vad_pointwise_h<ADD, RELU, 3, 2>(x, y, s, lens);
+    else if (s.cin == 128 && s.cout == 64) vad_pointwise_h<ADD, RELU, 4, 1>(x, y, s, lens);
+    else if (s.cin == 64 && s.cout == 64) vad_pointwise_h<ADD, RELU, 2, 1>(x, y, s, lens);
+    else if (s.cin == 64) vad_pointwise_h<ADD, RELU, 2, 2>(x, y, s, lens);
+    else vad_pointwise_h<ADD, RELU, 4, 2>(x, y, s, lens);
+}
+
+__global__ __launch_bounds__(256, 3) void k_vad_marblenet_bf16(VadNet net, const float *shared, const float *edge, const int *win_row,
+                                                            const int *lens_mel, float *prob) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    bf16_t *A = (bf16_t *)lds, *B = A + VT * VPH, *Tm = A + 2 * VT * VPH;
+    __shared__ float mean_s[VC];
+    const int w = blockIdx.x;
+    int lens = lens_mel[w];
+    lens = lens < 0 ? 0 : (lens > VAD_TVALID ? VAD_TVALID : lens);
+    const int row0 = win_row[w];
+    for (int e = threadIdx.x; e < VT * 96; e += 256) {                 // 80 mel channels + 16 zero columns (K padded to 96)
+        const int t = e / 96, c = e - t * 96;
+        float v = 0.0f;
+        if (c < DIAR_NMEL) {
+            if (t < 2) v = edge[((size_t)3 * w + t) * DIAR_NMEL + c];
+            else if (t == 62) v = edge[((size_t)3 * w + 2) * DIAR_NMEL + c];
+            else if (t < 62) v = shared[((size_t)row0 + t) * DIAR_NMEL + c];
+        }
+        A[t * VPH + c] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    bf16_t *in = A, *f1 = B, *f2 = Tm;
+    int si = 0;
+    const int repeat[6] = {1, 2, 2, 2, 1, 1};
+#pragma unroll 1
+    for (int b = 0; b < 6; b++) {
+        const bf16_t *x = in;
+        const bool has_res = b >= 1 && b <= 3;
+        for (int r = 0; r < repeat[b]; r++, si++) {
+            const VadSub &s = net.sub[si];
+            const bf16_t *pin = x;
+            if (s.dw) {
+                vad_depthwise_hh(x, f1, s, lens);
+                __syncthreads();
+                pin = f1;
+            }
+            const bool last = r + 1 == repeat[b];
+            if (!last || !has_res) vad_pointwise_hh<false, true>(pin, f2, s, lens);
+            else vad_pointwise_hh<false, false>(pin, f2, s, lens);
+            __syncthreads();
+            x = f2;
+        }
+        if (has_res) {
+            vad_pointwise_hh<true, true>(in, f2, net.res[b - 1], lens);
+            __syncthreads();
+        }
+        bf16_t *old_in = in;
+        in = f2;
+        f2 = old_in;
+    }
+    A = in;
+    if (threadIdx.x < VC) {
+        float sum = 0.0f;
+        for (int t = 0; t < VT; t++) sum += bf16_to_f32(A[t * VPH + threadIdx.x]);
+        mean_s[threadIdx.x] = sum * (1.0f / (float)VT);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lg[2];
+        for (int k = 0; k < 2; k++) {
+            float v = net.dec_b[k];
+            for (int c = 0; c < VC; c++) v += net.dec_w[k * VC + c] * mean_s[c];
+            lg[k] = v;
+        }
+        const float mx = fmaxf(lg[0], lg[1]);
+        const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx);
+        prob[w] = e1 / (e0 + e1);
+    }
+}
+
+void launch_vad_marblenet_bf16(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
+                               float *prob, int W, hipStream_t st) {
+    if (W <= 0) return;
+    hipLaunchKernelGGL(k_vad_marblenet_bf16, dim3(W), dim3(256), 3 * VT * VPH * 2, st, net, shared, edge, win_row, lens_mel, prob);
 }
 
 void init_diar_kernel_attributes() {

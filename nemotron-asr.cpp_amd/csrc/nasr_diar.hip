@@ -57,6 +57,7 @@ struct nasr_diar {
     VadNet vad{};
     // TitaNet-L
     bool bf16 = true; int esz = 2;
+    bool vad_bf16 = false;           // NASR_DIAR_VAD_BF16: MarbleNet on the bf16 MFMA with bf16 activation planes
     struct SpkSub { float *dw = nullptr; void *pw = nullptr; float *bias = nullptr; int kernel = 1, cin = 0, cin_pad = 0, cout = 0; };
     struct SpkBlock { int repeat = 1; bool residual = false; SpkSub sub[3], res; float *fc1 = nullptr, *fc2 = nullptr; int cin = 0, cout = 0; };
     SpkBlock spk[5];
@@ -152,6 +153,26 @@ std::vector<float> pack_mfma_f32(const std::vector<float> &w, int N, int K) {
     return out;
 }
 
+// pointwise weights [N][K] -> bf16 A-fragment tiles for v_mfma_f32_16x16x32_bf16 (the encoder GEMMs' layout): tile (nt, kt) = 16 rows x
+// 32 k, lane q*16+r holds W[nt*16+r][kt*32+q*8 .. +8); K zero-padded to a multiple of 32; round to nearest even
+std::vector<uint16_t> pack_mfma_bf16_host(const std::vector<float> &w, int N, int K) {
+    const int NT = N / 16, KT = (K + 31) / 32;
+    std::vector<uint16_t> out((size_t)NT * KT * 64 * 8, 0);
+    for (int nt = 0; nt < NT; nt++)
+        for (int kt = 0; kt < KT; kt++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int k = kt * 32 + (lane >> 4) * 8 + j;
+                    if (k >= K) continue;
+                    uint32_t u;
+                    const float f = w[(size_t)(nt * 16 + (lane & 15)) * K + k];
+                    memcpy(&u, &f, 4);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    out[(((size_t)nt * KT + kt) * 64 + lane) * 8 + j] = (uint16_t)(u >> 16);
+                }
+    return out;
+}
+
 int load_vad(nasr_diar *d) {
     if (front_end_constants(d, "vad", &d->vad_fbT, &d->vad_band)) return -1;
     int si = 0;
@@ -173,6 +194,12 @@ int load_vad(nasr_diar *d) {
             const auto *pw = get(d, pre + ".mconv." + std::to_string(pw_i) + ".conv.weight", (size_t)t.cout * cin);
             if (!pw || upload(d, pack_mfma_f32(*pw, t.cout, cin), &p)) return -1;
             vs.pw = p;
+            vs.pw16 = nullptr;
+            if (d->vad_bf16) {
+                uint16_t *p16;
+                if (upload(d, pack_mfma_bf16_host(*pw, t.cout, cin), &p16)) return -1;
+                vs.pw16 = p16;
+            }
             std::vector<float> sc, bi;
             if (fold_bn(d, pre + ".mconv." + std::to_string(bn_i), t.cout, 1e-3f, sc, bi)) return -1;   // Jasper BN eps 1e-3 (:34-36)
             if (upload(d, sc, &p)) return -1;
@@ -187,6 +214,12 @@ int load_vad(nasr_diar *d) {
             const auto *pw = get(d, pre + ".res.0.0.conv.weight", (size_t)t.cout * t.cin);
             if (!pw || upload(d, pack_mfma_f32(*pw, t.cout, t.cin), &p)) return -1;
             vr.pw = p;
+            vr.pw16 = nullptr;
+            if (d->vad_bf16) {
+                uint16_t *p16;
+                if (upload(d, pack_mfma_bf16_host(*pw, t.cout, t.cin), &p16)) return -1;
+                vr.pw16 = p16;
+            }
             std::vector<float> sc, bi;
             if (fold_bn(d, pre + ".res.0.1", t.cout, 1e-3f, sc, bi)) return -1;
             if (upload(d, sc, &p)) return -1;
@@ -296,8 +329,10 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const
     DCHK(hipSetDevice(device_id));
     nasr_diar *d = new nasr_diar();
     d->device = device_id;
-    if (dtype != NASR_DTYPE_BF16 && dtype != NASR_DTYPE_F32) { delete d; return failf("dtype must be NASR_DTYPE_F32 or NASR_DTYPE_BF16"); }
-    d->bf16 = dtype == NASR_DTYPE_BF16;      // TitaNet's pointwise convolutions; MarbleNet is always f32
+    d->vad_bf16 = (dtype & NASR_DIAR_VAD_BF16) != 0;
+    dtype &= ~NASR_DIAR_VAD_BF16;
+    if (dtype != NASR_DTYPE_BF16 && dtype != NASR_DTYPE_F32) { delete d; return failf("dtype must be NASR_DTYPE_F32 or NASR_DTYPE_BF16 (optionally | NASR_DIAR_VAD_BF16)"); }
+    d->bf16 = dtype == NASR_DTYPE_BF16;      // TitaNet's pointwise convolutions; MarbleNet is f32 unless NASR_DIAR_VAD_BF16 is set
     d->esz = d->bf16 ? 2 : 4;
     d->max_windows = std::max(max_windows, 1);
     d->max_segments = std::max(max_segments, 1);
@@ -407,7 +442,7 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     set_audio(d, flags, mp);
     mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band; mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
     launch_diar_frames(mp, d->fr_desc, (int)n_frames, d->fr_mel, d->st);
-    launch_vad_marblenet(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
+    (d->vad_bf16 ? launch_vad_marblenet_bf16 : launch_vad_marblenet)(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
     DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)W * sizeof(float), hipMemcpyDeviceToHost, d->st));
     DCHK(hipStreamSynchronize(d->st));
     for (int b = 0; b < B; b++) {

@@ -251,7 +251,7 @@ void launch_diar_logmel(const DiarMelParams &p, int W, bool per_feature_normaliz
 struct DiarFrameDesc { long long base; int n; int t; };
 void launch_diar_frames(const DiarMelParams &p, const DiarFrameDesc *frames, int n_frames, float *out, hipStream_t st);
 
-struct VadSub { const float *dw, *pw, *scale, *bias; int kernel, dil, cin, cout; };   // dw == nullptr: pointwise only
+struct VadSub { const float *dw, *pw, *scale, *bias; int kernel, dil, cin, cout; const bf16_t *pw16; };   // dw == nullptr: pointwise only; pw16: bf16 fragment tiles (NASR_DIAR_VAD_BF16), else null
 struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blocks, 9 sub-convs, 3 residual paths
     VadSub sub[9];
     VadSub res[3];                // blocks 1..3
@@ -262,6 +262,8 @@ struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blo
 // rows 0, 1, 62 = edge[3 w + {0, 1, 2}] (they see the window's own zero padding / pre-emphasis start), row 63 = 0
 void launch_vad_marblenet(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
                           float *prob, int W, hipStream_t st);
+void launch_vad_marblenet_bf16(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
+                               float *prob, int W, hipStream_t st);       // the same network on the bf16 MFMA, bf16 activation planes
 void init_diar_kernel_attributes();
 
 // TitaNet-L pieces (src/diarize_spk.cpp:320-515); activations [S * 160][C] f32, channels innermost

@@ -14,7 +14,7 @@ from nemotron_asr_amd import capi, synth
 
 B = 64
 W = synth.make_diar_weights()
-for dtype, name in ((capi.DTYPE_BF16, "bf16"), (capi.DTYPE_F32, "f32")):
+for dtype, name in ((capi.DTYPE_BF16 | capi.DIAR_VAD_BF16, "bf16, VAD on the bf16 MFMA"), (capi.DTYPE_BF16, "bf16, VAD f32"), (capi.DTYPE_F32, "f32")):
     eng = capi.Diar(W, dtype=dtype, max_windows=8192, max_segments=96)
     # one ASR step at R = 13 brings 1.12 s of new audio per stream: 112 new VAD windows (plus 0.63 s of history)
     audio = [synth.make_pcm(s, 1.75 + 0.02)[:10080 + 111 * 160].astype(np.float32) / 32768.0 for s in range(B)]

@@ -35,6 +35,28 @@ def test_vad_batched_windows_match_oracle(Wv):
         eng.close()
 
 
+def test_vad_on_the_bf16_mfma_stays_close_to_the_f32_network(Wv):
+    """NASR_DIAR_VAD_BF16 (what bench.py's configs[4] entry runs): MarbleNet's pointwise convolutions on the bf16 MFMA, bf16
+    activation planes.  P(speech) of every window against the oracle's f32 network: stated tolerance 2e-2 absolute (measured
+    below 1e-2 on the synthetic network), same window counts, same handling of short buffers, tiles smaller than the window count."""
+    om = db.DiarModel(Wv)
+    audios = [_audio(1, 10080 + 160 * 137 + 55), _audio(2, 9000), _audio(3, 10080), _audio(4, 10080 + 160 * 300)]
+    ref = [om.vad_batch(a) for a in audios]
+    worst = 0.0
+    for max_windows in (4096, 64):
+        eng = capi.Diar(Wv, dtype=capi.DTYPE_BF16 | capi.DIAR_VAD_BF16, max_windows=max_windows)
+        got = eng.vad(audios)
+        assert [g.size for g in got] == [r.size for r in ref] == [138, 0, 1, 301]
+        for g, r in zip(got, ref):
+            if r.size:
+                worst = max(worst, float(np.abs(g - r).max()))
+        eng.close()
+    assert worst < 2e-2, worst
+    f32 = capi.Diar(Wv, dtype=capi.DTYPE_BF16)            # without the flag MarbleNet stays f32: the 2e-5 parity above
+    assert np.abs(f32.vad(audios)[0] - ref[0]).max() < 2e-5
+    f32.close()
+
+
 @pytest.mark.parametrize("dtype,tol", [(capi.DTYPE_F32, 2e-3), (capi.DTYPE_BF16, 6e-2)])
 def test_speaker_embeddings_match_oracle(dtype, tol):
     """5 sub-segments (full, short, minimal lens) in ONE launch sequence, tiled by max_segments = 2: TitaNet-L embeddings
