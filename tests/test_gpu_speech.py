@@ -127,3 +127,22 @@ def test_config3_q8_0_64_streams_tokens_equal_f32_oracle(WS24):
         logs.append(log)
     del om
     _check(rows, logs, "speech_config3_q8_0", 1000)
+
+
+@pytest.mark.parametrize("R", [1, 6])
+def test_other_lookaheads_bf16_tokens_equal_f32_oracle(WS24, R):
+    """The read-out was fitted on R = 0 and R = 13 features; the two lookaheads in between (160 ms, 560 ms) were never seen by the fit.
+    3 streams x 20 s, bf16, 24 layers: tokens == F32 oracle tokens, the transcript is the phone sequence."""
+    pcms, evs = zip(*[synth.make_speech_pcm(40 + b, 20.0) for b in range(3)])
+    eng = capi.Engine(WS24, n_layers=24, dtype=capi.DTYPE_BF16, max_streams=3)
+    toks, frames = _engine_run(eng, R, list(pcms), pipeline=4)
+    eng.close()
+    om = ob.OracleModel(WS24, 24)
+    rows, logs = [], []
+    for b in range(3):
+        ref, rframes, log = _oracle_run(om, R, pcms[b])
+        assert ref == [synth.phone_token(k) for k, _, _ in evs[b]], b
+        rows.append(dict(stream=b, **ob.token_timing_report(log, ref, rframes, toks[b], frames[b])))
+        logs.append(log)
+    del om
+    _check(rows, logs, f"speech_R{R}_bf16", 100)
