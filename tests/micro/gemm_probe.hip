@@ -585,7 +585,7 @@ template <int MODE> static double run(const GemmParams &p, hipStream_t st, int r
 }
 int main() {
     hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    const int M = 896;
+    const int M = getenv("PROBE_M") ? atoi(getenv("PROBE_M")) : 896;
     struct Shape { const char *name; int N, K, splits, epi; } shapes[] = {
         {"W1   N=4096 K=1024", 4096, 1024, 1, EPI_SILU_ACT}, {"W2   N=1024 K=4096 split 4", 1024, 4096, 4, EPI_PART_F32},
         {"Wo   N=1024 K=1024 split 4", 1024, 1024, 4, EPI_PART_F32}, {"pw1  N=2048 K=1024 split 2", 2048, 1024, 2, EPI_PART_F32}};
@@ -597,6 +597,7 @@ int main() {
     if (getenv("PROBE32")) {
         // exact-arithmetic check of mode 10 against mode 7 (small-integer bf16 operands: every partial sum is exact), then timing
         std::vector<unsigned short> ha((size_t)M * 4096), hw((size_t)4096 * 4096);
+        if (M > 896) { hipFree(A); hipMalloc(&A, (size_t)M * 4096 * 2); hipFree(out); hipMalloc(&out, (size_t)8 * M * 4096 * 4); }
         unsigned rs = 777;
         auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; const int v = (int)((rs >> 24) % 7) - 3; float f = (float)v; unsigned u; memcpy(&u, &f, 4); return (unsigned short)(u >> 16); };
         for (auto &v : ha) v = rnd();
@@ -604,12 +605,13 @@ int main() {
         hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
         hipMemcpy(wpool, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
         char *out2; hipMalloc(&out2, (size_t)8 * M * 4096 * 4);
+        const bool big = M > 896;
         for (const Shape &s : shapes) {
             GemmParams p;
             memset(&p, 0, sizeof(p));
-            p.A = A; p.W = wpool; p.M = M; p.N = s.N; p.K = s.K; p.lda = s.K; p.splits = s.splits; p.epi = EPI_PART_F32;
+            p.A = A; p.W = wpool; p.M = M; p.N = s.N; p.K = s.K; p.lda = s.K; p.splits = big ? 1 : s.splits; p.epi = EPI_PART_F32;
             p.out_f32 = (float *)out; p.ldo = s.N; p.out_act = out; p.ldo_act = s.N;
-            const size_t n_out = (size_t)s.splits * M * s.N;
+            const size_t n_out = (size_t)p.splits * M * s.N;
             hipMemset(out, 0, n_out * 4); hipMemset(out2, 0xff, n_out * 4);
             run_roles(p, st, 1);
             GemmParams p2 = p; p2.out_f32 = (float *)out2;
