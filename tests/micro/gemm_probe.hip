@@ -17,6 +17,7 @@
 #include <vector>
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
+#include "nasr_wave.h"
 using namespace nasr;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -548,6 +549,166 @@ static double run_roles32(const GemmParams &p0, hipStream_t st, int reps) {
     hipEventElapsedTime(&ms, a, b);
     return 1e3 * ms / reps;
 }
+// mode 11 (round 3): PERSISTENT tile loop for GEMMs with several tiles per CU (512 streams: 7; TitaNet-L: 4).  One workgroup per
+// CU walks its tiles; the ring never drains between tiles (the next tile's first chunks land while the current one is multiplied) and
+// the epilogue leaves the critical path: the consumers park a finished tile in a 64 KiB staging tile BESIDE the ring (3 x 32 KiB ring
+// + 64 KiB = the CU's 160 KiB) and four STORER waves write it out in 16 slices, two per chunk interval of the next tile.
+// 16 waves: 0-7 consumers (the shipped 32 n x 64 m tiling), 8-11 loaders (8 LDS-DMA instructions per chunk each), 12-15 storers.
+// Every wave executes the same number of s_barriers: G + 16 (G = chunks of all this workgroup's tiles).
+constexpr int PS_NS = 3, PS_STAGE = PS_NS * G2_SLOT;            // staging tile [128][128] f32, 16-byte column groups XOR-swizzled by the row
+__device__ __forceinline__ unsigned stage_off(int row, int cg) { return PS_STAGE + row * 512 + ((cg ^ (row & 31)) << 4); }
+__global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_groups, int m_chunks) {
+    const bool getenv_silu_storer = p.rows_per_batch == -7;      // probe switch: SiLU in the storer waves instead of the consumers
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int n_tiles = n_groups * m_chunks;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int KT = p.K >> 5, CPT = KT >> 1;                      // chunks per tile (64-deep)
+    const int G = my_tiles * CPT, NB = G + 16;      // the last tile is parked at interval G and drained in intervals G + 1 .. G + 15
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto tile_mn = [&](int i, int &m0, int &ng) { const int id = i * (int)gridDim.x + (int)blockIdx.x; m0 = (id % m_chunks) * TM; ng = id / m_chunks; };
+    if (wave16 >= 8 && wave16 < 12) {
+        // ---------------- loaders ----------------
+        const int lw = wave16 - 8, prow = lane >> 3, pc = lane & 7;
+        int cur_tile = -1;
+        const char *asrc[4];
+        const uint4 *wpd[2];
+        auto set_tile = [&](int i) {
+            int m0, ng;
+            tile_mn(i, m0, ng);
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int row = lw * 32 + a * 8 + prow;
+                int m = m0 + row;
+                if (m >= p.M) m = p.M - 1;
+                asrc[a] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) wpd[j] = (const uint4 *)p.W + (size_t)(ng * 8 + 2 * lw + j) * KT * 64 + lane;
+            cur_tile = i;
+        };
+        auto issue = [&](int g) {
+            const int i = g / CPT, kc = g - i * CPT;
+            if (i != cur_tile) set_tile(i);
+            const unsigned sb = lds0 + (g % PS_NS) * G2_SLOT;
+#pragma unroll
+            for (int a = 0; a < 4; a++) glds16(asrc[a] + (size_t)kc * 128, sb + (lw * 32 + a * 8) * 128);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const unsigned wb = sb + 16384 + lw * 4096 + j * 2048;
+                glds16(wpd[j] + (size_t)(2 * kc) * 64, wb);
+                glds16(wpd[j] + (size_t)(2 * kc + 1) * 64, wb + 1024);
+            }
+        };
+        for (int g = 0; g < PS_NS - 1 && g < G; g++) issue(g);
+        for (int g = 0; g < NB; g++) {
+            if (g < G) {
+                if (G - 1 - g >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // chunk g landed, chunk g + 1 may be in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (g + PS_NS - 1 < G) issue(g + PS_NS - 1);
+        }
+        return;
+    }
+    if (wave16 >= 12) {
+        // ---------------- storers: slices of the tile parked in the staging area ----------------
+        const int sw = wave16 - 12;
+        for (int g = 0; g < NB; g++) {
+            __builtin_amdgcn_s_barrier();
+            if (g < 1) continue;
+            const int u = g - 1, ti = u / CPT - 1, s = u - (u / CPT) * CPT;
+            if (ti < 0 || ti >= my_tiles || s >= 15) continue;      // one slice per chunk interval 1 .. 15 of the next tile (two in the last)
+            int m0, ng;
+            tile_mn(ti, m0, ng);
+            for (int sl = s; sl < (s == 14 ? 16 : s + 1); sl++) {
+                const int row = 8 * sl + 2 * sw + (lane >> 5), cg = lane & 31;
+                const float4 v = *(const float4 *)(ring + stage_off(row, cg));
+                const int m = m0 + row, n0 = ng * 128 + cg * 4;
+                if (p.T == 777) { if (v.x == 12345.678f) p.out_f32[threadIdx.x] = v.x; }
+                else if (p.epi == EPI_SILU_ACT) store_wt_u2((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0, getenv_silu_storer ? pack4_bf16(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)) : pack4_bf16(v.x, v.y, v.z, v.w));
+                else if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
+                else epi_quad<true>(p, 0, m, n0, v.x, v.y, v.z, v.w);
+            }
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int wave = wave16, ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned w_addr = lds0 + 16384 + ng4 * 4096 + lane * 16;
+    unsigned b_addr[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) b_addr[k2] = lds0 + panel_off(mh * 64 + r, k2 * 4 + q);
+    uint4 wA[2], bA[4], wB[2], bB[4];
+    auto mm = [&](uint4 (&w)[2], uint4 (&bv)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[mt]);
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0]), bf, acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1]), bf, acc[1][mt], 0, 0, 0);
+        }
+    };
+    for (int g = 0; g < NB; g++) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned so = (unsigned)(g % PS_NS) * G2_SLOT;
+        if (g < G) {
+            const unsigned wa = w_addr + so, ba = b_addr[0] + so;
+            LDS_RD(wA[0], wa, 0); LDS_RD(wA[1], wa, 2048);
+            LDS_RD(bA[0], ba, 0); LDS_RD(bA[1], ba, 2048); LDS_RD(bA[2], ba, 4096); LDS_RD(bA[3], ba, 6144);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0 && g <= G) mm(wB, bB);                     // second half of chunk g - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0 && g <= G && g % CPT == 0) {               // tile g / CPT - 1 is complete: park it, start the next one from zero
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const int row = (mh * 4 + mt) * 16 + r, cg = (ng4 * 2 + j) * 4 + q;
+                    float4 v = make_float4(acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+                    if (p.epi == EPI_SILU_ACT && !getenv_silu_storer) v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+                    *(float4 *)(ring + stage_off(row, cg)) = v;
+                    acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < G) {
+            const unsigned wa = w_addr + so + 1024, ba = b_addr[1] + so;
+            LDS_RD(wB[0], wa, 0); LDS_RD(wB[1], wa, 2048);
+            LDS_RD(bB[0], ba, 0); LDS_RD(bB[1], ba, 2048); LDS_RD(bB[2], ba, 4096); LDS_RD(bB[3], ba, 6144);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mm(wA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+static double run_persist(const GemmParams &p0, hipStream_t st, int reps) {
+    GemmParams p = p0;
+    const int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+    const int tiles = n_groups * m_chunks;
+    const dim3 grid(tiles < 256 ? tiles : 256);
+    const int lds = PS_STAGE + 65536;
+    hipFuncSetAttribute((const void *)k_probe_persist, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks);
+    hipEventRecord(a, st);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks);
+    hipEventRecord(b, st);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("persist launch error: %s\n", hipGetErrorString(e));
+    return 1e3 * ms / reps;
+}
 static size_t g_cold_stride = 0;     // > 0: every launch reads its weights from a different part of the pool (cold: from HBM)
 static double run_roles(const GemmParams &p0, hipStream_t st, int reps) {
     GemmParams p = p0;
@@ -623,6 +784,20 @@ int main() {
             p.epi = s.epi; p2.epi = s.epi;
             const double flops = 2.0 * M * s.N * s.K;
             const double t7 = run_roles(p, st, 200), t10 = run_roles32(p2, st, 200);
+            if (big && getenv("PROBE_PERSIST")) {
+                hipMemset(out2, 0xff, n_out * 4);
+                GemmParams p3 = p2; p3.epi = EPI_PART_F32;
+                run_persist(p3, st, 1);
+                hipMemcpy(r2.data(), out2, n_out * 4, hipMemcpyDeviceToHost);
+                size_t bad3 = 0;
+                for (size_t i = 0; i < n_out; i++) bad3 += r1[i] != r2[i];
+                p3.epi = s.epi;
+                const double t11 = run_persist(p3, st, 100);
+                if (getenv("PROBE_SILU_STORER")) { GemmParams p4 = p3; p4.rows_per_batch = -7; printf("%-28s PERSISTENT, SiLU in the storers: %6.2f us\n", s.name, run_persist(p4, st, 100)); }
+                p3.T = 777;
+                const double t11n = run_persist(p3, st, 100);
+                printf("%-28s PERSISTENT: mismatches %zu | %6.2f us (%5.0f TFLOP/s) | without stores %6.2f us\n", s.name, bad3, t11, flops / t11 * 1e-6, t11n);
+            }
             p.T = 777; p2.T = 777;
             const double t7n = run_roles(p, st, 200), t10n = run_roles32(p2, st, 200);
             printf("%-28s loop only (no stores): 8 consumers %6.2f us | 4 consumers (32x32x16) %6.2f us\n", s.name, t7n, t10n);
