@@ -85,7 +85,7 @@ def parse(argv=None):
     ap.add_argument("--sync-steps", action="store_true",
                     help="every step returns its own tokens before the next one starts (engine option pipeline = 0); default: "
                          "pipelined steps, the decode graph of step s runs on a second HIP stream beside the encoder graph of step s + 1")
-    ap.add_argument("--pipeline-depth", type=int, default=4, choices=[1, 2, 3, 4],
+    ap.add_argument("--pipeline-depth", type=int, default=4, choices=[1, 2, 3, 4, 8],
                     help="engine option pipeline = E: the encoder in E pieces of L / E layers, piece k of step s beside piece k + 1 of step "
                          "s - 1 ..., the decode of step s - E beside them (1: only the decode beside the next encoder; the engine runs at most as many "
                          "pieces as it finds HIP streams that truly overlap: 4 with the runtime's 4 hardware queues, the decode graphs then run behind the fourth piece)")

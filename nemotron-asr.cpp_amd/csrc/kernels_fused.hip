@@ -116,8 +116,15 @@ __device__ __forceinline__ float dot32(const float *qs, const void *row) {   // 
 // row-staging form's 144 registers of partials out of their allocation: the one-row kernels fit 128 VGPRs = 4 waves per
 // SIMD, so the kernels of up to four launch chains (pipelined steps + decode) are resident on a CU together -- at 228
 // VGPRs two were the limit and a third chain queued behind them.
+#ifndef GRP_OCC
+#define GRP_OCC 4
+#endif
+// The kernel body is a device function with two entry points: k_fused_skinny (one problem per launch) and k_fused_skinny_grp (up
+// to FUSED_GROUP problems per launch, blockIdx.z = problem: the same layer type of several steps in flight, each with its own
+// weights, activations and state -- round 3, tests/micro/dual_probe.hip: two chains of 4-problem launches stream 4.1 TB/s where
+// four chains of 1-problem launches stream 2.45).  Same code per problem: results are bit-identical whichever entry runs it.
 template <int PRO, int MMAX>
-__global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k_fused_skinny(FusedParams p) {
+__device__ __forceinline__ void fused_skinny_body(const FusedParams &p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmParams &g = p.g;
     const int nt = blockIdx.x, split = blockIdx.y;
@@ -664,6 +671,17 @@ __global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k
     STAMP(7);
 }
 
+template <int PRO, int MMAX>
+__global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? 4 : 1) void k_fused_skinny(FusedParams p) {
+    fused_skinny_body<PRO, MMAX>(p);
+}
+template <int PRO, int MMAX>
+__global__ __launch_bounds__(256, (MMAX == 1 && PRO != PRO_ATTN) ? GRP_OCC : 1) void k_fused_skinny_grp(FusedParamsGroup pp) {
+    const FusedParams &p = pp.p[blockIdx.z];
+    if (p.g.M <= 0) return;                       // a stage of the pipeline that holds no step (fill / drain)
+    fused_skinny_body<PRO, MMAX>(p);
+}
+
 void init_fused_kernel_attributes() {   // LN / dwconv row staging can exceed the 64 KiB default dynamic-LDS limit at M = 16
     hipFuncSetAttribute((const void *)k_fused_skinny<PRO_LN, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
     hipFuncSetAttribute((const void *)k_fused_skinny<PRO_DWCONV, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 + 32768 + 16 * D * 4);
@@ -679,6 +697,34 @@ static void launch_fused_m(const FusedParams &p, hipStream_t st, size_t lds) {
     case PRO_ATTN: hipLaunchKernelGGL((k_fused_skinny<PRO_ATTN, MMAX>), dim3(g.N / 128, g.splits), dim3(256), lds, st, p); break;   // (column group, head)
     case PRO_DWCONV: hipLaunchKernelGGL((k_fused_skinny<PRO_DWCONV, MMAX>), grid, dim3(256), lds, st, p); break;
     }
+}
+
+template <int MMAX>
+static void launch_fused_grp_m(const FusedParamsGroup &pp, const FusedParams &p, int n, hipStream_t st, size_t lds) {
+    const GemmParams &g = p.g;
+    dim3 grid(g.N / 16, g.splits, n);
+    switch (p.pro) {
+    case PRO_LN: hipLaunchKernelGGL((k_fused_skinny_grp<PRO_LN, MMAX>), grid, dim3(256), lds, st, pp); break;
+    case PRO_PLAIN: hipLaunchKernelGGL((k_fused_skinny_grp<PRO_PLAIN, MMAX>), grid, dim3(256), 4096, st, pp); break;
+    case PRO_ATTN: hipLaunchKernelGGL((k_fused_skinny_grp<PRO_ATTN, MMAX>), dim3(g.N / 128, g.splits, n), dim3(256), lds, st, pp); break;
+    case PRO_DWCONV: hipLaunchKernelGGL((k_fused_skinny_grp<PRO_DWCONV, MMAX>), grid, dim3(256), lds, st, pp); break;
+    }
+}
+
+// n <= FUSED_GROUP problems of the SAME kind (pro, M, N, K, splits) in one launch; a problem with g.M == 0 is skipped
+void launch_fused_skinny_group(const FusedParamsGroup &pp, int n, hipStream_t st) {
+    int first = -1;
+    for (int i = 0; i < n; i++)
+        if (pp.p[i].g.M > 0) { first = i; break; }
+    if (first < 0) return;
+    const FusedParams &p = pp.p[first];
+    const GemmParams &g = p.g;
+    const int KP = (g.K / g.splits);
+    size_t lds = 4096 + (size_t)16 * KP * 2;
+    if (p.pro == PRO_ATTN) lds += (size_t)(2 * 16 * DH + 16 * KVC) * 4;
+    const bool fits_u2 = p.pro != PRO_DWCONV || (g.K / 32 / g.splits + 3) / 4 <= 2;
+    if (g.M == 1 && fits_u2) launch_fused_grp_m<1>(pp, p, n, st, lds);
+    else launch_fused_grp_m<2>(pp, p, n, st, lds);          // grouped launches exist for M <= 2 only (the engine checks)
 }
 
 void launch_fused_skinny(const FusedParams &p, hipStream_t st) {

@@ -147,7 +147,9 @@ struct nasr_engine {
     // their own HIP streams -- see the comment at pipe_step().  Everything a step in flight owns exists once per slot:
     // workspace set, descriptor blocks, joint.enc buffer, token landing zone, graphs (their kernel arguments point into
     // the slot).  E + 1 steps are in flight; slot of a step = its sequence number mod NSLOT.
-    static const int MAXSEG = 4, NSLOT = MAXSEG + 1;
+    static const int MAXSEG = 4, LSLOT = MAXSEG + 1;     // lanes mode: E + 1 steps in flight, slot = sequence number mod LSLOT
+    static const int GP_C = 2, GP_Y = FUSED_GROUP, GP_S = GP_C * GP_Y;   // grouped mode ("pipeline" = 8): 2 chains x 4 problems per launch = 8 stages
+    static const int NSLOT = GP_S + 3;                    // grouped mode: 8 steps in flight + the one being decoded + the one being collected + one spare
     struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; };
     WS ws[NSLOT];                    // ws[0] = the set the synchronous paths use (mirrored in x, x2, ... below)
     int opt_pipeline = 0;            // 0: synchronous steps; E >= 1: the encoder in E pieces + the decode, each piece one step behind the previous
@@ -173,6 +175,16 @@ struct nasr_engine {
         int T = 0, G = 0, nseg = 0;
         int64_t key = 0;
     } pipe[NSLOT];
+    // grouped pipeline ("pipeline" = 8, one or two rows per step on the fused path): the 8 steps in flight are at 8 stages of 3 layers;
+    // chain c (HIP stream lane[c]) runs stages 4c .. 4c+3, each of its 24 launches per call carrying the same layer kind of FOUR steps
+    struct GpEntry { int slot; int done; };            // a step in flight: its slot, the stages it has completed
+    std::vector<GpEntry> gp_flight;                    // oldest first
+    int64_t gp_calls = 0;
+    int gp_next_slot = 0, gp_dec_pending = -1;          // slot whose decode graph is in flight (collected in the next call)
+    hipEvent_t gp_ev[GP_C][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // chain c has finished the call of that parity
+    bool gp_ev_set[GP_C][2] = {{false, false}, {false, false}};
+    std::map<int64_t, hipGraphExec_t> gp_graphs[NSLOT][GP_C];                   // steady-state graphs by slot of the newest step
+    int64_t gp_steps = 0, gp_graph_chains = 0, gp_eager_chains = 0;
     double host_launch_s = 0, host_wait_s = 0;     // NASR_STATS: host time inside hipGraphLaunch / waiting for the device (pipelined steps)
     int64_t pipe_seq = 0;            // steps launched through the pipeline so far
     bool pipe_ready = false;
@@ -752,10 +764,16 @@ static void engine_destroy_impl(nasr_engine *e) {
         fprintf(stderr, "nasr: graph replays %lld (%lld pipelined), eager steps %lld, decode fallbacks %lld (%lld rounds); pipelined steps: host %.1f us in "
                 "hipGraphLaunch + %.1f us waiting per step\n", (long long)e->graph_replays,
                 (long long)e->pipe_steps, (long long)e->eager_steps, (long long)e->decode_fallbacks, (long long)e->decode_fallback_rounds,
-                e->pipe_steps ? 1e6 * e->host_launch_s / e->pipe_steps : 0.0, e->pipe_steps ? 1e6 * e->host_wait_s / e->pipe_steps : 0.0);
+                e->pipe_steps + e->gp_steps ? 1e6 * e->host_launch_s / (e->pipe_steps + e->gp_steps) : 0.0,
+                e->pipe_steps + e->gp_steps ? 1e6 * e->host_wait_s / (e->pipe_steps + e->gp_steps) : 0.0);
+    if (getenv("NASR_STATS") && e->gp_steps)
+        fprintf(stderr, "nasr: grouped pipeline: %lld steps, chain launches %lld through graphs, %lld eager\n", (long long)e->gp_steps,
+                (long long)e->gp_graph_chains, (long long)e->gp_eager_chains);
     for (auto *s : e->slots) delete s;
     for (void *p : e->allocs) hipFree(p);
     for (auto &kv : e->graphs) hipGraphExecDestroy(kv.second);
+    for (auto &per_slot : e->gp_graphs) for (auto &m : per_slot) for (auto &kv : m) if (kv.second) hipGraphExecDestroy(kv.second);
+    for (auto &ce : e->gp_ev) for (auto &ev : ce) if (ev) hipEventDestroy(ev);
     for (int k = 1; k < nasr_engine::MAXSEG; k++) if (e->lane[k]) hipStreamSynchronize(e->lane[k]);
     for (int p = 0; p < nasr_engine::NSLOT; p++) {
         nasr_engine::Pipe &P = e->pipe[p];
@@ -941,7 +959,9 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
 // ---- small-M form of the 24 layers: 8 launches per layer (kernels_fused.hip) ------------------------
 // launches [k0, k1) of the 8 x n_layers launches of the fused layers: a piece boundary may sit inside a layer (every
 // intermediate lives in the step's workspace set), so the pieces of a pipelined step can be balanced to a launch
-static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G, int k0, int k1) {
+// rec != null: the launches are RECORDED (their parameters appended to *rec) instead of launched, and the closing k_post of the
+// last layer is left out (the grouped pipeline launches several steps' records together, then calls this with k0 == k1 == 8 nL for it)
+static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, int G, int k0, int k1, std::vector<FusedParams> *rec = nullptr) {
     const int TS = G * T;                      // rows per stream in this launch (G chunks batched)
     const int M = B * TS, nL = e->hp.n_layers, ks = e->hp.kernel_size;
     hipStream_t st = e->st;
@@ -955,6 +975,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
     auto launch = [&](FusedParams &f, const char *name, double bytes, double flops) {
         const int k = kidx++;
         if (k < k0 || k >= k1) return;                          // another piece's launch
+        if (rec) { rec->push_back(f); return; }
         ProfScope ps(e, name, bytes, flops);
 #ifdef NASR_STAMPS
         f.stamps = stamp_buf + (size_t)k * 32;
@@ -1054,7 +1075,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         launch(f, "k_fused_plain_gemm", wbytes(D, FF), 2.0 * M * D * FF);
         prev_splits = 4;
     }
-    if (k1 < 8 * nL) return 0;                 // the next piece's first kernel picks the intermediates up
+    if (k1 < 8 * nL || rec) return 0;          // the next piece's first kernel picks the intermediates up
     // x = norm_out(x + 0.5 * FFN2) of the last layer (cur is back at X[0] = e->x: 4 flips per layer)
     cur = 0;
     PostParams q;
@@ -1074,8 +1095,9 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
 // seg / nseg: piece `seg` of `nseg` of the encoder (pipelined steps capture every piece into its own graph): piece k covers
 // layers [L k / nseg, L (k + 1) / nseg); piece 0 starts with the subsampling, the last piece ends with prompt fusion and
 // joint.enc.  nseg = 1: the whole encoder.
+// part: 0 = the piece as described; 1 = the front end only (subsampling: no layers, no tail); 2 = the tail only (prompt fusion, joint.enc)
 static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, const int *tap_slots, int B, int T, int R, int G = 1, int seg = 0,
-                           int nseg = 1) {
+                           int nseg = 1, int part = 0) {
     const int Bs = B * G;                      // subsampling batch: one entry per (stream, chunk)
     const int M = Bs * T;
     const int chunk_mel = PRE_CACHE + 8 * (1 + R);
@@ -1103,7 +1125,7 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
         return std::max(1, nLayers * k / nseg - shift);
     };
     const int l0 = bound(seg), l1 = bound(seg + 1);
-    const bool front = seg == 0, tail = seg == nseg - 1;
+    const bool front = part == 0 ? seg == 0 : part == 1, tail = part == 0 ? seg == nseg - 1 : part == 2;
     GemmParams g;
 
     // debug taps are indexed by slot: [slot][TMAX][1024] (+ layers)
@@ -1148,7 +1170,9 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     const bool fused = e->bf16 && e->opt_fused && !e->debug && M <= fused_rows;
     const int TS = G * T;                      // rows per stream in this launch
     if (G > 1 && e->debug) return fail("internal: multi-chunk steps are not available in debug mode");
-    if (fused) {
+    if (part != 0) {
+        // front end or tail only: the layers are launched by the caller (grouped pipeline)
+    } else if (fused) {
         // pieces of the fused path can be cut at any launch: the first one also carries the front end (about 8 launches' worth
         // of time), the last one the joint's encoder projection.  Three pieces: 57 + 69 + 66 launches of 192.  Worth little:
         // batch 1 0.492-0.497 ms per step against 0.498-0.500 at 7 + 9 + 8 layers (56 + 72 + 64) -- with three lanes the step is
@@ -1469,7 +1493,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         ApiGuard api_guard;
         HIPCHK(hipSetDevice(e->device));
         if (pipe_drain(e)) return -1;
-        if (value < 0 || value > nasr_engine::MAXSEG) return fail("pipeline must be 0 .. %d", (int)nasr_engine::MAXSEG);
+        if ((value < 0 || value > nasr_engine::MAXSEG) && value != nasr_engine::GP_S) return fail("pipeline must be 0 .. %d, or %d (grouped)", (int)nasr_engine::MAXSEG, (int)nasr_engine::GP_S);
         e->opt_pipeline = value;
     }
     else if (!strcmp(key, "lanes")) {
@@ -1797,11 +1821,13 @@ static int pipe_finish(nasr_engine *e, int p) {
 }
 
 // completes whatever the pipeline has in flight, oldest step first (tokens stay queued on their streams); cheap when nothing is
+static int gp_drain(nasr_engine *e);
 static int pipe_drain(nasr_engine *e) {
     if (!e->pipe_ready) return 0;
-    for (int64_t q = e->pipe_seq - nasr_engine::NSLOT; q < e->pipe_seq; q++) {
+    if (gp_drain(e)) return -1;
+    for (int64_t q = e->pipe_seq - nasr_engine::LSLOT; q < e->pipe_seq; q++) {
         if (q < 0) continue;
-        const int p = (int)(q % nasr_engine::NSLOT);
+        const int p = (int)(q % nasr_engine::LSLOT);
         if (e->pipe[p].stage != 0 && e->pipe[p].seq == q && pipe_finish(e, p)) return -1;
     }
     return 0;
@@ -1810,13 +1836,13 @@ static int pipe_drain(nasr_engine *e) {
 static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev, const int32_t *n_samples, int G,
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
-    if (ensure_pipe(e, (int)(e->pipe_seq % nasr_engine::NSLOT))) return -1;     // also picks the lanes
+    if (ensure_pipe(e, (int)(e->pipe_seq % nasr_engine::LSLOT))) return -1;     // also picks the lanes
     const int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, e->max_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
     const int64_t seq = e->pipe_seq;
-    const int p = (int)(seq % nasr_engine::NSLOT);
+    const int p = (int)(seq % nasr_engine::LSLOT);
     if (ensure_pipe(e, p)) return -1;
     nasr_engine::Pipe &P = e->pipe[p];
-    if (pipe_finish(e, p)) return -1;                      // the slot's previous occupant (NSLOT steps ago): done in steady state
+    if (pipe_finish(e, p)) return -1;                      // the slot's previous occupant (LSLOT steps ago): done in steady state
     const int64_t key = ((int64_t)B << 40) | ((int64_t)T << 24) | ((int64_t)G << 8) | (int64_t)nseg;
     auto ge = P.seg_graphs[0].find(key);
     e->graph_used[key | ((int64_t)1 << 62)] = ++e->graph_tick;
@@ -1827,7 +1853,7 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
         // lazily, the next NSLOT - 1 calls would each drain the pipeline and hold the API lock again).
         // Bounded cache: a server whose batch size changes from call to call would otherwise keep NSLOT x (E + 1) graph execs per
         // shape it has ever seen.  Nothing is in flight here: the least recently used shape of a full slot goes.
-        for (int q = 0; q < nasr_engine::NSLOT; q++) {
+        for (int q = 0; q < nasr_engine::LSLOT; q++) {
             if (ensure_pipe(e, q)) return -1;
             nasr_engine::Pipe &Q = e->pipe[q];
             if (Q.seg_graphs[0].count(key)) continue;
@@ -1896,7 +1922,7 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
     int fin[nasr_engine::MAXSEG], nfin = 0;                // steps that have had all their pieces: decoded in this call, oldest first
     for (int k = nasr_engine::MAXSEG; k >= 1; k--) {
         if (k > seq) continue;
-        const int q = (int)((seq - k) % nasr_engine::NSLOT);
+        const int q = (int)((seq - k) % nasr_engine::LSLOT);
         const nasr_engine::Pipe &Q = e->pipe[q];
         if (Q.stage != 0 && Q.seq == seq - k && Q.stage >= Q.nseg) fin[nfin++] = q;
     }
@@ -1904,7 +1930,7 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
     for (int i = 0; i < nfin; i++)
         if (dec_behind_last_piece(e, e->pipe[fin[i]]) && pipe_finish_launch(e, fin[i])) return -1;
     for (int k = 1; k <= nasr_engine::MAXSEG && k <= seq; k++) {
-        const int q = (int)((seq - k) % nasr_engine::NSLOT);
+        const int q = (int)((seq - k) % nasr_engine::LSLOT);
         nasr_engine::Pipe &Q = e->pipe[q];
         if (Q.stage == 0 || Q.seq != seq - k) continue;
         if (Q.stage < Q.nseg) { if (pipe_advance(e, q)) return -1; }
@@ -1913,6 +1939,289 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
         if (pipe_finish(e, fin[i])) return -1;
     e->graph_replays++;
     e->pipe_steps++;
+    deliver(streams, B, tokens_out, tokens_cap, n_tokens);
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Grouped pipeline ("pipeline" = 8; fused path, one or two rows per step).  tests/micro/dual_probe.hip: four chains of one-problem
+// launches (the lanes above) stream 2.45 TB/s of weights, two chains of FOUR-problem launches 4.1 TB/s -- twice the bytes in flight
+// per launch boundary.  The 24 layers are 8 stages of 3; a step advances one stage per call, so 8 steps are in flight; chain c (HIP
+// stream lane[c]) runs stages 4c .. 4c+3 and each of its 24 launches per call carries the same kernel of FOUR steps at four different
+// layers (k_fused_skinny_grp: blockIdx.z = problem).  Chain 0 also carries the newest step's front end, chain 1 the oldest step's
+// closing k_post + joint.enc and, behind them, its decode graph.  Per problem the code and the order of operations are those of the
+// one-problem kernels: tokens, caches and decoder state are bit-identical to synchronous stepping (tests).  Tokens come out 8 calls
+// later; every entry point that needs finished steps drains (bubbles run through the remaining stages).
+// ---------------------------------------------------------------------------------------------------------------------------
+static bool gp_eligible(const nasr_engine *e, int B, int T, int G) {
+    static const int fuse_max_m = getenv("NASR_FUSE_MAXM") ? atoi(getenv("NASR_FUSE_MAXM")) : 2;
+    return e->opt_pipeline == nasr_engine::GP_S && e->bf16 && e->opt_fused && !e->debug && B * T * G <= std::min(2, fuse_max_m) &&
+           e->hp.n_layers % nasr_engine::GP_S == 0 && e->hp.num_prompts == 0 && e->n_lanes >= nasr_engine::GP_C && e->max_lanes >= nasr_engine::GP_C;
+}
+
+// everything chain c does in one call; slot_of_stage[j] = slot of the step at stage j, or -1.  Launches go to e->st (the caller
+// captures them or has pointed e->st at the chain's stream).
+static int gp_enqueue_chain(nasr_engine *e, int c, const int *slot_of_stage, int B, int T, int R, int G) {
+    const int nL = e->hp.n_layers, per_stage = 8 * nL / nasr_engine::GP_S;
+    float *const encproj_saved = e->encproj;
+    const GraphDescLayout L = graph_desc_layout(B, G);
+    int rc = 0;
+    if (c == 0 && slot_of_stage[0] >= 0) {                       // the newest step: descriptors, mel, subsampling
+        nasr_engine::Pipe &P = e->pipe[slot_of_stage[0]];
+        const RowDesc *g_rows = (const RowDesc *)(P.g_desc + L.rows), *g_vrows = (const RowDesc *)(P.g_desc + L.vrows);
+        use_ws(e, e->ws[slot_of_stage[0]]);
+        HIPCHK(hipMemcpyAsync(P.g_desc, P.gh, L.total, hipMemcpyHostToDevice, e->st));
+        MelParams mp;
+        memset(&mp, 0, sizeof(mp));
+        mp.desc = (const PcmDesc *)(P.g_desc + L.pcm); mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
+        mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
+        launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
+        rc = enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, 0, 1, 1);
+    }
+    std::vector<FusedParams> rec[nasr_engine::GP_Y];
+    for (int y = 0; y < nasr_engine::GP_Y && !rc; y++) {
+        const int j = c * nasr_engine::GP_Y + y, slot = slot_of_stage[j];
+        if (slot < 0) continue;
+        nasr_engine::Pipe &P = e->pipe[slot];
+        use_ws(e, e->ws[slot]);
+        rc = run_layers_fused(e, (const RowDesc *)(P.g_desc + L.rows), B, T, G, per_stage * j, per_stage * (j + 1), &rec[y]);
+        if (!rc && (int)rec[y].size() != per_stage) rc = fail("internal: grouped pipeline expects %d launches per stage, got %d", per_stage, (int)rec[y].size());
+    }
+    for (int i = 0; i < per_stage && !rc; i++) {
+        FusedParamsGroup grp;
+        memset(&grp, 0, sizeof(grp));
+        for (int y = 0; y < nasr_engine::GP_Y; y++)
+            if (!rec[y].empty()) grp.p[y] = rec[y][(size_t)i];           // an empty stage keeps g.M == 0: skipped by the kernel
+        launch_fused_skinny_group(grp, nasr_engine::GP_Y, e->st);
+    }
+    if (!rc && c == nasr_engine::GP_C - 1 && slot_of_stage[nasr_engine::GP_S - 1] >= 0) {       // the oldest step: norm_out of layer 24, joint.enc
+        const int slot = slot_of_stage[nasr_engine::GP_S - 1];
+        nasr_engine::Pipe &P = e->pipe[slot];
+        const RowDesc *g_rows = (const RowDesc *)(P.g_desc + L.rows);
+        use_ws(e, e->ws[slot]);
+        e->encproj = P.encproj;
+        rc = run_layers_fused(e, g_rows, B, T, G, 8 * nL, 8 * nL);
+        if (!rc) rc = enqueue_encoder(e, g_rows, g_rows, nullptr, B, T, R, G, 0, 1, 2);
+    }
+    e->encproj = encproj_saved;
+    use_ws(e, e->ws[0]);
+    return rc ? -1 : 0;
+}
+
+static int gp_capture(nasr_engine *e, hipGraphExec_t *out, const std::function<int()> &body, hipStream_t st) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+    if (ce != hipSuccess) return fail("hipStreamEndCapture (grouped pipeline) failed: %s", hipGetErrorString(ce));
+    hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ie != hipSuccess) return fail("hipGraphInstantiate (grouped pipeline) failed: %s", hipGetErrorString(ie));
+    return 0;
+}
+
+// the decode graph of slot p (same content as the lanes mode's)
+static int gp_decode_graph(nasr_engine *e, int p, int B, int T, int G, hipGraphExec_t *out) {
+    nasr_engine::Pipe &P = e->pipe[p];
+    const GraphDescLayout L = graph_desc_layout(B, G);
+    const RowDesc *g_rows = (const RowDesc *)(P.g_desc + L.rows);
+    hipStream_t cs = e->lane[nasr_engine::GP_C - 1];
+    return gp_capture(e, out, [&]() -> int {
+        HIPCHK(hipMemcpyAsync(P.g_dmeta, P.gh_dmeta, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, cs));
+        DecParams dp;
+        make_dec_params(e, g_rows, B, T * G, dp);
+        dp.encproj = P.encproj;
+        launch_decode_begin(dp, cs);
+        int it = 0;
+        for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, cs);
+        hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, cs, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, cs));
+        return 0;
+    }, cs);
+}
+
+// one call of the grouped pipeline: every step in flight advances one stage (new_slot >= 0: a new step enters at stage 0); the step
+// that leaves the last stage is decoded and its tokens are queued on its streams
+static int gp_finish_decode(nasr_engine *e);
+static int gp_call(nasr_engine *e, int new_slot, int64_t key, int B, int T, int R, int G) {
+    constexpr int S = nasr_engine::GP_S, C = nasr_engine::GP_C;
+    if (new_slot >= 0) e->gp_flight.push_back({new_slot, 0});
+    if (e->gp_flight.empty()) return 0;
+    int slot_of_stage[S];
+    for (int j = 0; j < S; j++) slot_of_stage[j] = -1;
+    for (const auto &en : e->gp_flight) slot_of_stage[en.done] = en.slot;
+    bool full = new_slot >= 0;
+    for (int j = 0; j < S && full; j++) full = slot_of_stage[j] == (new_slot - j + 2 * nasr_engine::NSLOT) % nasr_engine::NSLOT;
+    const int par = (int)(e->gp_calls & 1);
+    for (int c = 0; c < C; c++) {
+        bool any = c == 0 ? slot_of_stage[0] >= 0 : false;
+        for (int y = 0; y < nasr_engine::GP_Y; y++) any |= slot_of_stage[c * nasr_engine::GP_Y + y] >= 0;
+        if (!any) { e->gp_ev_set[c][par] = false; continue; }
+        if (c > 0 && e->gp_ev_set[c - 1][par ^ 1] && hipEventQuery(e->gp_ev[c - 1][par ^ 1]) != hipSuccess) {
+            // stage 4c of this call reads what stage 4c - 1 wrote in the previous call on the other chain: normally long done; the HOST
+            // waits if not (a pending cross-queue barrier packet slows every queue's dispatch: lanes mode, tests/micro/pipe_probe.hip)
+            HostTimer ht(e->host_wait_s);
+            HIPCHK(hipEventSynchronize(e->gp_ev[c - 1][par ^ 1]));
+        }
+        hipGraphExec_t ex = nullptr;
+        if (full) {
+            auto &m = e->gp_graphs[new_slot][c];
+            auto it = m.find(key);
+            if (it != m.end()) ex = it->second;
+        }
+        if (ex) {
+            HostTimer ht(e->host_launch_s);
+            HIPCHK(hipGraphLaunch(ex, e->lane[c]));
+            e->gp_graph_chains++;
+        } else {
+            e->gp_eager_chains++;                                                     // fill, drain, or a shape not captured yet: the same launches, eagerly
+            hipStream_t keep = e->st;
+            e->st = e->lane[c];
+            const int rc = gp_enqueue_chain(e, c, slot_of_stage, B, T, R, G);
+            e->st = keep;
+            if (rc) return -1;
+        }
+        HIPCHK(hipEventRecord(e->gp_ev[c][par], e->lane[c]));
+        e->gp_ev_set[c][par] = true;
+    }
+    e->gp_calls++;
+    for (auto &en : e->gp_flight) en.done++;
+    // The decode launched in the PREVIOUS call is completed now -- after this call's chains have been queued, so the device is never
+    // idle while the host waits -- and only then the decode of the step that has just left the encoder is launched (its token
+    // gather needs the read position the previous decode's tokens have moved).  It runs behind chain C - 1 and is collected next call.
+    if (gp_finish_decode(e)) return -1;
+    if (!e->gp_flight.empty() && e->gp_flight.front().done >= S) {
+        const int p = e->gp_flight.front().slot;
+        e->gp_flight.erase(e->gp_flight.begin());
+        nasr_engine::Pipe &P = e->pipe[p];
+        const int nB = (int)P.streams.size();
+        hipStream_t ds = e->lane[C - 1];
+        for (int b = 0; b < nB; b++) { P.gh_dmeta[b] = P.streams[b]->slot; P.gh_dmeta[nB + b] = P.streams[b]->tok_read; }
+        { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.dec_graphs[P.key], ds)); }
+        HIPCHK(hipEventRecord(P.dec_done, ds));
+        e->gp_dec_pending = p;
+    }
+    return 0;
+}
+
+// completes the decode that is in flight (launched one call earlier), queues its tokens on its streams
+static int gp_finish_decode(nasr_engine *e) {
+    if (e->gp_dec_pending < 0) return 0;
+    nasr_engine::Pipe &P = e->pipe[e->gp_dec_pending];
+    e->gp_dec_pending = -1;
+    const int nB = (int)P.streams.size();
+    hipStream_t ds = e->lane[nasr_engine::GP_C - 1];
+    { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.dec_done)); }
+    int *gh_active = P.gh_collect + (size_t)nB * (1 + COLLECT_STRIDE);
+    if (*gh_active != 0) {                                      // a burst beyond the graph's iteration budget: finish eagerly
+        const GraphDescLayout L = graph_desc_layout(nB, P.G);
+        DecParams dp;
+        make_dec_params(e, (const RowDesc *)(P.g_desc + L.rows), nB, P.T * P.G, dp);
+        dp.encproj = P.encproj;
+        int itn = pipe_blind_iterations(P.T * P.G), round = 8;
+        e->decode_fallbacks++;
+        for (;;) {
+            e->decode_fallback_rounds++;
+            enqueue_decode_iters(e, dp, nB, round, itn, ds);
+            HIPCHK(hipMemcpyAsync(gh_active, e->n_active, sizeof(int), hipMemcpyDeviceToHost, ds));
+            HIPCHK(hipStreamSynchronize(ds));
+            if (*gh_active == 0) break;
+            if (itn > P.T * P.G * MAX_SYMBOLS + 64) return fail("decode did not terminate");
+            round = std::min(2 * round, 32);
+        }
+        hipLaunchKernelGGL(k_collect, dim3(nB), dim3(64), 0, ds, P.g_dmeta, P.g_dmeta + nB, nB, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
+        HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)nB * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, ds));
+        HIPCHK(hipStreamSynchronize(ds));
+    }
+    return consume_collect(e, P.gh_collect, P.streams.data(), nB);
+}
+
+static int gp_drain(nasr_engine *e) {
+    while (!e->gp_flight.empty()) {
+        nasr_engine::Pipe &P = e->pipe[e->gp_flight.front().slot];
+        if (gp_call(e, -1, P.key, (int)P.streams.size(), P.T, P.streams[0]->R, P.G)) return -1;
+    }
+    return gp_finish_decode(e);
+}
+
+static int gp_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t *const *pcm_dev, const int32_t *n_samples, int G,
+                   int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
+    const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
+    const int64_t key = ((int64_t)B << 40) | ((int64_t)T << 24) | ((int64_t)G << 8) | (int64_t)nasr_engine::GP_S;
+    // lanes-mode steps in flight, or grouped steps of another shape or other streams: complete them first
+    for (int q = 0; q < nasr_engine::LSLOT; q++)
+        if (e->pipe[q].stage != 0) { if (pipe_drain(e)) return -1; break; }
+    if (!e->gp_flight.empty()) {
+        nasr_engine::Pipe &O = e->pipe[e->gp_flight.back().slot];
+        bool same = O.key == key && (int)O.streams.size() == B;
+        for (int b = 0; b < B && same; b++) same = O.streams[(size_t)b] == streams[b];
+        if (!same && gp_drain(e)) return -1;
+    }
+    const int p = e->gp_next_slot;
+    e->gp_next_slot = (p + 1) % nasr_engine::NSLOT;
+    if (ensure_pipe(e, p)) return -1;
+    for (auto &ce : e->gp_ev)
+        for (auto &ev : ce)
+            if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    nasr_engine::Pipe &P = e->pipe[p];
+    e->graph_used[key | ((int64_t)1 << 62)] = ++e->graph_tick;
+    if (!P.dec_graphs.count(key)) {                                  // a new shape: every slot's decode graph and chain graphs, once
+        if (gp_drain(e)) return -1;
+        for (int c = 0; c < nasr_engine::GP_C; c++) HIPCHK(hipStreamSynchronize(e->lane[c]));
+        CaptureExclusive alone;
+        for (int q = 0; q < nasr_engine::NSLOT; q++) {
+            if (ensure_pipe(e, q)) return -1;
+            if (e->pipe[q].dec_graphs.count(key)) continue;
+            hipGraphExec_t dec = nullptr;
+            if (gp_decode_graph(e, q, B, T, G, &dec)) return -1;
+            e->pipe[q].dec_graphs[key] = dec;
+        }
+        for (int q = 0; q < nasr_engine::NSLOT; q++) {
+            int sos[nasr_engine::GP_S];
+            for (int j = 0; j < nasr_engine::GP_S; j++) sos[j] = (q - j + 2 * nasr_engine::NSLOT) % nasr_engine::NSLOT;
+            for (int c = 0; c < nasr_engine::GP_C; c++) {
+                hipGraphExec_t ex = nullptr;
+                if (gp_capture(e, &ex, [&]() -> int { return gp_enqueue_chain(e, c, sos, B, T, R, G); }, e->st)) return -1;
+                e->gp_graphs[q][c][key] = ex;
+            }
+        }
+    }
+    const GraphDescLayout L = graph_desc_layout(B, G);
+    RowDesc *gh_rows = (RowDesc *)(P.gh + L.rows), *gh_vrows = (RowDesc *)(P.gh + L.vrows);
+    PcmDesc *gh_pcm = (PcmDesc *)(P.gh + L.pcm);
+    for (int b = 0; b < B; b++) {
+        nasr_stream *s = streams[b];
+        PcmDesc &d = gh_pcm[b];
+        memset(&d, 0, sizeof(d));
+        d.pcm = pcm_dev[b]; d.slot = s->slot; d.n = n_samples[b]; d.cnt = s->abuf_cnt; d.par = s->abuf_par;
+        const int avail = d.cnt + d.n;
+        d.n_frames = avail < NFFT ? 0 : (avail - NFFT + HOP) / HOP;
+        d.mel_wpos = (s->mel_start + s->mel_count) & (MEL_RING - 1);
+        d.consumed = d.n_frames * HOP;
+        fill_row_desc(gh_rows[b], s, T * G);
+        for (int g = 0; g < G; g++) {
+            RowDesc &v = gh_vrows[b * G + g];
+            v = gh_rows[b];
+            v.mel_start = (s->mel_start + g * shift) & (MEL_RING - 1);
+        }
+    }
+    for (int b = 0; b < B; b++) {                          // every count is a pure function of the samples pushed
+        nasr_stream *s = streams[b];
+        const PcmDesc &d = gh_pcm[b];
+        s->abuf_cnt = d.cnt + d.n - d.consumed;
+        if (d.n_frames > 0) s->abuf_par ^= 1;
+        s->mel_count += d.n_frames;
+        const int par = s->cc_par;
+        for (int g = 0; g < G; g++) chunk_bookkeeping(s, b);
+        s->cc_par = par ^ 1;
+        s->last_T = T * G; s->last_row = b; s->last_ws = p;
+    }
+    P.streams.assign(streams, streams + B);
+    P.T = T; P.G = G; P.key = key; P.seq = -1; P.stage = 0;
+    if (gp_call(e, p, key, B, T, R, G)) return -1;
+    e->graph_replays++;
+    e->gp_steps++;
     deliver(streams, B, tokens_out, tokens_cap, n_tokens);
     return 1;
 }
@@ -1942,7 +2251,12 @@ static int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, co
         // Needs the fused small-M path and the new rows to fit in the K/V ring next to the 70-row window.
         if (!e->opt_multichunk || B * G * T > e->w_rows || G * T > MAXNEW) return 0;
     }
-    if (e->opt_pipeline) return pipe_step(e, streams, B, pcm_dev, n_samples, G, tokens_out, tokens_cap, n_tokens);
+    if (e->opt_pipeline) {
+        if (!e->pipe_ready && ensure_pipe(e, 0)) return -1;          // picks the lanes
+        if (gp_eligible(e, B, T, G)) return gp_step(e, streams, B, pcm_dev, n_samples, G, tokens_out, tokens_cap, n_tokens);
+        if (gp_drain(e)) return -1;
+        return pipe_step(e, streams, B, pcm_dev, n_samples, G, tokens_out, tokens_cap, n_tokens);
+    }
     if (pipe_drain(e)) return -1;
     const int64_t key = ((int64_t)B << 32) | ((int64_t)T << 16) | (int64_t)G;
     auto it = e->graphs.find(key);
@@ -2305,12 +2619,14 @@ extern "C" int nasr_engine_get_counter(const nasr_engine *e, const char *name, i
         for (auto &kv : e->pipe[p].dec_graphs) execs += kv.second != nullptr;
     }
     shapes += (int64_t)keys.size();
+    for (auto &per_slot : e->gp_graphs) for (auto &m : per_slot) execs += (int64_t)m.size();
     if (!strcmp(name, "graph_execs")) *value = execs;
     else if (!strcmp(name, "graph_shapes")) *value = shapes;
     else if (!strcmp(name, "graph_evictions")) *value = e->graph_evictions;
     else if (!strcmp(name, "graph_replays")) *value = e->graph_replays;
     else if (!strcmp(name, "eager_steps")) *value = e->eager_steps;
     else if (!strcmp(name, "pipelined_steps")) *value = e->pipe_steps;
+    else if (!strcmp(name, "grouped_steps")) *value = e->gp_steps;
     else return fail("unknown counter '%s'", name);
     return 0;
 }

@@ -211,6 +211,9 @@ struct FusedParams {
 #endif
 };
 void launch_fused_skinny(const FusedParams &p, hipStream_t st);
+constexpr int FUSED_GROUP = 4;
+struct FusedParamsGroup { FusedParams p[FUSED_GROUP]; };
+void launch_fused_skinny_group(const FusedParamsGroup &pp, int n, hipStream_t st);   // n problems of one kind, M <= 2; g.M == 0: skipped
 
 void launch_prompt_add_relu(float *h, const float *w1p, const RowDesc *rows, int M, int T, int P, hipStream_t st);
 void launch_relu(float *x, int64_t n, hipStream_t st);

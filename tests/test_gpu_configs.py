@@ -225,12 +225,12 @@ def test_q8_0_token_agreement_vs_ggml_q8_semantics(Q24):
         assert d is None or (d["decision"] >= 0 and d["margin"] < EPS_MARGIN), r
 
 
-def _shipped_pipeline_identity(eng, R, pcms, n_steps, ragged_at, L, spot_streams):
-    """steps `pcms` through `eng` with pipeline = 0..4 and returns per mode: tokens, token frames, encoder-out taps at three
+def _shipped_pipeline_identity(eng, R, pcms, n_steps, ragged_at, L, spot_streams, modes=(0, 1, 2, 3, 4)):
+    """steps `pcms` through `eng` with pipeline = 0..4 (8 = the grouped pipeline) and returns per mode: tokens, token frames, encoder-out taps at three
     points of the run, decoder state, K / V / conv caches of every layer for the spot streams, per-stream counters"""
     B, n = len(pcms), synth.shift_samples(R)
     res = {}
-    for mode in (0, 1, 2, 3, 4):
+    for mode in modes:
         eng.set_option("pipeline", mode)
         sts = [eng.stream(R) for _ in range(B)]
         toks, encs = [[] for _ in range(B)], []
@@ -261,7 +261,7 @@ def _shipped_pipeline_identity(eng, R, pcms, n_steps, ragged_at, L, spot_streams
 def _assert_modes_identical(res):
     toks0, frames0, encs0, dec0, caches0, counters0 = res[0]
     assert sum(len(t) for t in toks0) > 0
-    for mode in (1, 2, 3, 4):
+    for mode in [m for m in res if m != 0]:
         toks, frames, encs, dec, caches, counters = res[mode]
         assert toks == toks0 and frames == frames0, mode
         assert counters == counters0, mode
@@ -279,7 +279,8 @@ def test_shipped_pipeline_bit_identity_batch1_R0_24_layers(W24):
     n_steps = 160
     pcm = synth.make_pcm(31, n_steps * 0.08 + 0.01)[:n_steps * 1280]
     eng = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=2)
-    res = _shipped_pipeline_identity(eng, R, [pcm], n_steps, 81, L, (0,))
+    res = _shipped_pipeline_identity(eng, R, [pcm], n_steps, 81, L, (0,), modes=(0, 1, 2, 3, 4, 8))
+    assert eng.counter("grouped_steps") > n_steps - 10          # mode 8 really ran the grouped pipeline
     eng.close()
     assert res[0][5][0][0] >= n_steps - 1
     _assert_modes_identical(res)
@@ -350,6 +351,49 @@ def test_graph_cache_is_bounded_over_10000_calls_with_random_batches(W2):
         n = sum(1 for f in rf if f < 480)
         got = [t for t, f in zip(res[4][b], c4["frames"][b]) if f < 480]
         assert got == ref[:n] and n > 0, b
+
+
+def test_grouped_pipeline_two_streams_ragged_and_mixed_calls():
+    """pipeline = 8 (two chains of four-problem launches, 8 steps in flight) on an 8-layer model, two streams: together (M = 2
+    rows per problem), alone, a ragged push (drains, runs eagerly), a stats call in the middle (drains: bubbles run through the
+    stages), another lookahead in between (not eligible: lanes mode), finalize -- tokens, frames, decoder state and encoder
+    output equal synchronous stepping bit for bit."""
+    L = 8
+    W = synth.make_weights(n_layers=L)
+    pcms = [synth.make_pcm(70 + b, 6.0) for b in range(3)]
+    res = {}
+    for mode in (0, 8):
+        eng = capi.Engine(W, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=3)
+        eng.set_option("pipeline", mode)
+        a, b = eng.stream(0), eng.stream(0)
+        c = eng.stream(1)
+        toks = [[], [], []]
+        n = 1280
+        for k in range(60):
+            if k % 7 == 3:                          # stream a alone
+                toks[0] += eng.step([a], [pcms[0][k * n:(k + 1) * n]])[0]
+                toks[1] += eng.step([b], [pcms[1][k * n:(k + 1) * n]])[0]
+            elif k == 31:                           # ragged: two uneven parts
+                for sl in (slice(k * n, k * n + 500), slice(k * n + 500, (k + 1) * n)):
+                    out = eng.step([a, b], [pcms[0][sl], pcms[1][sl]])
+                    toks[0] += out[0]; toks[1] += out[1]
+            else:
+                out = eng.step([a, b], [pcms[0][k * n:(k + 1) * n], pcms[1][k * n:(k + 1) * n]])
+                toks[0] += out[0]; toks[1] += out[1]
+            if k % 9 == 4:                          # a third stream with another lookahead (T = 2: M = 2 rows, eligible too)
+                toks[2] += eng.step([c], [pcms[2][(k // 9) * 2560:(k // 9 + 1) * 2560]])[0]
+            if k == 20:
+                assert a.stats().chunks > 0         # drains
+            if k == 57:                             # right after a joint step (valid until the engine's next chunk step; drains)
+                enc = np.stack([s.tap(capi.TAP_ENCODER_OUT) for s in (a, b)])
+        out = eng.finalize([a, b]) + eng.finalize([c])
+        for i in range(3):
+            toks[i] += out[i]
+        res[mode] = (toks, [s.token_frames() for s in (a, b, c)], np.stack([s.tap(capi.TAP_DEC_STATE) for s in (a, b, c)]), enc, eng.counter("grouped_steps"))
+        eng.close()
+    assert res[8][4] > 40 and res[0][4] == 0
+    assert res[8][0] == res[0][0] and res[8][1] == res[0][1] and sum(len(t) for t in res[0][0]) > 0
+    assert np.array_equal(res[8][2], res[0][2]) and np.array_equal(res[8][3], res[0][3])
 
 
 def test_reset_reference_mode_keeps_what_the_reference_keeps(W2):
