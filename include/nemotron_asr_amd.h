@@ -196,6 +196,9 @@ enum {
  * the last of these streams: a queue of their own up to E = 3, right behind the fourth piece at E = 4 (worth 1-5 % at 16-64
  * streams, nothing at one stream); fewer pieces when the process leaves the engine fewer queues.  Throughput option for callers that push back to back
  * (a server draining a backlog, a file); a live stream keeps the default.
+ * "pipeline" = 8 (round 3, experimental): for calls of one or two rows per step (one stream x R = 0 or 1, two streams x R = 0) the 8 steps in flight
+ * sit at 8 stages of 3 layers and every launch of the two chains carries the same kernel of FOUR steps (grouped launches); tokens 9 calls later;
+ * other shapes fall back to four lanes.  Bit-identical as well; measured +2.7 % at batch 1 (profiles/r3_grouped_pipeline.md), so 4 stays the default.
  * "lanes" (1..4): keep at most this many encoder lanes and give the other lanes' streams back -- for a process with another GPU
  * client (the diarization side-car): a stream created after this call gets a hardware queue the engine no longer uses.  Not
  * reversible for the engine's lifetime.
