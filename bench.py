@@ -475,6 +475,17 @@ def main():
         host_pcm = summarize(host_regions, args.steps, run.audio_per_step, world)
     step_s = statistics.median(regions) / args.steps
 
+    # the grouped pipeline (option pipeline = 8: 8 steps in flight, four steps per launch) on the same run, for the record
+    grouped_ms = None
+    if depth == 4 and B * T * args.chunks_per_step <= 2 and args.dtype == "bf16" and args.layers % 8 == 0:
+        run.eng.set_option("pipeline", 8)
+        for _ in range(12):
+            run.step()
+        gr = timed_regions(run, args.steps, barrier, max_over_ranks, repeats=min(3, args.regions), prime=12)
+        run.drain()
+        run.eng.set_option("pipeline", depth)
+        grouped_ms = summarize(gr, args.steps, run.audio_per_step, world)["ms_per_step"]
+
     roofline, kernels = None, []
     label = f"batch={B} R={R} {args.dtype}" + (f" from {args.weights}" if args.weights != "f32" else "")
     sync_step_s = None
@@ -768,6 +779,7 @@ def main():
             "cold_ms_per_step": cold["ms_per_step"],
             "synchronous_ms_per_step": round(1e3 * sync_step_s, 4) if sync_step_s else None,
             "host_pcm_ms_per_step": host_pcm["ms_per_step"] if host_pcm else None,
+            "pipeline8_ms_per_step": grouped_ms,
             "step_roofline": {"hbm_frac": sr["hbm_frac"], "mfma_frac": sr["mfma_frac"], "gbs": sr["gbs"]},
             "buffered_audio": buffered,
             "diarization": diar,
