@@ -1193,11 +1193,20 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
             if (nseg == 4 && nLayers >= 8 && !bounds_env) return (k == 1 ? 48 : k == 2 ? 104 : 164) * nLayers / 24;
             return 8 * bound(k);
         };
-        // a boundary between K3 (QKV: appends the step's K/V rows to the rings) and K4 (attention: reads them) would let the lane
-        // of K3 run up to three steps ahead of the lane of K4 on the same ring; keep the two launches of a layer in one piece
-        // (the shipped 24-layer cuts 48 | 104 | 164 and 57 | 126 are not of that kind; other depths can be)
-        auto snap8 = [&](int b) { return b % 8 == 3 && b < 8 * nLayers ? b + 1 : b; };
-        if (run_layers_fused(e, rows, B, T, G, snap8(bound8(seg)), snap8(bound8(seg + 1)))) return -1;
+        // The launches of a layer that touch PER-STREAM state shared by all steps -- K3 / K4 (the layer's K/V ring) and K6 (its conv
+        // cache) -- must run on the SAME lane whatever the step's shape: steps of one stream follow each other through a layer in lane
+        // order only.  The unfused path (more than four rows) cuts at whole layers, bound(k); a fused cut may therefore only move
+        // launches that touch nothing but the step's own workspace across that boundary: K7 / K8 of the layer before it (FFN2) or
+        // K1 / K2 of the layer after it (FFN1), i.e. it must lie in [8 bound(k) - 2, 8 bound(k) + 2].  Round 2 shipped 164 for the third cut
+        // of the 24-layer model (layer 20's K3 / K4 on lane 2 for one-to-four-row steps, on lane 3 for larger ones): a stream whose steps
+        // alternate between the two forms while both are in flight could read or write that layer's ring out of order -- found in
+        // round 3 by the soak test on 8 layers (cuts 16 | 34 | 54), never seen at 24; the cut is 162 now.
+        auto snap8 = [&](int k, int b) {
+            if (k <= 0 || k >= nseg || b8_env) return b;
+            const int lb = 8 * bound(k);
+            return std::min(std::max(b, lb - 2), lb + 2);
+        };
+        if (run_layers_fused(e, rows, B, T, G, snap8(seg, bound8(seg)), snap8(seg + 1, bound8(seg + 1)))) return -1;
     } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
         if (front) {

@@ -1,7 +1,7 @@
 """soak test (GPU): a pipelined engine (option pipeline = 4: four lanes) against a synchronous one over thousands of calls with random push
 sizes (partial chunks, several chunks at once, ragged groups), random subsets of the streams per call, resets, finalize / collect
 in between -- token streams must be identical.  The parity suite covers each of these once; this looks for the rare ordering bug.
-usage: python tests/micro/soak_pipeline.py [calls] [seed]"""
+usage: python tests/micro/soak_pipeline.py [calls] [seed] [pipeline mode (default 4; 8 = grouped pipeline, run on 8 layers)]"""
 import sys
 from pathlib import Path
 
@@ -17,11 +17,12 @@ from nemotron_asr_amd import capi, synth  # noqa: E402
 def main():
     calls = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    pmode = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     rng = np.random.default_rng(seed)
-    n_layers, B = 4, 5
+    n_layers, B = (8 if pmode == 8 or len(sys.argv) > 4 else 4), 5
     W = synth.make_weights(n_layers=n_layers)
     engs = []
-    for mode in (0, 4):
+    for mode in (0, pmode):
         e = capi.Engine(W, n_layers=n_layers, dtype=capi.DTYPE_BF16, max_streams=B)
         e.set_option("pipeline", mode)
         engs.append(e)
@@ -31,6 +32,7 @@ def main():
     pos = [0] * B
     toks = [[[] for _ in range(B)] for _ in engs]
     n_tok = 0
+    log = []
     for c in range(calls):
         # a group = streams of one right context (the engine batches equal T only)
         R = int(rng.choice(sorted(set(Rs))))
@@ -39,6 +41,11 @@ def main():
             continue
         piece = synth.shift_samples(R)
         mode = rng.random()
+        feat = int(__import__("os").environ.get("SOAK_FEATURES", "7"))      # bisecting aid: 1 ragged pushes, 2 multi-chunk pushes, 4 finalize / reset / collect
+        if mode >= 0.7 and mode < 0.85 and not feat & 1:
+            mode = 0.0
+        if mode >= 0.85 and not feat & 2:
+            mode = 0.0
         if mode < 0.7:
             n = [piece] * len(group)                                  # the steady-state shape: one chunk each (graph replay)
         elif mode < 0.85:
@@ -57,6 +64,8 @@ def main():
             for b, o in zip(group, out):
                 toks[ei][b] += o
         r = rng.random()
+        if not feat & 4:
+            r = 1.0
         if r < 0.01:                                                  # finalize one stream, then reset it
             b = int(rng.integers(0, B))
             for ei, e in enumerate(engs):
@@ -68,6 +77,20 @@ def main():
                     idx = [b for b in range(B) if Rs[b] == Rg]
                     for b, o in zip(idx, e.collect([streams[ei][b] for b in idx])):
                         toks[ei][b] += o
+        log.append((c, R, group, n, round(r, 3)))
+        chk = int(__import__("os").environ.get("SOAK_CHECK", "0"))
+        if chk and c % chk == chk - 1:                                # localise a divergence: drain both engines, compare so far
+            for ei, e in enumerate(engs):
+                for Rg in sorted(set(Rs)):
+                    idx = [b for b in range(B) if Rs[b] == Rg]
+                    for b, o in zip(idx, e.collect([streams[ei][b] for b in idx])):
+                        toks[ei][b] += o
+            for b in range(B):
+                if toks[0][b] != toks[1][b]:
+                    print(f"divergence on stream {b} within calls {c - chk + 1}..{c}: sync {toks[0][b][-6:]} pipelined {toks[1][b][-6:]}")
+                    for item in log[-chk:]:
+                        print("   ", item)
+                    sys.exit(1)
         if c % 500 == 499:
             print(f"call {c + 1}: tokens so far {sum(len(t) for t in toks[0])}", flush=True)
     for ei, e in enumerate(engs):

@@ -518,15 +518,18 @@ def test_progress_does_not_drain_the_pipeline(W2):
     eng.close()
 
 
-def test_pipelined_engine_soak():
-    """tests/micro/soak_pipeline.py, short form: 800 calls with random push sizes (partial chunks, several chunks, ragged groups),
-    random subsets of five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine (four lanes)
-    emits exactly the tokens of a synchronous one."""
+@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1200", "7", "8")])
+def test_pipelined_engine_soak(args):
+    """tests/micro/soak_pipeline.py, short form: random push sizes (partial chunks, several chunks, ragged groups), random subsets of
+    five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine emits exactly the tokens of a
+    synchronous one.  (800 calls, seed 11): four lanes on 4 layers (round 2).  (1200 calls, seed 7, 8 layers): the sequence that
+    exposed the lane inconsistency of the round-2 cuts at calls 475-499 (a stream alternating between one-to-four-row steps and larger
+    ones while both are in flight; enqueue_encoder: snap8) -- with four lanes, and with the grouped pipeline (mode 8)."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "soak_pipeline.py"), "800", "11"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "soak_pipeline.py"), *args], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "pipelined == synchronous" in r.stdout
 
