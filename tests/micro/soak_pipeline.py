@@ -1,7 +1,7 @@
 """soak test (GPU): a pipelined engine (option pipeline = 4: four lanes) against a synchronous one over thousands of calls with random push
 sizes (partial chunks, several chunks at once, ragged groups), random subsets of the streams per call, resets, finalize / collect
 in between -- token streams must be identical.  The parity suite covers each of these once; this looks for the rare ordering bug.
-usage: python tests/micro/soak_pipeline.py [calls] [seed] [pipeline mode (default 4; 8 = grouped pipeline, run on 8 layers)]"""
+usage: python tests/micro/soak_pipeline.py [calls] [seed] [pipeline mode (default 4; 8 = grouped pipeline)] [L<layers> (default 4; 8 with mode 8)]"""
 import sys
 from pathlib import Path
 
@@ -19,7 +19,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     pmode = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     rng = np.random.default_rng(seed)
-    n_layers, B = (8 if pmode == 8 or len(sys.argv) > 4 else 4), 5
+    n_layers = int(sys.argv[4][1:]) if len(sys.argv) > 4 else (8 if pmode == 8 else 4)      # "L8", "L24"
+    B = 5
     W = synth.make_weights(n_layers=n_layers)
     engs = []
     for mode in (0, pmode):
