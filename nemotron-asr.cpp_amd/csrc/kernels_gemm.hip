@@ -253,6 +253,87 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
 }
 
 // ------------------------------------------------------------------------------------
+// The same 128 x 128 tile with 32-deep chunks (ONE k-tile per ring slot: 8 KiB activation panel + 8 KiB weight tiles), for
+// pipelined steps: NS slots of 16 KiB (+ the staged epilogue's 66 KiB) let TWO workgroups share a CU -- GEMMs of two launch
+// chains, whose ring fills, barrier waits and epilogues then run under each other's MFMAs.  Same MFMAs in the same order per
+// accumulator as k_gemm_tiled2 / k_gemm_roles (k ascending, split boundaries on 64-deep chunks): bit-identical results.
+// Panel rows are 64 B here, so four rows share a 256-byte bank line: 16-byte column c of row r lives at column c ^ ((-(r >> 2)) & 3)
+// (conflict-free for the four 16-lane groups a ds_read_b128 is served in: MI355X_MICROARCH.md, LDS).
+// ------------------------------------------------------------------------------------
+constexpr int K32_SLOT = 16384;
+__device__ __forceinline__ int panel32_off(int row, int col) { return row * 64 + ((col ^ ((0 - (row >> 2)) & 3)) << 4); }
+template <int NS>
+__global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int P = NS - 1;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int t0 = 2 * (int)((long)kc_total * split / p.splits), t1 = 2 * (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = t1 - t0, m0 = mc * TM;
+    // this wave DMAs weight tile ng * 8 + wave (one k-tile per chunk) and panel rows [wave * 16, +16)
+    const uint4 *wpd = (const uint4 *)p.W + (size_t)(ng * 8 + wave) * KT * 64 + lane;
+    const char *asrc;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc = a_row_ptr(p, m, 2) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kt, int slot) {
+        const unsigned sb = ring_base + slot * K32_SLOT;
+        glds16(asrc + (size_t)kt * 64, sb + wave * 1024);
+        glds16(wpd + (size_t)kt * 64, sb + 8192 + wave * 1024);
+    };
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        if (i < nchunks) issue(t0 + i, i);
+    int slot = 0;
+    for (int i = 0; i < nchunks; i++) {
+        const int left = nchunks - 1 - i;                                          // chunks allowed to stay in flight: min(left, P - 1)
+        if (left >= P - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (P - 1)) : "memory");   // 2 DMA instructions per wave per chunk
+        else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
+        const char *sp = ring + slot * K32_SLOT;
+        const char *wl = sp + 8192 + ng4 * 2048 + lane * 16;
+        const uint4 w0 = *(const uint4 *)(wl), w1 = *(const uint4 *)(wl + 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const uint4 bv = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), bf, acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), bf, acc[1][mt], 0, 0, 0);
+        }
+        if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);     // the slot chunk i - 1 has just left
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    __syncthreads();                           // every wave is done with the ring
+    float *stage = (float *)ring;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (ng4 * 2 + j) * 16 + q * 4, acc[j][mt]);
+    __syncthreads();
+    staged_epilogue<512>(p, split, m0, ng * 128, stage);
+}
+
+// ------------------------------------------------------------------------------------
 // 128 (M) x 64 (N) tile of the same structure, for the split-K GEMMs with N = 1024 (W2, Wo, pw2) at M = 896: the 128 x 128
 // tile gives 56 output tiles, so K had to be split four ways to fill the chip and every GEMM wrote 4 x 3.67 MB of f32
 // partials that k_post read back (round 1: 59 MB per layer).  Half-width tiles fill the chip with TWO splits: half the
@@ -480,12 +561,20 @@ static size_t gemm_lds_bytes(int ns) {     // the ring, or the f32 tile the epil
     return ring > stage ? ring : stage;
 }
 
+static size_t gemm_k32_lds_bytes(int ns) {
+    const size_t ring = (size_t)ns * K32_SLOT, stage = (size_t)TM * STG_LD * 4;
+    return ring > stage ? ring : stage;
+}
+
 void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_tiled2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_roles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
     hipFuncSetAttribute((const void *)k_gemm_roles<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
     hipFuncSetAttribute((const void *)k_gemm_t64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T64_SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_t64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T64_SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(5));
     hipFuncSetAttribute((const void *)k_gemm_tiled2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
     hipFuncSetAttribute((const void *)k_gemm_roles<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
 }
@@ -519,6 +608,19 @@ int gemm_skinny_max_m() {
     return v;
 }
 
+// Pipelined steps (GemmParams::coresident): four launch chains advance in lock-step rounds, so the GEMM launches of a round start
+// together and, with one 96-128 KiB workgroup per CU, run one after the other -- a round costs the SUM of its GEMMs.  With rings of
+// <= 72 KiB two of them share every CU: one workgroup's ring fill and barrier waits run under the other's MFMAs (64 streams x
+// R = 13: 2.64 -> 2.48 ms per step; alone on the chip the shallower rings cost 8 %, so synchronous steps keep the deep ones).
+// From seven 128-row tiles up (M > 768), where every GEMM of the step covers most of the chip: measured per step with four lanes,
+// 64 streams x R = 13 (M = 896) 2.61 -> 2.47 ms, 48 streams (M = 672) 2.05 -> 2.03, 40 streams (M = 560) 1.76 -> 1.81, 32 streams 1.51 -> 1.59.
+static bool gemm_coresident(const GemmParams &p) {
+    static const int force = getenv("NASR_GEMM_CORES") ? atoi(getenv("NASR_GEMM_CORES")) : -1;    // 0: never, 1: always (A/B runs)
+    static const int min_m = getenv("NASR_GEMM_CORES_MIN_M") ? atoi(getenv("NASR_GEMM_CORES_MIN_M")) : 769;
+    if (force >= 0) return force != 0;
+    return p.coresident && p.M >= min_m;
+}
+
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     if (p.splits < 1) p.splits = 1;
@@ -531,10 +633,19 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
         if (gemm_use_t64(p.M, p.N, p.epi)) {       // half-width tiles: the caller chose splits for N / 64 column groups (gemm_tile_n)
             n_groups = p.N / 64;
-            hipLaunchKernelGGL(k_gemm_t64<4>, dim3(n_groups * m_chunks * p.splits), dim3(512), 4 * T64_SLOT, st, p, n_groups, m_chunks);
+            if (gemm_coresident(p))      // 3 slots = 72 KiB: two workgroups per CU
+                hipLaunchKernelGGL(k_gemm_t64<3>, dim3(n_groups * m_chunks * p.splits), dim3(512), 3 * T64_SLOT, st, p, n_groups, m_chunks);
+            else
+                hipLaunchKernelGGL(k_gemm_t64<4>, dim3(n_groups * m_chunks * p.splits), dim3(512), 4 * T64_SLOT, st, p, n_groups, m_chunks);
             return;
         }
         dim3 grid(n_groups * m_chunks * p.splits);
+        if (gemm_coresident(p)) {
+            static const int k32 = getenv("NASR_GEMM_K32_SLOTS") ? atoi(getenv("NASR_GEMM_K32_SLOTS")) : 4;
+            if (k32 == 5) hipLaunchKernelGGL(k_gemm_tiled2_k32<5>, grid, dim3(512), gemm_k32_lds_bytes(5), st, p, n_groups, m_chunks);
+            else hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            return;
+        }
         static const int roles_min_chunks = getenv("NASR_ROLES_MIN_CHUNKS") ? atoi(getenv("NASR_ROLES_MIN_CHUNKS")) : 8;
         const bool roles = (p.K >> 6) / p.splits >= roles_min_chunks;
         const int ns = gemm_ring_slots();

@@ -188,6 +188,7 @@ struct nasr_engine {
     double host_launch_s = 0, host_wait_s = 0;     // NASR_STATS: host time inside hipGraphLaunch / waiting for the device (pipelined steps)
     int64_t pipe_seq = 0;            // steps launched through the pipeline so far
     bool pipe_ready = false;
+    bool gemm_coresident = false;  // set while the graphs of a step with >= 2 launch chains are captured (run_gemm)
     size_t desc_bytes = 0, col_bytes = 0;
     int64_t pipe_steps = 0;
     void *a, *hbuf, *ctx, *cbuf, *sub_b;             // (with x, x2, part, q, glu, sub_a, hfuse: the CURRENT workspace set, see use_ws)
@@ -933,6 +934,7 @@ static int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char 
     const bool use_bf16 = e->bf16 && !f32_weights;
     const char *name = !use_bf16 ? "k_gemm_f32" : (g.M <= gemm_skinny_max_m() ? "k_gemm_skinny" : "k_gemm_tiled");
     ProfScope ps(e, name, gemm_bytes(e, g.M, g.N, g.K, use_bf16 ? 2 : 4), 2.0 * g.M * g.N * g.K);
+    g.coresident = e->gemm_coresident ? 1 : 0;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);
     return 0;
@@ -1881,7 +1883,10 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
             hipGraphExec_t gs[nasr_engine::MAXSEG] = {nullptr, nullptr, nullptr, nullptr}, dec = nullptr;
             {
                 CaptureExclusive alone;
-                if (build_pipe_graphs(e, q, B, T, R, G, nseg, gs, &dec)) return -1;
+                e->gemm_coresident = nseg >= 2;          // several launch chains side by side: co-resident GEMM variants
+                const int rc = build_pipe_graphs(e, q, B, T, R, G, nseg, gs, &dec);
+                e->gemm_coresident = false;
+                if (rc) return -1;
             }
             for (int k = 0; k < nseg; k++) Q.seg_graphs[k][key] = gs[k];
             Q.dec_graphs[key] = dec;

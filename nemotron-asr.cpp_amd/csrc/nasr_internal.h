@@ -108,6 +108,9 @@ struct GemmParams {
     void  *kv_pool;               // K/V rings of this layer: [slot][2][KVC][1024] act dtype
     int64_t kv_slot_stride;       // elements between slots
     const RowDesc *rows;  int T;  // row m -> stream m / T, frame m % T
+    // pipelined steps: this launch shares the chip with other launch chains' GEMMs -- the large-M kernels then use the variants
+    // whose LDS ring lets two workgroups share a CU (same arithmetic in the same order: bit-identical to the default kernels)
+    int coresident;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
