@@ -618,7 +618,9 @@ static bool gemm_coresident(const GemmParams &p) {
     static const int force = getenv("NASR_GEMM_CORES") ? atoi(getenv("NASR_GEMM_CORES")) : -1;    // 0: never, 1: always (A/B runs)
     static const int min_m = getenv("NASR_GEMM_CORES_MIN_M") ? atoi(getenv("NASR_GEMM_CORES_MIN_M")) : 769;
     if (force >= 0) return force != 0;
-    return p.coresident && p.M >= min_m;
+    // more than one wave of tiles (M >= 1 792): workgroups of ONE launch start as earlier ones finish, so the two on a CU are out of
+    // phase by themselves -- synchronous steps gain as well (128 streams x R = 13: 6.51 -> 5.95 ms, 512 streams 19.9 -> 18.6 ms)
+    return p.M >= 1792 || (p.coresident && p.M >= min_m);
 }
 
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {

@@ -1,5 +1,5 @@
 """Bit-identity of GEMM kernel variants chosen by environment knobs: 16 streams x R = 13 (M = 224) and 64 streams x R = 13
-(M = 896) on a 3-layer bf16 engine, a few steps; prints one digest per knob setting (run: python gemm_variant_identity.py
+(M = 896) and 128 streams (M = 1 792) on a 3-layer bf16 engine, a few steps; prints one digest per knob setting (run: python gemm_variant_identity.py
 "NASR_GEMM_CORES=1" "NASR_GEMM_CORES=0" ...; the first digest is the build's default)."""
 import hashlib
 import os
@@ -18,7 +18,7 @@ def child():
     L, R = 3, 13
     W = synth.make_weights(n_layers=L)
     h = hashlib.sha256()
-    for B, pipeline in ((16, 0), (64, 0), (64, 4)):
+    for B, pipeline in ((16, 0), (64, 0), (64, 4), (128, 0)):
         eng = capi.Engine(W, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
         eng.set_option("pipeline", pipeline)
         n = synth.shift_samples(R)
