@@ -1,0 +1,61 @@
+// Round 3: do GEMM workgroups of two launch chains (two HIP streams on two hardware queues) really share CUs, and what does a pair cost?
+// Links the engine's own kernels_gemm.o.  W1 shape (M = 896, N = 4096, K = 1024, SiLU -> bf16) and W2 shape (N = 1024, K = 4096, 2 splits,
+// f32 partials), deep-ring kernels (coresident = 0) against the shallow-ring ones (1): one chain of 60 launches alone, then two
+// chains of 60 side by side (different outputs, same weights).  Perfect overlap = the time of one chain; none = twice that.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../nemotron-asr.cpp_amd/csrc -o cores_probe cores_probe.hip ../../nemotron-asr.cpp_amd/csrc/kernels_gemm.o
+#include "nasr_internal.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+using namespace nasr;
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+__global__ void k_spin(unsigned long long ticks) {          // 100 MHz s_memrealtime: 1 tick = 10 ns
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int main(int argc, char **argv) {
+    const int offset_us = argc > 1 ? atoi(argv[1]) : 0;      // chain 1 starts this much later (a one-workgroup spin kernel at the head of its graph)
+    init_gemm_kernel_attributes();
+    const int M = 896, L = 60;
+    bf16_t *A, *W, *act[2]; float *part[2];
+    CHK(hipMalloc(&A, (size_t)M * 4096 * 2)); CHK(hipMalloc(&W, (size_t)4096 * 1024 * 2));
+    std::vector<bf16_t> h((size_t)4096 * 1024);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (bf16_t)(0x3c00 + (i * 2654435761u >> 24 & 0x7f) + ((i & 8) ? 0x8000 : 0));
+    CHK(hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    CHK(hipMemcpy(A, h.data(), (size_t)M * 4096 * 2 < h.size() * 2 ? (size_t)M * 4096 * 2 : h.size() * 2, hipMemcpyHostToDevice));
+    for (int c = 0; c < 2; c++) { CHK(hipMalloc(&act[c], (size_t)M * 4096 * 2)); CHK(hipMalloc(&part[c], (size_t)2 * M * 1024 * 4)); }
+    hipStream_t st[2];
+    for (auto &s : st) CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (int shape = 0; shape < 2; shape++)
+        for (int cores = 0; cores < 2; cores++) {
+            hipGraphExec_t ex[2];
+            for (int c = 0; c < 2; c++) {
+                GemmParams g;
+                memset(&g, 0, sizeof(g));
+                g.A = A; g.W = W; g.M = M; g.coresident = cores;
+                if (shape == 0) { g.N = 4096; g.K = 1024; g.lda = 1024; g.splits = 1; g.epi = EPI_SILU_ACT; g.out_act = act[c]; g.ldo_act = 4096; }
+                else { g.N = 1024; g.K = 4096; g.lda = 4096; g.splits = 2; g.epi = EPI_PART_F32; g.out_f32 = part[c]; g.ldo = 1024; }
+                hipGraph_t gr;
+                CHK(hipStreamBeginCapture(st[c], hipStreamCaptureModeThreadLocal));
+                if (c == 1 && offset_us > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[c], (unsigned long long)offset_us * 100);
+                for (int i = 0; i < L; i++) launch_gemm_bf16(g, st[c]);
+                CHK(hipStreamEndCapture(st[c], &gr)); CHK(hipGraphInstantiate(&ex[c], gr, nullptr, nullptr, 0)); CHK(hipGraphDestroy(gr));
+            }
+            double t[2] = {1e18, 1e18};
+            for (int n = 1; n <= 2; n++)
+                for (int rep = 0; rep < 8; rep++) {
+                    for (auto &s : st) CHK(hipStreamSynchronize(s));
+                    auto t0 = std::chrono::steady_clock::now();
+                    for (int c = 0; c < n; c++) CHK(hipGraphLaunch(ex[c], st[c]));
+                    for (int c = 0; c < n; c++) CHK(hipStreamSynchronize(st[c]));
+                    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                    if (us < t[n - 1]) t[n - 1] = us;
+                }
+            printf("[offset %d us] %s, %s rings: one chain %.2f us per launch; two chains side by side %.2f us per launch pair (%.2fx one chain)\n",
+                   offset_us, shape == 0 ? "W1 (4096 x 1024, SiLU bf16 out)" : "W2 (1024 x 4096, 2 splits, f32 partials)", cores ? "shallow (two workgroups per CU)" : "deep (one workgroup per CU)",
+                   t[0] / L, t[1] / L, t[1] / t[0]);
+            for (auto &e : ex) CHK(hipGraphExecDestroy(e));
+        }
+    return 0;
+}
