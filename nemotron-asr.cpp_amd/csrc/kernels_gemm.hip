@@ -159,9 +159,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmParams &p, int split, 
     }
 }
 
-// NS = slots of the LDS ring (NS - 1 chunks in flight).  NS = 4: 128 KiB, one workgroup per CU.  NS = 2: 64 KiB (+ the 66 KiB
-// the staged epilogue needs), TWO workgroups per CU -- of this launch or of a launch of another HIP stream (pipelined steps run
-// two or three launch chains side by side): one workgroup's fill, waits and epilogue run under the other's MFMAs.
+// NS = slots of the LDS ring (NS - 1 chunks in flight); shipped with NS = 4: 128 KiB, one workgroup per CU.  (A 2-slot ring so that two
+// workgroups could share a CU was slower -- profiles/lab_book_rounds_1_2.md; what does pay is k_gemm_tiled2_k32 below: the same ring depth
+// in 32-deep chunks.)
 template <int NS>
 __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups, int m_chunks) {
     constexpr int P = NS - 1;
@@ -552,10 +552,6 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
     staged_epilogue<1024>(p, split, m0, ng * 128, stage);
 }
 
-static int gemm_ring_slots() {      // 4 (default): one workgroup per CU, three chunks in flight; 2: two workgroups per CU, one chunk in flight
-    static const int v = getenv("NASR_GEMM_SLOTS") ? atoi(getenv("NASR_GEMM_SLOTS")) : 4;
-    return v == 2 || v == 3 ? v : 4;
-}
 static size_t gemm_lds_bytes(int ns) {     // the ring, or the f32 tile the epilogue parks in it, whichever is larger
     const size_t ring = (size_t)ns * G2_SLOT, stage = (size_t)TM * STG_LD * 4;
     return ring > stage ? ring : stage;
@@ -569,14 +565,9 @@ static size_t gemm_k32_lds_bytes(int ns) {
 void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_tiled2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_roles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
-    hipFuncSetAttribute((const void *)k_gemm_tiled2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
-    hipFuncSetAttribute((const void *)k_gemm_roles<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(3));
     hipFuncSetAttribute((const void *)k_gemm_t64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_t64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
-    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(5));
-    hipFuncSetAttribute((const void *)k_gemm_tiled2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
-    hipFuncSetAttribute((const void *)k_gemm_roles<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(2));
 }
 
 // 128 x 64 tiles (k_gemm_t64): for the split-K GEMMs with N = 1024 when that halves the split factor, and for any other GEMM
@@ -642,25 +633,15 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             return;
         }
         dim3 grid(n_groups * m_chunks * p.splits);
-        if (gemm_coresident(p)) {
-            static const int k32 = getenv("NASR_GEMM_K32_SLOTS") ? atoi(getenv("NASR_GEMM_K32_SLOTS")) : 4;
-            if (k32 == 5) hipLaunchKernelGGL(k_gemm_tiled2_k32<5>, grid, dim3(512), gemm_k32_lds_bytes(5), st, p, n_groups, m_chunks);
-            else hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+        if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU
+            hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             return;
         }
         static const int roles_min_chunks = getenv("NASR_ROLES_MIN_CHUNKS") ? atoi(getenv("NASR_ROLES_MIN_CHUNKS")) : 8;
         const bool roles = (p.K >> 6) / p.splits >= roles_min_chunks;
-        const int ns = gemm_ring_slots();
-        const size_t lds = gemm_lds_bytes(ns);
-#define NASR_LAUNCH_TILED(NS_)                                                                                             \
-        do {                                                                                                               \
-            if (roles) hipLaunchKernelGGL(k_gemm_roles<NS_>, grid, dim3(1024), lds, st, p, n_groups, m_chunks);             \
-            else hipLaunchKernelGGL(k_gemm_tiled2<NS_>, grid, dim3(512), lds, st, p, n_groups, m_chunks);                   \
-        } while (0)
-        if (ns == 2) NASR_LAUNCH_TILED(2);
-        else if (ns == 3) NASR_LAUNCH_TILED(3);
-        else NASR_LAUNCH_TILED(4);
-#undef NASR_LAUNCH_TILED
+        const size_t lds = gemm_lds_bytes(4);
+        if (roles) hipLaunchKernelGGL(k_gemm_roles<4>, grid, dim3(1024), lds, st, p, n_groups, m_chunks);
+        else hipLaunchKernelGGL(k_gemm_tiled2<4>, grid, dim3(512), lds, st, p, n_groups, m_chunks);
     }
 }
 

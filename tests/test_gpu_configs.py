@@ -534,6 +534,20 @@ def test_pipelined_engine_soak(args):
     assert "pipelined == synchronous" in r.stdout
 
 
+def test_gemm_ring_variants_are_bit_identical():
+    """The large-M GEMMs come in two ring depths: deep rings (one 96-128 KiB workgroup per CU: synchronous steps below 1 792 rows) and
+    shallow ones of which two share a CU (k_gemm_tiled2_k32<4>, k_gemm_t64<3>: pipelined steps above 768 rows, every step from 1 792 rows).
+    Same MFMAs in the same order: tokens, encoder output, K/V and conv caches of 16 / 64 / 128 streams x R = 13 (M = 224, 896, 1 792;
+    synchronous and four lanes) have ONE digest whether the choice is left to the engine or forced either way (NASR_GEMM_CORES)."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "NASR_GEMM_CORES=1", "NASR_GEMM_CORES=0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("==") == 3 and "!=" not in r.stdout
+
+
 def test_lanes_option_gives_queues_back_and_keeps_results(W2):
     """Engine option "lanes": the engine keeps fewer encoder lanes (before or after it has picked them) -- fewer pieces in flight,
     identical tokens."""
