@@ -20,16 +20,24 @@ def main():
     pmode = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     rng = np.random.default_rng(seed)
     n_layers = int(sys.argv[4][1:]) if len(sys.argv) > 4 else (8 if pmode == 8 else 4)      # "L8", "L24"
-    B = 5
+    # SOAK_STREAMS="13x72,0x4": 72 streams of R = 13 and 4 of R = 0 (default: 0, 0, 0, 1, 13).  With ~58 of 72 R = 13 streams per call
+    # the row count of a step crosses 768 both ways: deep-ring and co-resident GEMM kernels alternate between the steps in flight.
+    spec = __import__("os").environ.get("SOAK_STREAMS")
+    Rs = [0, 0, 0, 1, 13]
+    if spec:
+        Rs = []
+        for part in spec.split(","):
+            r, n = part.split("x")
+            Rs += [int(r)] * int(n)
+    B = len(Rs)
     W = synth.make_weights(n_layers=n_layers)
     engs = []
     for mode in (0, pmode):
         e = capi.Engine(W, n_layers=n_layers, dtype=capi.DTYPE_BF16, max_streams=B)
         e.set_option("pipeline", mode)
         engs.append(e)
-    Rs = [0, 0, 0, 1, 13]
     streams = [[e.stream(R) for R in Rs] for e in engs]
-    pcm = [synth.make_pcm(500 + b, 900.0) for b in range(B)]
+    pcm = [synth.make_pcm(500 + b, 900.0 if B <= 8 else 150.0) for b in range(B)]
     pos = [0] * B
     toks = [[[] for _ in range(B)] for _ in engs]
     n_tok = 0

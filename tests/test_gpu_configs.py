@@ -518,18 +518,23 @@ def test_progress_does_not_drain_the_pipeline(W2):
     eng.close()
 
 
-@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1200", "7", "8")])
+@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1200", "7", "8"), ("1000", "3", "4", "L4", "SOAK_STREAMS=13x72,0x4")])
 def test_pipelined_engine_soak(args):
     """tests/micro/soak_pipeline.py, short form: random push sizes (partial chunks, several chunks, ragged groups), random subsets of
     five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine emits exactly the tokens of a
     synchronous one.  (800 calls, seed 11): four lanes on 4 layers (round 2).  (1200 calls, seed 7, 8 layers): the sequence that
     exposed the lane inconsistency of the round-2 cuts at calls 475-499 (a stream alternating between one-to-four-row steps and larger
-    ones while both are in flight; enqueue_encoder: snap8) -- with four lanes, and with the grouped pipeline (mode 8)."""
+    ones while both are in flight; enqueue_encoder: snap8) -- with four lanes, and with the grouped pipeline (mode 8).  Last case: 72
+    streams of R = 13 (+ 4 of R = 0), ~58 of them per call: the rows of a step cross 768 both ways, so steps on the deep-ring GEMM
+    kernels and steps on the co-resident ones are in flight together."""
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "soak_pipeline.py"), *args], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    env.update(a.split("=", 1) for a in args if "=" in a)
+    args = [a for a in args if "=" not in a]
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "soak_pipeline.py"), *args], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "pipelined == synchronous" in r.stdout
 
