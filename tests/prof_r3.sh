@@ -5,11 +5,12 @@
 #   2. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only, MI355X_MICROARCH.md)
 #                                                  -> gpurun_out/r3_pmc_traffic_<tag>.json (per kernel: HBM bytes per launch,
 #                                                     FETCH_SIZE x 2 + WRITE_SIZE, KiB counters -> bytes)
+# PROF_MODE="" profiles pipelined steps instead (the profiler serialises the queues: same kernels as the pipelined path, each alone on the chip).
 # Runs synchronous steps (one launch chain at a time: the kernels alone on the chip), one timed region, < 60 graph
 # steps in all: rocprofv3 (ROCm 7.2) crashes in its queue interceptor after ~15 000 graph-launched kernels in one process.
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-ARGS="--no-cpu-baseline --no-profile-pass --no-buffered --no-extra-configs --no-host-pcm --regions 1 --sync-steps --steps ${PROF_STEPS:-40} --warmup 3 $*"
+ARGS="--no-cpu-baseline --no-profile-pass --no-buffered --no-extra-configs --no-host-pcm --no-b512 --no-f32-engine --regions 1 ${PROF_MODE---sync-steps} --steps ${PROF_STEPS:-40} --warmup 3 $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/prof_$TAG.log 2>&1
 echo "stats pass rc=$? segv=$(grep -c SIGSEGV $OUT/prof_$TAG.log) $(grep -o '"ms_per_step": [0-9.]*' $OUT/prof_$TAG.log | head -1)"
