@@ -14,9 +14,11 @@ __global__ void k_spin(unsigned long long ticks) {          // 100 MHz s_memreal
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
+__global__ void k_empty() {}
 int main(int argc, char **argv) {
     const int offset_us = argc > 1 ? atoi(argv[1]) : 0;
     const int K1 = argc > 2 ? atoi(argv[2]) : 1024;         // K of the W1-shaped GEMM (sweep: fixed part and per-chunk part of a launch)      // chain 1 starts this much later (a one-workgroup spin kernel at the head of its graph)
+    const int fence_mode = argc > 4 ? atoi(argv[4]) : 0;    // 1: chain 1 = empty launches (8 per GEMM launch of chain 0): what do its kernel boundaries cost chain 0?
     const int K2 = argc > 3 ? atoi(argv[3]) : 4096;         // K of the W2-shaped GEMM (N = 1024, 2 splits)
     if (K2 < 256 || K2 > 4096 || K2 % 128) { fprintf(stderr, "K2: a multiple of 128 up to 4096\n"); return 1; }
     if (K1 < 64 || K1 > 1024 || K1 % 64) { fprintf(stderr, "K1: a multiple of 64 up to 1024 (the weight buffer holds 4096 x 1024)\n"); return 1; }
@@ -43,7 +45,8 @@ int main(int argc, char **argv) {
                 hipGraph_t gr;
                 CHK(hipStreamBeginCapture(st[c], hipStreamCaptureModeThreadLocal));
                 if (c == 1 && offset_us > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[c], (unsigned long long)offset_us * 100);
-                for (int i = 0; i < L; i++) launch_gemm_bf16(g, st[c]);
+                if (fence_mode && c == 1) { for (int i = 0; i < 8 * L; i++) hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st[c]); }
+                else for (int i = 0; i < L; i++) launch_gemm_bf16(g, st[c]);
                 CHK(hipStreamEndCapture(st[c], &gr)); CHK(hipGraphInstantiate(&ex[c], gr, nullptr, nullptr, 0)); CHK(hipGraphDestroy(gr));
             }
             double t[2] = {1e18, 1e18};
