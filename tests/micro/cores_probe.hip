@@ -19,6 +19,7 @@ int main(int argc, char **argv) {
     const int offset_us = argc > 1 ? atoi(argv[1]) : 0;
     const int K1 = argc > 2 ? atoi(argv[2]) : 1024;         // K of the W1-shaped GEMM (sweep: fixed part and per-chunk part of a launch)      // chain 1 starts this much later (a one-workgroup spin kernel at the head of its graph)
     const int fence_mode = argc > 4 ? atoi(argv[4]) : 0;    // 1: chain 1 = empty launches (8 per GEMM launch of chain 0): what do its kernel boundaries cost chain 0?
+    const int mask_mode = argc > 5 ? atoi(argv[5]) : 0;     // CU masks of the two streams: 1 = low / high half of the 256 mask bits, 2 = even / odd bits, 3 = bits with (i / 8) even / odd
     const int K2 = argc > 3 ? atoi(argv[3]) : 4096;         // K of the W2-shaped GEMM (N = 1024, 2 splits)
     if (K2 < 256 || K2 > 4096 || K2 % 128) { fprintf(stderr, "K2: a multiple of 128 up to 4096\n"); return 1; }
     if (K1 < 64 || K1 > 1024 || K1 % 64) { fprintf(stderr, "K1: a multiple of 64 up to 1024 (the weight buffer holds 4096 x 1024)\n"); return 1; }
@@ -32,7 +33,17 @@ int main(int argc, char **argv) {
     CHK(hipMemcpy(A, h.data(), (size_t)M * 4096 * 2 < h.size() * 2 ? (size_t)M * 4096 * 2 : h.size() * 2, hipMemcpyHostToDevice));
     for (int c = 0; c < 2; c++) { CHK(hipMalloc(&act[c], (size_t)M * 4096 * 2)); CHK(hipMalloc(&part[c], (size_t)2 * M * 1024 * 4)); }
     hipStream_t st[2];
-    for (auto &s : st) CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (mask_mode == 0) { for (auto &s : st) CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    else {
+        for (int c = 0; c < 2; c++) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 256; i++) {
+                const int side = mask_mode == 1 ? (i >= 128) : mask_mode == 2 ? (i & 1) : ((i >> 3) & 1);
+                if (side == c) mask[i >> 5] |= 1u << (i & 31);
+            }
+            CHK(hipExtStreamCreateWithCUMask(&st[c], 8, mask));
+        }
+    }
     for (int shape = 0; shape < 3; shape++)          // 2: chain 0 runs W1 launches, chain 1 W2 launches (different lengths: the phases drift)
         for (int cores = 0; cores < 2; cores++) {
             hipGraphExec_t ex[2];
@@ -59,8 +70,8 @@ int main(int argc, char **argv) {
                     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
                     if (us < t[n - 1]) t[n - 1] = us;
                 }
-            printf("[offset %d us, K1 %d, K2 %d] %s, %s rings: one chain %.2f us per launch; two chains side by side %.2f us per launch pair (%.2fx one chain)\n",
-                   offset_us, K1, K2, shape == 0 ? "W1 (4096 x 1024, SiLU bf16 out)" : shape == 1 ? "W2 (1024 x 4096, 2 splits, f32 partials)" : "chain 0 W1 / chain 1 W2 (one chain = W1 alone)", cores ? "shallow (two workgroups per CU)" : "deep (one workgroup per CU)",
+            printf("[offset %d us, K1 %d, K2 %d, masks %d] %s, %s rings: one chain %.2f us per launch; two chains side by side %.2f us per launch pair (%.2fx one chain)\n",
+                   offset_us, K1, K2, mask_mode, shape == 0 ? "W1 (4096 x 1024, SiLU bf16 out)" : shape == 1 ? "W2 (1024 x 4096, 2 splits, f32 partials)" : "chain 0 W1 / chain 1 W2 (one chain = W1 alone)", cores ? "shallow (two workgroups per CU)" : "deep (one workgroup per CU)",
                    t[0] / L, t[1] / L, t[1] / t[0]);
             for (auto &e : ex) CHK(hipGraphExecDestroy(e));
         }
