@@ -10,11 +10,15 @@
 //     for the access pattern, not inherited from the file format.
 //   * the weight tile is the MFMA A operand (rows = n), activations are the B operand
 //     (cols = m), so D[n][m]: lane holds 4 consecutive n for one m -> row-major stores.
-//   * k_gemm_skinny (M <= 128): weight-streaming kernel, HBM-bound.  One 16-column tile x one
+//   * k_gemm_skinny (M <= 32): weight-streaming kernel, HBM-bound.  One 16-column tile x one
 //     64-row slab per workgroup, K split over the 4 waves (and over blockIdx.y for split-K);
 //     activations go straight to registers (requested before the weights); no LDS in the loop.
-//   * k_gemm_tiled2 (M > 128): 128 rows x 128 cols per workgroup, both operands by LDS-DMA
-//     into a 4-slot ring, 8 waves.
+//   * M > 32: LDS-tiled kernels, both operands by LDS-DMA into a ring, staged epilogue.  Deep rings, one workgroup per CU:
+//     k_gemm_roles<4> (128 x 128 tile, 8 loader + 8 consumer waves; >= 8 chunks per workgroup), k_gemm_tiled2<4> (the same
+//     tile, 8 waves that do both; short K), k_gemm_t64<4> (128 x 64 tile x 2 K-splits for the N = 1024 GEMMs).  Shallow rings,
+//     TWO workgroups per CU (pipelined steps above 768 rows, every step from 1 792 rows; GemmParams::coresident):
+//     k_gemm_tiled2_k32<4> (32-deep chunks, 4 x 16 KiB) and k_gemm_t64<3> (72 KiB).  All of them perform the same MFMAs in the
+//     same order per accumulator: which one runs never changes a bit of the result (tests/micro/gemm_variant_identity.py).
 // f32 path (parity mode): plain LDS-tiled FMA kernel, k ascending, deterministic.
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
