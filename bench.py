@@ -525,6 +525,21 @@ def main():
         eng.synchronize()
         tsum = time.perf_counter() - tq
         buffered = dict(chunks_per_push=G, ms_per_push=round(1e3 * tsum / n_push, 3), value=round(n_push * nb / synth.SAMPLE_RATE / tsum, 1))
+        # the same pushes with pipelined steps (a file transcription does not need its tokens in the same call): the pieces of push
+        # k + 1 .. k + 3 run beside push k's.  Timed like the headline: priming pushes, then call-to-call time of the timed ones.
+        eng.synchronize()
+        eng2_stream.reset()
+        eng.set_option("pipeline", args.pipeline_depth if args.pipeline_depth in (2, 3, 4) else 4)
+        n_prime, n_timed = 8, 16
+        for k in range(n_prime):
+            push(k % (n_push + 1))
+        tq = time.perf_counter()
+        for k in range(n_timed):
+            push((n_prime + k) % (n_push + 1))
+        tsum = time.perf_counter() - tq
+        eng.synchronize()
+        buffered.update(pipelined_ms_per_push=round(1e3 * tsum / n_timed, 3), pipelined_value=round(n_timed * nb / synth.SAMPLE_RATE / tsum, 1))
+        eng.set_option("pipeline", 0)
         details["buffered_audio_note"] = ("same engine, same stream semantics (80 ms lookahead, chunk-by-chunk caches), the 256 chunks of a push go "
                                           "through every layer as one launch sequence; not the headline value")
 

@@ -19,7 +19,8 @@ static void usage(const char *prog) {
             "Usage: %s <model.gguf> <audio.pcm | -> [chunk_ms] [right_context] [--lang CODE] [--f32] [--device N] [--print-tokens] [--read-chunks N] [--timestamps] [--pipeline [E]]\n"
             "  audio: raw s16le, 16 kHz, mono.  right_context in {0, 1, 6, 13} (80 ms .. 1.12 s lookahead)\n"
             "  --read-chunks N: read N chunks of audio per call (default 1 = the reference's read size); a file is\n"
-            "                   transcribed fastest with N = 256: same transcript, the chunks of a read share one launch sequence\n"
+            "                   transcribed fastest with N = 256 and --pipeline 4: same transcript, the chunks of a read share one\n"
+            "                   launch sequence and consecutive reads run side by side\n"
             "  --timestamps:    print the final transcript again with {seconds} in front of every word\n"
             "  --pipeline E:    consecutive reads overlap on the GPU, E = 0..4 (same transcript; each delta appears E reads later).\n"
             "                   1: decode of one read beside the encoder of the next; 2..4: the encoder in E pieces on E hardware queues\n"

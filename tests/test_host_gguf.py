@@ -129,6 +129,11 @@ def test_cli_end_to_end(tmp_path):
         r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--print-tokens", flag], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         assert [int(x) for x in r.stdout.splitlines()[-1].split()[1:]] == ref, flag
+    # the fastest way through a file: many chunks per read AND pipelined steps (bench.py buffered_audio.pipelined_value)
+    r = subprocess.run([str(cli), str(model), str(audio), "80", "0", "--f32", "--print-tokens", "--read-chunks", "8", "--pipeline", "4"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert [int(x) for x in r.stdout.splitlines()[-1].split()[1:]] == ref
     r = subprocess.run([str(cli), str(model), str(audio), "80", "5"], capture_output=True, text=True)
     assert r.returncode == 1 and "right_context" in r.stderr
     # the default of nemo_init (bf16 engine, no --f32): against the bf16-emulating oracle -- same leading tokens, high aligned
