@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_spk_depthwise(const float *x, int x_pit
             if (t < L && c < C) {
 #pragma unroll
                 for (int i = 0; i < DW_KMAX; i++)
-                    if (i < kernel) { const float prod = in[u + i] * wk[i]; acc = i == 0 ? prod : acc + prod; }
+                    if (i < kernel) acc = i == 0 ? in[u + i] * wk[i] : __builtin_fmaf(in[u + i], wk[i], acc);   // explicit fma chain (what the compiler chose anyway: pinned)
             }
             if (t < SPK_T) store_a(a_out, ((size_t)s * SPK_T + t) * Cpad + c, acc, out_bf16);
         }
