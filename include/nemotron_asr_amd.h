@@ -242,6 +242,9 @@ typedef struct nasr_diar nasr_diar;
  * convolutions run on the bf16 MFMA with bf16 activation planes (3 workgroups per CU instead of 1; P(speech) within a few 1e-3).
  * max_windows / max_segments size the scratch (larger calls are tiled). */
 #define NASR_DIAR_VAD_BF16 0x100
+/* the same kernel with IEEE-half planes and weights on the f16 MFMA (same rate, 11 significand bits instead of 8: P(speech) within
+ * 1e-3, and the onset / offset segments of the f32 network on the config-5 audio -- tests/test_gpu_diar.py); values saturate at 65 504 */
+#define NASR_DIAR_VAD_F16  0x200
 int  nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
                       int max_windows, int max_segments);
 void nasr_diar_destroy(nasr_diar *d);

@@ -18,6 +18,7 @@ TYPE_F32, TYPE_F16, TYPE_Q4_0, TYPE_Q8_0 = 0, 1, 2, 8
 FLAG_PCM_DEVICE, FLAG_NO_SYNC = 1, 2
 FLAG_AUDIO_S16 = 4
 DIAR_VAD_BF16 = 0x100       # OR into Diar's dtype: MarbleNet on the bf16 MFMA
+DIAR_VAD_F16 = 0x200        # ... on the f16 MFMA with IEEE-half activation planes
 RESET_FRESH, RESET_REFERENCE = 0, 1
 TAP_MEL, TAP_SUBSAMPLED, TAP_LAYER_OUT, TAP_ENCODER_OUT, TAP_K_CACHE, TAP_V_CACHE, TAP_CONV_CACHE, TAP_DEC_STATE = range(8)
 

@@ -270,6 +270,7 @@ template <int NS>
 __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_groups, int m_chunks) {
     constexpr int P = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char ring[];
+    if (p.prio & 1) __builtin_amdgcn_s_setprio(3);
     const int nblk = gridDim.x;
     int id = blockIdx.x;
     {
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
         if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);     // the slot chunk i - 1 has just left
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
+    if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                           // every wave is done with the ring
     float *stage = (float *)ring;
 #pragma unroll
@@ -349,6 +351,7 @@ template <int NS>
 __global__ __launch_bounds__(512) void k_gemm_t64(GemmParams p, int n_groups, int m_chunks) {
     constexpr int P = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char ring[];
+    if (p.prio & 1) __builtin_amdgcn_s_setprio(3);
     const int nblk = gridDim.x;
     int id = blockIdx.x;
     {
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(512) void k_gemm_t64(GemmParams p, int n_groups, in
         }
         if (i + P < nchunks) issue(c0 + i + P, (i + P) % NS);
     }
+    if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                           // every wave is done with the ring
     float *stage = (float *)ring;              // f32 tile [128][68]
 #pragma unroll

@@ -58,6 +58,7 @@ struct nasr_diar {
     // TitaNet-L
     bool bf16 = true; int esz = 2;
     bool vad_bf16 = false;           // NASR_DIAR_VAD_BF16: MarbleNet on the bf16 MFMA with bf16 activation planes
+    bool vad_f16 = false;            // NASR_DIAR_VAD_F16: ... on the f16 MFMA with IEEE-half planes (same kernel, 8x less rounding)
     struct SpkSub { float *dw = nullptr; void *pw = nullptr; float *bias = nullptr; int kernel = 1, cin = 0, cin_pad = 0, cout = 0; };
     struct SpkBlock { int repeat = 1; bool residual = false; SpkSub sub[3], res; float *fc1 = nullptr, *fc2 = nullptr; int cin = 0, cout = 0; };
     SpkBlock spk[5];
@@ -155,7 +156,29 @@ std::vector<float> pack_mfma_f32(const std::vector<float> &w, int N, int K) {
 
 // pointwise weights [N][K] -> bf16 A-fragment tiles for v_mfma_f32_16x16x32_bf16 (the encoder GEMMs' layout): tile (nt, kt) = 16 rows x
 // 32 k, lane q*16+r holds W[nt*16+r][kt*32+q*8 .. +8); K zero-padded to a multiple of 32; round to nearest even
-std::vector<uint16_t> pack_mfma_bf16_host(const std::vector<float> &w, int N, int K) {
+static uint16_t f32_to_half_rne(float f) {           // IEEE binary16, round to nearest even, saturating (the kernel's planes saturate too)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                 // NaN
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);                // >= 65520 (rounds past the largest half) and Inf: 65504
+    if (u < 0x38800000u) {                                                  // below 2^-14: subnormal half (or zero)
+        if (u < 0x33000000u) return (uint16_t)sign;                         // below 2^-25
+        const int shift = 113 - (int)(u >> 23);                             // 1 .. 11 extra bits to drop
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;
+        const uint32_t drop = 13 + shift, half = 1u << (drop - 1), rest = m & ((1u << drop) - 1);
+        m >>= drop;
+        if (rest > half || (rest == half && (m & 1u))) m++;
+        return (uint16_t)(sign | m);
+    }
+    uint32_t h = ((u - 0x38000000u) >> 13);
+    const uint32_t rest = u & 0x1fffu;
+    if (rest > 0x1000u || (rest == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+std::vector<uint16_t> pack_mfma_bf16_host(const std::vector<float> &w, int N, int K, bool half = false) {
     const int NT = N / 16, KT = (K + 31) / 32;
     std::vector<uint16_t> out((size_t)NT * KT * 64 * 8, 0);
     for (int nt = 0; nt < NT; nt++)
@@ -166,6 +189,7 @@ std::vector<uint16_t> pack_mfma_bf16_host(const std::vector<float> &w, int N, in
                     if (k >= K) continue;
                     uint32_t u;
                     const float f = w[(size_t)(nt * 16 + (lane & 15)) * K + k];
+                    if (half) { out[(((size_t)nt * KT + kt) * 64 + lane) * 8 + j] = f32_to_half_rne(f); continue; }
                     memcpy(&u, &f, 4);
                     u += 0x7fffu + ((u >> 16) & 1u);
                     out[(((size_t)nt * KT + kt) * 64 + lane) * 8 + j] = (uint16_t)(u >> 16);
@@ -195,9 +219,9 @@ int load_vad(nasr_diar *d) {
             if (!pw || upload(d, pack_mfma_f32(*pw, t.cout, cin), &p)) return -1;
             vs.pw = p;
             vs.pw16 = nullptr;
-            if (d->vad_bf16) {
+            if (d->vad_bf16 || d->vad_f16) {
                 uint16_t *p16;
-                if (upload(d, pack_mfma_bf16_host(*pw, t.cout, cin), &p16)) return -1;
+                if (upload(d, pack_mfma_bf16_host(*pw, t.cout, cin, d->vad_f16), &p16)) return -1;
                 vs.pw16 = p16;
             }
             std::vector<float> sc, bi;
@@ -215,9 +239,9 @@ int load_vad(nasr_diar *d) {
             if (!pw || upload(d, pack_mfma_f32(*pw, t.cout, t.cin), &p)) return -1;
             vr.pw = p;
             vr.pw16 = nullptr;
-            if (d->vad_bf16) {
+            if (d->vad_bf16 || d->vad_f16) {
                 uint16_t *p16;
-                if (upload(d, pack_mfma_bf16_host(*pw, t.cout, t.cin), &p16)) return -1;
+                if (upload(d, pack_mfma_bf16_host(*pw, t.cout, t.cin, d->vad_f16), &p16)) return -1;
                 vr.pw16 = p16;
             }
             std::vector<float> sc, bi;
@@ -329,9 +353,10 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const
     DCHK(hipSetDevice(device_id));
     nasr_diar *d = new nasr_diar();
     d->device = device_id;
-    d->vad_bf16 = (dtype & NASR_DIAR_VAD_BF16) != 0;
-    dtype &= ~NASR_DIAR_VAD_BF16;
-    if (dtype != NASR_DTYPE_BF16 && dtype != NASR_DTYPE_F32) { delete d; return failf("dtype must be NASR_DTYPE_F32 or NASR_DTYPE_BF16 (optionally | NASR_DIAR_VAD_BF16)"); }
+    d->vad_f16 = (dtype & NASR_DIAR_VAD_F16) != 0;
+    d->vad_bf16 = !d->vad_f16 && (dtype & NASR_DIAR_VAD_BF16) != 0;
+    dtype &= ~(NASR_DIAR_VAD_BF16 | NASR_DIAR_VAD_F16);
+    if (dtype != NASR_DTYPE_BF16 && dtype != NASR_DTYPE_F32) { delete d; return failf("dtype must be NASR_DTYPE_F32 or NASR_DTYPE_BF16 (optionally | NASR_DIAR_VAD_BF16 or NASR_DIAR_VAD_F16)"); }
     d->bf16 = dtype == NASR_DTYPE_BF16;      // TitaNet's pointwise convolutions; MarbleNet is f32 unless NASR_DIAR_VAD_BF16 is set
     d->esz = d->bf16 ? 2 : 4;
     d->max_windows = std::max(max_windows, 1);
@@ -442,7 +467,7 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     set_audio(d, flags, mp);
     mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band; mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
     launch_diar_frames(mp, d->fr_desc, (int)n_frames, d->fr_mel, d->st);
-    (d->vad_bf16 ? launch_vad_marblenet_bf16 : launch_vad_marblenet)(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
+    (d->vad_f16 ? launch_vad_marblenet_f16 : d->vad_bf16 ? launch_vad_marblenet_bf16 : launch_vad_marblenet)(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
     DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)W * sizeof(float), hipMemcpyDeviceToHost, d->st));
     DCHK(hipStreamSynchronize(d->st));
     for (int b = 0; b < B; b++) {

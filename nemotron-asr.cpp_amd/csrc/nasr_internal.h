@@ -111,6 +111,9 @@ struct GemmParams {
     // pipelined steps: this launch shares the chip with other launch chains' GEMMs -- the large-M kernels then use the variants
     // whose LDS ring lets two workgroups share a CU (same arithmetic in the same order: bit-identical to the default kernels)
     int coresident;
+    // wave priority of the co-resident kernels (round-4 probe, tests/micro/cores_probe.hip): bit 0 = s_setprio 3 for the whole kernel,
+    // bit 1 = back to 0 before the epilogue.  0 = leave the default (what ships unless the probe says otherwise).
+    int prio;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
@@ -257,7 +260,7 @@ void launch_diar_logmel(const DiarMelParams &p, int W, bool per_feature_normaliz
 struct DiarFrameDesc { long long base; int n; int t; };
 void launch_diar_frames(const DiarMelParams &p, const DiarFrameDesc *frames, int n_frames, float *out, hipStream_t st);
 
-struct VadSub { const float *dw, *pw, *scale, *bias; int kernel, dil, cin, cout; const bf16_t *pw16; };   // dw == nullptr: pointwise only; pw16: bf16 fragment tiles (NASR_DIAR_VAD_BF16), else null
+struct VadSub { const float *dw, *pw, *scale, *bias; int kernel, dil, cin, cout; const bf16_t *pw16; };   // dw == nullptr: pointwise only; pw16: bf16 / half fragment tiles (NASR_DIAR_VAD_BF16 / _F16), else null
 struct VadNet {                   // MarbleNet, src/diarize_vad.cpp:25-32: 6 blocks, 9 sub-convs, 3 residual paths
     VadSub sub[9];
     VadSub res[3];                // blocks 1..3
@@ -270,6 +273,8 @@ void launch_vad_marblenet(const VadNet &net, const float *shared, const float *e
                           float *prob, int W, hipStream_t st);
 void launch_vad_marblenet_bf16(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
                                float *prob, int W, hipStream_t st);       // the same network on the bf16 MFMA, bf16 activation planes
+void launch_vad_marblenet_f16(const VadNet &net, const float *shared, const float *edge, const int *win_row, const int *lens_mel,
+                              float *prob, int W, hipStream_t st);        // ... on the f16 MFMA, IEEE-half planes (pw16 = half tiles)
 void init_diar_kernel_attributes();
 
 // TitaNet-L pieces (src/diarize_spk.cpp:320-515); activations [S * 160][C] f32, channels innermost

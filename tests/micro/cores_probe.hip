@@ -20,6 +20,7 @@ int main(int argc, char **argv) {
     const int K1 = argc > 2 ? atoi(argv[2]) : 1024;         // K of the W1-shaped GEMM (sweep: fixed part and per-chunk part of a launch)      // chain 1 starts this much later (a one-workgroup spin kernel at the head of its graph)
     const int fence_mode = argc > 4 ? atoi(argv[4]) : 0;    // 1: chain 1 = empty launches (8 per GEMM launch of chain 0): what do its kernel boundaries cost chain 0?
     const int mask_mode = argc > 5 ? atoi(argv[5]) : 0;     // CU masks of the two streams: 1 = low / high half of the 256 mask bits, 2 = even / odd bits, 3 = bits with (i / 8) even / odd
+    const int prio_mode = argc > 6 ? atoi(argv[6]) : 0;     // GemmParams::prio of chain 0 (chain 1 keeps 0): 1 = s_setprio 3 throughout, 3 = only in the K loop; +4: chain 1 gets it instead
     const int K2 = argc > 3 ? atoi(argv[3]) : 4096;         // K of the W2-shaped GEMM (N = 1024, 2 splits)
     if (K2 < 256 || K2 > 4096 || K2 % 128) { fprintf(stderr, "K2: a multiple of 128 up to 4096\n"); return 1; }
     if (K1 < 64 || K1 > 1024 || K1 % 64) { fprintf(stderr, "K1: a multiple of 64 up to 1024 (the weight buffer holds 4096 x 1024)\n"); return 1; }
@@ -50,7 +51,7 @@ int main(int argc, char **argv) {
             for (int c = 0; c < 2; c++) {
                 GemmParams g;
                 memset(&g, 0, sizeof(g));
-                g.A = A; g.W = W; g.M = M; g.coresident = cores;
+                g.A = A; g.W = W; g.M = M; g.coresident = cores; g.prio = (c == ((prio_mode >> 2) & 1)) ? (prio_mode & 3) : 0;
                 if (shape == 0 || (shape == 2 && c == 0)) { g.N = 4096; g.K = K1; g.lda = K1; g.splits = 1; g.epi = EPI_SILU_ACT; g.out_act = act[c]; g.ldo_act = 4096; }
                 else { g.N = 1024; g.K = K2; g.lda = K2; g.splits = 2; g.epi = EPI_PART_F32; g.out_f32 = part[c]; g.ldo = 1024; }
                 hipGraph_t gr;
@@ -70,8 +71,8 @@ int main(int argc, char **argv) {
                     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
                     if (us < t[n - 1]) t[n - 1] = us;
                 }
-            printf("[offset %d us, K1 %d, K2 %d, masks %d] %s, %s rings: one chain %.2f us per launch; two chains side by side %.2f us per launch pair (%.2fx one chain)\n",
-                   offset_us, K1, K2, mask_mode, shape == 0 ? "W1 (4096 x 1024, SiLU bf16 out)" : shape == 1 ? "W2 (1024 x 4096, 2 splits, f32 partials)" : "chain 0 W1 / chain 1 W2 (one chain = W1 alone)", cores ? "shallow (two workgroups per CU)" : "deep (one workgroup per CU)",
+            printf("[offset %d us, K1 %d, K2 %d, masks %d, prio %d] %s, %s rings: one chain %.2f us per launch; two chains side by side %.2f us per launch pair (%.2fx one chain)\n",
+                   offset_us, K1, K2, mask_mode, prio_mode, shape == 0 ? "W1 (4096 x 1024, SiLU bf16 out)" : shape == 1 ? "W2 (1024 x 4096, 2 splits, f32 partials)" : "chain 0 W1 / chain 1 W2 (one chain = W1 alone)", cores ? "shallow (two workgroups per CU)" : "deep (one workgroup per CU)",
                    t[0] / L, t[1] / L, t[1] / t[0]);
             for (auto &e : ex) CHK(hipGraphExecDestroy(e));
         }

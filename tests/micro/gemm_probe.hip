@@ -557,16 +557,34 @@ static double run_roles32(const GemmParams &p0, hipStream_t st, int reps) {
 // Every wave executes the same number of s_barriers: G + 16 (G = chunks of all this workgroup's tiles).
 constexpr int PS_NS = 3, PS_STAGE = PS_NS * G2_SLOT;            // staging tile [128][128] f32, 16-byte column groups XOR-swizzled by the row
 __device__ __forceinline__ unsigned stage_off(int row, int cg) { return PS_STAGE + row * 512 + ((cg ^ (row & 31)) << 4); }
-__global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_groups, int m_chunks) {
+// tile order (round 4): 0 = round 3's (tile id = i * grid + block: the 32 workgroups of an XCD hold 32 different m-chunks of ONE
+// n-group at a time, so every activation panel is fetched from MALL / HBM once per n-group: 32 x 14.7 MB for W1 at M = 7 168);
+// 1 = an m-band per XCD (block & 7): XCD x owns m-chunks [m_chunks x / 8, m_chunks (x + 1) / 8) x all n-groups and walks them m fastest,
+// so its activation panels stay in its L2 for the whole launch and every weight panel is fetched once per XCD; 2 = an n-band per XCD.
+__device__ __forceinline__ int persist_tiles(int order, int n_groups, int m_chunks, int block, int grid, int &lo, int &band) {
+    if (order == 0) { lo = 0; band = 0; return (n_groups * m_chunks - block + grid - 1) / grid; }
+    const int x = block & 7, slot = block >> 3, S = grid >> 3, dim = order == 1 ? m_chunks : n_groups, other = order == 1 ? n_groups : m_chunks;
+    lo = dim * x / 8;
+    band = dim * (x + 1) / 8 - lo;
+    const int tiles = band * other;
+    return slot < tiles ? (tiles - slot + S - 1) / S : 0;
+}
+__device__ __forceinline__ void persist_tile_mn(int order, int i, int n_groups, int m_chunks, int block, int grid, int lo, int band, int &m0, int &ng) {
+    if (order == 0) { const int id = i * grid + block; m0 = (id % m_chunks) * TM; ng = id / m_chunks; return; }
+    const int u = (block >> 3) + i * (grid >> 3);
+    if (order == 1) { ng = u / band; m0 = (lo + u % band) * TM; }
+    else { m0 = (u / band) * TM; ng = lo + u % band; }
+}
+__global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_groups, int m_chunks, int order) {
     const bool getenv_silu_storer = p.rows_per_batch == -7;      // probe switch: SiLU in the storer waves instead of the consumers
     extern __shared__ __attribute__((aligned(16))) char ring[];
-    const int n_tiles = n_groups * m_chunks;
-    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int band_lo, band_n;
+    const int my_tiles = persist_tiles(order, n_groups, m_chunks, (int)blockIdx.x, (int)gridDim.x, band_lo, band_n);
     const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int KT = p.K >> 5, CPT = KT >> 1;                      // chunks per tile (64-deep)
     const int G = my_tiles * CPT, NB = G + 16;      // the last tile is parked at interval G and drained in intervals G + 1 .. G + 15
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
-    auto tile_mn = [&](int i, int &m0, int &ng) { const int id = i * (int)gridDim.x + (int)blockIdx.x; m0 = (id % m_chunks) * TM; ng = id / m_chunks; };
+    auto tile_mn = [&](int i, int &m0, int &ng) { persist_tile_mn(order, i, n_groups, m_chunks, (int)blockIdx.x, (int)gridDim.x, band_lo, band_n, m0, ng); };
     if (wave16 >= 8 && wave16 < 12) {
         // ---------------- loaders ----------------
         const int lw = wave16 - 8, prow = lane >> 3, pc = lane & 7;
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_grou
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
-static double run_persist(const GemmParams &p0, hipStream_t st, int reps) {
+static double run_persist(const GemmParams &p0, hipStream_t st, int reps, int order = 0) {
     GemmParams p = p0;
     const int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
     const int tiles = n_groups * m_chunks;
@@ -698,9 +716,9 @@ static double run_persist(const GemmParams &p0, hipStream_t st, int reps) {
     hipFuncSetAttribute((const void *)k_probe_persist, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks, order);
     hipEventRecord(a, st);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks, order);
     hipEventRecord(b, st);
     hipEventSynchronize(b);
     float ms = 0;
@@ -797,6 +815,19 @@ int main() {
                 p3.T = 777;
                 const double t11n = run_persist(p3, st, 100);
                 printf("%-28s PERSISTENT: mismatches %zu | %6.2f us (%5.0f TFLOP/s) | without stores %6.2f us\n", s.name, bad3, t11, flops / t11 * 1e-6, t11n);
+                for (int order = 1; order <= 2; order++) {
+                    GemmParams p5 = p2; p5.epi = EPI_PART_F32;
+                    hipMemset(out2, 0xff, n_out * 4);
+                    run_persist(p5, st, 1, order);
+                    hipMemcpy(r2.data(), out2, n_out * 4, hipMemcpyDeviceToHost);
+                    size_t bad5 = 0;
+                    for (size_t i = 0; i < n_out; i++) bad5 += r1[i] != r2[i];
+                    p5.epi = s.epi;
+                    const double t = run_persist(p5, st, 100, order);
+                    p5.T = 777;
+                    const double tn = run_persist(p5, st, 100, order);
+                    printf("%-28s PERSISTENT, %s-band per XCD: mismatches %zu | %6.2f us (%5.0f TFLOP/s) | without stores %6.2f us (%5.0f TFLOP/s)\n", s.name, order == 1 ? "m" : "n", bad5, t, flops / t * 1e-6, tn, flops / tn * 1e-6);
+                }
             }
             p.T = 777; p2.T = 777;
             const double t7n = run_roles(p, st, 200), t10n = run_roles32(p2, st, 200);
