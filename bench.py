@@ -65,6 +65,7 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 (spec)
 HBM_MEASURED_GBS = 6290.0
 MFMA_MEASURED_TFLOPS = 1261.0
 REPEATS = 5
+ENGINE_OPTIONS = []          # filled from --engine-option
 
 
 def parse(argv=None):
@@ -105,6 +106,8 @@ def parse(argv=None):
     ap.add_argument("--extra-steps", type=int, default=200, help="timed steps per region of the extra configurations")
     ap.add_argument("--diarize", action="store_true",
                     help="BASELINE config 5 on the HEADLINE workload too: also time the diarization side-car on each step's audio")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="nasr_engine_set_option on every engine of the run before its first step (gemm_cores, persistent_gemm, f32_mfma, ...)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks started by --gpus N (0: pick a free one)")
     ap.add_argument("--stub-engine", action="store_true",
                     help=argparse.SUPPRESS)   # launch-path test only (tests/test_bench_launch.py): no GPU, gloo, a sleeping stand-in
@@ -179,6 +182,9 @@ class Run:
         self.B, self.R, self.T = B, R, 1 + R
         self.n_step = synth.shift_samples(R) * chunks_per_step
         self.eng = capi.Engine(engW, n_layers=layers, dtype=dtype, max_streams=B, device=device)
+        for kv in ENGINE_OPTIONS:                  # --engine-option key=value (A/B runs: tests/micro/ab_b64.sh)
+            k, v = kv.split("=", 1)
+            self.eng.set_option(k, int(v))
         self.eng.set_option("pipeline", pipeline)
         self.streams = [self.eng.stream(R) for _ in range(B)]
         self.n_avail = max(2, int(audio_s * synth.SAMPLE_RATE) // self.n_step)       # steps of audio per stream before it wraps
@@ -365,6 +371,7 @@ def reference_cli_baseline(pcm, R):
 
 def main():
     args = parse()
+    ENGINE_OPTIONS[:] = args.engine_option
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

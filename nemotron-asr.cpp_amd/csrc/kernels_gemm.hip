@@ -23,7 +23,6 @@
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
 #include "nasr_wave.h"
-#include <cstdlib>
 
 namespace nasr {
 
@@ -560,6 +559,197 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
     staged_epilogue<1024>(p, split, m0, ng * 128, stage);
 }
 
+// ------------------------------------------------------------------------------------
+// PERSISTENT tile loop (round 4; probe: tests/micro/gemm_probe.hip mode 11) for GEMMs with several 128 x 128 tiles per CU (128+
+// streams x R = 13, buffered audio, TitaNet-L: M >= 1 792).  One workgroup per CU walks its tiles (tile id = i * grid + block):
+//   waves 0-7   consumers: k_gemm_roles' tiling and MFMA order (32 n x 64 m per wave, k ascending) -- same bits;
+//   waves 8-11  loaders: 8 LDS-DMA instructions per 64-deep chunk each, running straight on into the next tile's chunks, so the ring
+//               (3 x 32 KiB) never drains between tiles;
+//   waves 12-15 storers: the consumers park a finished tile as raw f32 in a 64 KiB staging tile BESIDE the ring (96 + 64 = the CU's
+//               160 KiB) and go on multiplying; the storers evaluate the epilogue (SiLU, GLU, bias, K/V scatter) and write the tile
+//               out in 16 slices of 8 rows, one per chunk interval of the next tile (two in the fifteenth).
+// Every wave executes G + 16 barriers (G = chunks of all tiles of the workgroup).  What the round-3 probe left on the table was in the
+// storers (stamps: profiles/r4_persistent_gemm.md): their slice took 0.44-0.56 us -- the epilogue switch, 64-bit index arithmetic and a
+// branchy bf16 pack in ONE wave's dependent instruction stream -- and set the length of every chunk interval (0.68 us against 0.42
+// with idle storers); and SiLU in the consumers stalled the MFMAs 1.3 us per tile.  Here the epilogue is a template parameter, the
+// per-tile pointers are computed once, the pack is branch-free and SiLU is the storers' work.
+// ------------------------------------------------------------------------------------
+constexpr int PS_NS = 3, PS_STAGE = PS_NS * G2_SLOT, PS_LDS = PS_STAGE + 65536;
+__device__ __forceinline__ unsigned ps_stage_off(int row, int cg) { return PS_STAGE + row * 512 + ((cg ^ (row & 31)) << 4); }
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // f32_to_bf16 without a branch (same values, NaN kept NaN)
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return (u & 0x7fffffffu) > 0x7f800000u ? ((u >> 16) | 0x40u) : r;
+}
+template <int EPI>
+__global__ __launch_bounds__(1024) void k_gemm_persist(GemmParams p, int n_groups, int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int n_tiles = n_groups * m_chunks, grid = (int)gridDim.x, block = (int)blockIdx.x;
+    const int my_tiles = (n_tiles - block + grid - 1) / grid;
+    const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int KT = p.K >> 5, CPT = KT >> 1;                      // 64-deep chunks per tile (>= 16: the launcher checks)
+    const int G = my_tiles * CPT, NB = G + 16;                   // the last tile is parked in interval G and drained in G + 1 .. G + 15
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto tile_mn = [&](int i, int &m0, int &ng) { const int id = i * grid + block; m0 = (id % m_chunks) * TM; ng = id / m_chunks; };
+    if (wave16 >= 8 && wave16 < 12) {
+        // ---------------- loaders ----------------
+        const int lw = wave16 - 8, prow = lane >> 3, pc = lane & 7;
+        const char *asrc[4];
+        const uint4 *wpd[2];
+        auto set_tile = [&](int i) {
+            int m0, ng;
+            tile_mn(i, m0, ng);
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int row = lw * 32 + a * 8 + prow;
+                int m = m0 + row;
+                if (m >= p.M) m = p.M - 1;
+                asrc[a] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) wpd[j] = (const uint4 *)p.W + (size_t)(ng * 8 + 2 * lw + j) * KT * 64 + lane;
+        };
+        int it = 0, ikc = 0;                                     // tile / chunk-in-tile of the next chunk to issue
+        if (G > 0) set_tile(0);
+        auto issue_next = [&](int g) {
+            const unsigned sb = lds0 + (g % PS_NS) * G2_SLOT;
+#pragma unroll
+            for (int a = 0; a < 4; a++) glds16(asrc[a] + (size_t)ikc * 128, sb + (lw * 32 + a * 8) * 128);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const unsigned wb = sb + 16384 + lw * 4096 + j * 2048;
+                glds16(wpd[j] + (size_t)(2 * ikc) * 64, wb);
+                glds16(wpd[j] + (size_t)(2 * ikc + 1) * 64, wb + 1024);
+            }
+            if (++ikc == CPT) { ikc = 0; if (++it < my_tiles) set_tile(it); }
+        };
+        for (int g = 0; g < PS_NS - 1 && g < G; g++) issue_next(g);
+        for (int g = 0; g < NB; g++) {
+            if (g < G) {
+                if (G - 1 - g >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // chunk g landed, chunk g + 1 may be in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (g + PS_NS - 1 < G) issue_next(g + PS_NS - 1);
+        }
+        return;
+    }
+    if (wave16 >= 12) {
+        // ---------------- storers: the tile parked in the staging area, 8 rows per slice ----------------
+        const int sw = wave16 - 12, half = lane >> 5, cg = lane & 31;
+        int ti = -1, m0 = 0, ng = 0, n0 = 0;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int kv_which = 0;
+        int rd_slot = 0, rd_head = 0;                            // EPI_QKV: the slice's row descriptor, requested one interval ahead
+        auto qkv_fetch = [&](int m) {
+            if (EPI != EPI_QKV) return;
+            if (m >= p.M) m = p.M - 1;
+            const RowDesc *rd = p.rows + m / p.T;
+            rd_slot = rd->slot; rd_head = rd->kv_head;
+        };
+        auto emit = [&](int row, int fetch_row) {
+            const float4 v = *(const float4 *)(ring + ps_stage_off(row, cg));
+            const int m = m0 + row;
+            const int my_slot = rd_slot, my_head = rd_head;
+            if (fetch_row >= 0) qkv_fetch(m0 + fetch_row);       // the next slice's descriptor travels while this slice is stored
+            if (m >= p.M) return;
+            if (EPI == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
+            else if (EPI == EPI_SILU_ACT) {
+                const float a = silu_f(v.x), b = silu_f(v.y), c = silu_f(v.z), d = silu_f(v.w);
+                store_wt_u2((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0, make_uint2(bf16_rne_bits(a) | (bf16_rne_bits(b) << 16), bf16_rne_bits(c) | (bf16_rne_bits(d) << 16)));
+            } else if (EPI == EPI_GLU) {
+                *(float2 *)(p.out_f32 + (size_t)m * p.ldo + (n0 >> 1)) = make_float2(v.x * sigmoid_f(v.y), v.z * sigmoid_f(v.w));
+            } else if (EPI == EPI_BIAS_F32) {
+                *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) = make_float4(v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w);
+            } else if (EPI == EPI_BIAS_RELU_F32) {
+                *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) = make_float4(fmaxf(v.x + bias4.x, 0.f), fmaxf(v.y + bias4.y, 0.f), fmaxf(v.z + bias4.z, 0.f), fmaxf(v.w + bias4.w, 0.f));
+            } else if (EPI == EPI_QKV) {
+                if (kv_which == 0) *(float4 *)(p.q_out + (size_t)m * D + n0) = v;
+                else {
+                    const int i = m - (m / p.T) * p.T;
+                    int r = my_head + LCTX + i;
+                    if (r >= KVC) r -= KVC;
+                    const size_t off = (size_t)my_slot * p.kv_slot_stride + ((size_t)(kv_which - 1) * KVC + r) * D + (n0 & 1023);
+                    *(uint2 *)((bf16_t *)p.kv_pool + off) = make_uint2(bf16_rne_bits(v.x) | (bf16_rne_bits(v.y) << 16), bf16_rne_bits(v.z) | (bf16_rne_bits(v.w) << 16));
+                }
+            }
+        };
+        for (int g = 0; g < NB; g++) {
+            __builtin_amdgcn_s_barrier();
+            if (g < 1) continue;
+            const int u = g - 1, t = u / CPT - 1, sl = u - (u / CPT) * CPT;
+            if (t < 0 || t >= my_tiles || sl >= 15) continue;
+            if (t != ti) {                                       // first slice of a tile: its constants
+                ti = t;
+                tile_mn(t, m0, ng);
+                n0 = ng * 128 + cg * 4;
+                if (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RELU_F32) bias4 = *(const float4 *)(p.bias + n0);
+                if (EPI == EPI_QKV) { kv_which = n0 >> 10; qkv_fetch(m0 + 2 * sw + half); }
+            }
+            const int row = 8 * sl + 2 * sw + half;
+            emit(row, row + 8);
+            if (sl == 14) emit(row + 8, -1);
+        }
+        return;
+    }
+    // ---------------- consumers (k_gemm_roles' loop; a finished tile is parked raw and the accumulators restart from zero) ----------------
+    const int wave = wave16, ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned w_addr = lds0 + 16384 + ng4 * 4096 + lane * 16;
+    unsigned b_addr[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) b_addr[k2] = lds0 + panel_off(mh * 64 + r, k2 * 4 + q);
+    uint4 wA[2], bA[4], wB[2], bB[4];
+    auto mm = [&](uint4 (&w)[2], uint4 (&bv)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv[mt]);
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0]), bf, acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1]), bf, acc[1][mt], 0, 0, 0);
+        }
+    };
+    int in_tile = 0;                                             // chunks of the current tile multiplied so far (second halves pending)
+    for (int g = 0; g < NB; g++) {
+        __builtin_amdgcn_s_barrier();
+        const unsigned so = (unsigned)(g % PS_NS) * G2_SLOT;
+        if (g < G) {
+            const unsigned wa = w_addr + so, ba = b_addr[0] + so;
+            LDS_RD(wA[0], wa, 0); LDS_RD(wA[1], wa, 2048);
+            LDS_RD(bA[0], ba, 0); LDS_RD(bA[1], ba, 2048); LDS_RD(bA[2], ba, 4096); LDS_RD(bA[3], ba, 6144);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0 && g <= G) mm(wB, bB);                         // second half of chunk g - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0 && g <= G && in_tile == CPT) {                 // the tile is complete: park it, start the next one from zero
+            in_tile = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    const int row = (mh * 4 + mt) * 16 + r, cgw = (ng4 * 2 + j) * 4 + q;
+                    *(float4 *)(ring + ps_stage_off(row, cgw)) = make_float4(acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+                    acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < G) {
+            const unsigned wa = w_addr + so + 1024, ba = b_addr[1] + so;
+            LDS_RD(wB[0], wa, 0); LDS_RD(wB[1], wa, 2048);
+            LDS_RD(bB[0], ba, 0); LDS_RD(bB[1], ba, 2048); LDS_RD(bB[2], ba, 4096); LDS_RD(bB[3], ba, 6144);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mm(wA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            in_tile++;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 static size_t gemm_lds_bytes(int ns) {     // the ring, or the f32 tile the epilogue parks in it, whichever is larger
     const size_t ring = (size_t)ns * G2_SLOT, stage = (size_t)TM * STG_LD * 4;
     return ring > stage ? ring : stage;
@@ -570,12 +760,26 @@ static size_t gemm_k32_lds_bytes(int ns) {
     return ring > stage ? ring : stage;
 }
 
+constexpr int F32M_KC = 32, F32M_NS = 3;
+template <int BM, int BN> __global__ void k_gemm_f32_mfma(GemmParams p, int n_groups, int m_chunks);      // the f32 engine's MFMA kernel, below
+
+static int g_num_cus = 256;      // MI355X; refreshed from the device below
 void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_tiled2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_roles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_t64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_t64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_persist<EPI_PART_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    hipFuncSetAttribute((const void *)k_gemm_persist<EPI_SILU_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    hipFuncSetAttribute((const void *)k_gemm_persist<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    hipFuncSetAttribute((const void *)k_gemm_persist<EPI_GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
+    hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
+    hipFuncSetAttribute((const void *)k_gemm_f32_mfma<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 128 * 128);
 }
 
 // 128 x 64 tiles (k_gemm_t64): for the split-K GEMMs with N = 1024 when that halves the split factor, and for any other GEMM
@@ -585,12 +789,10 @@ void init_gemm_kernel_attributes() {
 // 1.22 vs 1.32 ms per step, 32 streams (64-128 tiles) 1.82 vs 1.77, 64 streams (pw1: 112 tiles -> 224) 2.66 vs 2.65 -- although
 // alone the 112-tile launch takes 13.3 us and the vendor library's MT128x64 kernel 10.6 (tests/prof_gemm_shapes.sh).
 bool gemm_use_t64(int M, int N, int epi) {
-    static const int on = getenv("NASR_GEMM_T64") ? atoi(getenv("NASR_GEMM_T64")) : 1;
-    if (!on || M <= gemm_skinny_max_m()) return false;
+    if (M <= gemm_skinny_max_m()) return false;
     const int tiles = (N / 128) * ((M + 127) / 128);
     if (epi == EPI_PART_F32) return N == 1024 && tiles < 128;
-    static const int wide_max = getenv("NASR_GEMM_T64_WIDE") ? atoi(getenv("NASR_GEMM_T64_WIDE")) : 64;
-    return tiles <= wide_max;
+    return tiles <= 64;
 }
 int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 128; }
 
@@ -603,8 +805,7 @@ int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 1
 // -> 32 rows.  ONE threshold for both modes: which kernel a GEMM runs on must not depend on the mode, or pipelined steps would
 // stop being bit-identical to synchronous ones (the synchronous step pays <= 6 % for it between 33 and 64 rows and gains above).
 int gemm_skinny_max_m() {
-    static const int v = getenv("NASR_SKINNY_MAXM") ? atoi(getenv("NASR_SKINNY_MAXM")) : 32;
-    return v;
+    return 32;
 }
 
 // Pipelined steps (GemmParams::coresident): four launch chains advance in lock-step rounds, so the GEMM launches of a round start
@@ -614,12 +815,11 @@ int gemm_skinny_max_m() {
 // From seven 128-row tiles up (M > 768), where every GEMM of the step covers most of the chip: measured per step with four lanes,
 // 64 streams x R = 13 (M = 896) 2.61 -> 2.47 ms, 48 streams (M = 672) 2.05 -> 2.03, 40 streams (M = 560) 1.76 -> 1.81, 32 streams 1.51 -> 1.59.
 static bool gemm_coresident(const GemmParams &p) {
-    static const int force = getenv("NASR_GEMM_CORES") ? atoi(getenv("NASR_GEMM_CORES")) : -1;    // 0: never, 1: always (A/B runs)
-    static const int min_m = getenv("NASR_GEMM_CORES_MIN_M") ? atoi(getenv("NASR_GEMM_CORES_MIN_M")) : 769;
-    if (force >= 0) return force != 0;
+    constexpr int min_m = 769;
+    if (p.coresident >= 2) return p.coresident == 2;          // engine option "gemm_cores" (A/B runs, the bit-identity test)
     // more than one wave of tiles (M >= 1 792): workgroups of ONE launch start as earlier ones finish, so the two on a CU are out of
     // phase by themselves -- synchronous steps gain as well (128 streams x R = 13: 6.51 -> 5.95 ms, 512 streams 19.9 -> 18.6 ms)
-    return p.M >= 1792 || (p.coresident && p.M >= min_m);
+    return p.M >= 1792 || (p.coresident == 1 && p.M >= min_m);
 }
 
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
@@ -640,12 +840,26 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 hipLaunchKernelGGL(k_gemm_t64<4>, dim3(n_groups * m_chunks * p.splits), dim3(512), 4 * T64_SLOT, st, p, n_groups, m_chunks);
             return;
         }
+        // several 128 x 128 tiles per CU: the persistent tile loop (one workgroup per CU; ring fills and epilogues off the critical path).
+        // From 1.75 tiles per CU: below that a workgroup has no second tile to hide anything under.
+        if (!p.no_persist && p.splits == 1 && p.K >= 1024 && (p.K & 63) == 0 && (long)n_groups * m_chunks * 4 >= (long)g_num_cus * 7) {
+            const dim3 pgrid(g_num_cus), pblock(1024);
+            switch (p.epi) {
+            case EPI_PART_F32: hipLaunchKernelGGL(k_gemm_persist<EPI_PART_F32>, pgrid, pblock, PS_LDS, st, p, n_groups, m_chunks); return;
+            case EPI_SILU_ACT: hipLaunchKernelGGL(k_gemm_persist<EPI_SILU_ACT>, pgrid, pblock, PS_LDS, st, p, n_groups, m_chunks); return;
+            case EPI_QKV: hipLaunchKernelGGL(k_gemm_persist<EPI_QKV>, pgrid, pblock, PS_LDS, st, p, n_groups, m_chunks); return;
+            case EPI_GLU: hipLaunchKernelGGL(k_gemm_persist<EPI_GLU>, pgrid, pblock, PS_LDS, st, p, n_groups, m_chunks); return;
+            case EPI_BIAS_F32: hipLaunchKernelGGL(k_gemm_persist<EPI_BIAS_F32>, pgrid, pblock, PS_LDS, st, p, n_groups, m_chunks); return;
+            case EPI_BIAS_RELU_F32: hipLaunchKernelGGL(k_gemm_persist<EPI_BIAS_RELU_F32>, pgrid, pblock, PS_LDS, st, p, n_groups, m_chunks); return;
+            default: break;                        // the act-dtype bias epilogues (subsampling) stay on the per-tile kernels
+            }
+        }
         dim3 grid(n_groups * m_chunks * p.splits);
         if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU
             hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             return;
         }
-        static const int roles_min_chunks = getenv("NASR_ROLES_MIN_CHUNKS") ? atoi(getenv("NASR_ROLES_MIN_CHUNKS")) : 8;
+        constexpr int roles_min_chunks = 8;
         const bool roles = (p.K >> 6) / p.splits >= roles_min_chunks;
         const size_t lds = gemm_lds_bytes(4);
         if (roles) hipLaunchKernelGGL(k_gemm_roles<4>, grid, dim3(1024), lds, st, p, n_groups, m_chunks);
@@ -772,12 +986,112 @@ __global__ __launch_bounds__(256) void k_gemm_f32_rows(GemmParams p) {
     if (active) epi_elem_f32(p, m, n0 + r, acc, vp);
 }
 
+// ------------------------------------------------------------------------------------
+// The f32 engine above four rows on the f32-input MFMA (round 4).  v_mfma_f32_32x32x2_f32 multiplies f32 operands exactly and adds the
+// products to the accumulator one k after the other -- the fmaf chain of k_gemm_f32 (MI355X_MICROARCH.md, matrix-core table: "exact
+// f32 (= fmaf chain, bitwise)") -- so a kernel that feeds it k ascending from a zero accumulator returns k_gemm_f32's bits at the f32
+// matrix rate (155 TFLOP/s against the ~10 the FMA tile reaches): the configuration whose tokens equal the oracle's on ANY
+// checkpoint becomes usable at batch 64 (tests/test_gpu_parity.py::test_f32_mfma_gemm_is_bit_identical_to_the_fma_tile).
+//   tile BM (rows m) x BN (weight rows n), 4 waves = 2 x 2 sub-tiles of (BM/2) x (BN/2), 32-deep K chunks (128 B per row) of both
+//   operands by LDS-DMA into a 3-slot ring, 16-byte columns XOR-swizzled by the row on the SOURCE side.  Weights are the MFMA's A
+//   operand (rows = n), activations its B operand (columns = m): lane l feeds row / column l & 31 at k = k0 + (l >> 5) and holds
+//   D[n = 8 (i / 4) + 4 (l / 32) + i % 4][m = l & 31] in accumulator register i: four consecutive n per quad -> epi_quad<false>.
+// ------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int ROWS = BM + BN, SLOT = ROWS * 128, DMA = ROWS / 32;      // DMA instructions per wave and chunk (8 rows each)
+    constexpr int IM = BM / 64, IN = BN / 64;                              // 32 x 32 blocks per wave along m / n
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    int id = blockIdx.x;
+    {
+        const int nblk = gridDim.x, qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, ng = id / m_chunks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, kh = lane >> 5;
+    const int m0 = mc * BM, n0 = ng * BN, nchunks = p.K / F32M_KC;
+    // this wave fills rows [wave * ROWS / 4, + ROWS / 4) of every slot: activation rows first, weight rows behind them
+    const char *src[DMA];
+#pragma unroll
+    for (int j = 0; j < DMA; j++) {
+        const int row = wave * (ROWS / 4) + j * 8 + (lane >> 3), c4 = lane & 7;
+        const char *base;
+        if (row < BM) { int m = m0 + row; if (m >= p.M) m = p.M - 1; base = a_row_ptr(p, m, 4); }
+        else base = (const char *)p.W + (size_t)(n0 + row - BM) * p.K * 4;
+        src[j] = base + (((c4 ^ (row >> 1)) & 7) << 4);
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kc, int slot) {
+        const unsigned sb = ring_base + slot * SLOT + wave * (ROWS / 4) * 128;
+#pragma unroll
+        for (int j = 0; j < DMA; j++) glds16(src[j] + (size_t)kc * 128, sb + j * 1024);
+    };
+    f32x16 acc[IN][IM];
+#pragma unroll
+    for (int a = 0; a < IN; a++)
+#pragma unroll
+        for (int b = 0; b < IM; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
+    issue(0, 0);
+    if (nchunks > 1) issue(1, 1);
+    int slot = 0;
+    for (int i = 0; i < nchunks; i++) {
+        if (i + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");     // chunk i has landed, chunk i + 1 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // ... for every wave; and every wave is done with chunk i - 1
+        if (i + 2 < nchunks) issue(i + 2, slot == 0 ? 2 : slot - 1);     // into the slot chunk i - 1 has just left
+        const char *sp = ring + slot * SLOT;
+        const char *arow = sp + (wm * (BM / 2) + l31) * 128, *wrow = sp + (BM + wn * (BN / 2) + l31) * 128;
+        const int swa = ((wm * (BM / 2) + l31) >> 1) & 7, sww = ((BM + wn * (BN / 2) + l31) >> 1) & 7;     // + 32 rows: the same swizzle ((row >> 1) & 7 has period 16)
+#pragma unroll
+        for (int k2 = 0; k2 < F32M_KC / 2; k2++) {
+            const int k = 2 * k2 + kh;
+            const int oa = (((k >> 2) ^ swa) << 4) + ((k & 3) << 2), ow = (((k >> 2) ^ sww) << 4) + ((k & 3) << 2);
+            float av[IM], wv[IN];
+#pragma unroll
+            for (int b = 0; b < IM; b++) av[b] = *(const float *)(arow + b * 32 * 128 + oa);
+#pragma unroll
+            for (int a = 0; a < IN; a++) wv[a] = *(const float *)(wrow + a * 32 * 128 + ow);
+#pragma unroll
+            for (int a = 0; a < IN; a++)
+#pragma unroll
+                for (int b = 0; b < IM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[a], av[b], acc[a][b], 0, 0, 0);
+        }
+        slot = slot + 1 == F32M_NS ? 0 : slot + 1;
+    }
+#pragma unroll
+    for (int a = 0; a < IN; a++)
+#pragma unroll
+        for (int b = 0; b < IM; b++) {
+            const int m = m0 + wm * (BM / 2) + b * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = n0 + wn * (BN / 2) + a * 32 + g * 8 + kh * 4;
+                epi_quad<false>(p, 0, m, n, acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            }
+        }
+}
 void launch_gemm_f32(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     p.splits = 1;
-    static const bool rows_off = getenv("NASR_F32_ROWS_OFF") != nullptr;      // diagnostic: the 64-row form at every M
-    if (!rows_off && p.M <= F32R_MMAX && p.N % F32R_NR == 0 && p.K % 4 == 0 && p.lda % 4 == 0) {
+    if (p.M <= F32R_MMAX && p.N % F32R_NR == 0 && p.K % 4 == 0 && p.lda % 4 == 0) {
         hipLaunchKernelGGL(k_gemm_f32_rows, dim3(p.N / F32R_NR), dim3(256), 0, st, p);
+        return;
+    }
+    if (!p.f32_fma_tile && p.M > F32R_MMAX && p.N % 64 == 0 && p.K % F32M_KC == 0 && p.lda % 4 == 0 && ((size_t)p.A & 15) == 0 && ((size_t)p.W & 15) == 0 &&
+        (p.rows_per_batch == 0 || (p.batch_stride % 4 == 0))) {
+        // 128 x 128 tiles when they fill the chip (or the width allows nothing else to), 64 x 64 otherwise: more, smaller workgroups, three per CU
+        const long big = (long)(p.N / 128) * ((p.M + 127) / 128);
+        if (p.N % 128 == 0 && big >= 192) {
+            const int n_groups = p.N / 128, m_chunks = (p.M + 127) / 128;
+            hipLaunchKernelGGL((k_gemm_f32_mfma<128, 128>), dim3(n_groups * m_chunks), dim3(256), F32M_NS * 256 * 128, st, p, n_groups, m_chunks);
+        } else {
+            const int n_groups = p.N / 64, m_chunks = (p.M + 63) / 64;
+            hipLaunchKernelGGL((k_gemm_f32_mfma<64, 64>), dim3(n_groups * m_chunks), dim3(256), F32M_NS * 128 * 128, st, p, n_groups, m_chunks);
+        }
         return;
     }
     dim3 grid(p.N / 64, (p.M + 15) / 16);

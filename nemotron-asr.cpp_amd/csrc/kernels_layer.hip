@@ -416,8 +416,7 @@ __global__ __launch_bounds__(256) void k_attention_row1(AttnParams a) {
 
 void launch_attention(const AttnParams &p, hipStream_t st) {
     const int TS = p.TS > 0 ? p.TS : p.T;
-    static const bool row1 = !(getenv("NASR_ATTN_ROW1") && atoi(getenv("NASR_ATTN_ROW1")) == 0);
-    if (row1 && p.act_bf16 && p.T == 1 && TS == 1) {
+    if (p.act_bf16 && p.T == 1 && TS == 1) {
         hipLaunchKernelGGL(k_attention_row1, dim3(NH, p.B), dim3(256), 0, st, p);
         return;
     }

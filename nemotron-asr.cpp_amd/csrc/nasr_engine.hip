@@ -140,6 +140,11 @@ struct nasr_engine {
     int w_rows = 0;                  // workspace rows = max(max_streams x TMAX, MAXNEW)
     char *g_desc = nullptr;          // device mirror of the packed descriptor block (layout: graph_desc_layout)
     bool opt_multichunk = true;
+    int opt_decode_graph_iters = 12;   // blind decode iterations a pipelined step's decode graph carries at most (option "decode_graph_iterations")
+    bool opt_decode_lane = true;       // the decode graphs get a lane of their own when a queue is free (option "decode_lane")
+    int opt_gemm_cores = -1;           // -1: the engine's rule; 0 / 1: never / always the GEMM kernels of which two share a CU (option "gemm_cores")
+    bool opt_persist_gemm = true;    // GEMMs with >= 1.75 tiles of 128 x 128 per CU on the persistent tile loop (k_gemm_persist; same bits)
+    bool opt_f32_mfma = true;        // f32 GEMMs above four rows on v_mfma_f32_32x32x2_f32 (bit-identical to the FMA tile kernel)
     char *gh = nullptr;                                                               // pinned host block
     int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active
     int64_t graph_replays = 0, eager_steps = 0, decode_fallbacks = 0, decode_fallback_rounds = 0;
@@ -603,6 +608,7 @@ static int ensure_posproj(nasr_engine *e, int T) {
         memset(&g, 0, sizeof(g));
         g.A = demb; g.W = L.wpos_f32; g.M = n_rel; g.N = D; g.K = D; g.lda = D;
         g.epi = EPI_PART_F32; g.out_f32 = dout; g.ldo = D; g.splits = 1;
+        g.f32_fma_tile = e->opt_f32_mfma ? 0 : 1;
         launch_gemm_f32(g, e->st);
         if (e->bf16) {
             bf16_t *pp;
@@ -934,7 +940,9 @@ static int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char 
     const bool use_bf16 = e->bf16 && !f32_weights;
     const char *name = !use_bf16 ? "k_gemm_f32" : (g.M <= gemm_skinny_max_m() ? "k_gemm_skinny" : "k_gemm_tiled");
     ProfScope ps(e, name, gemm_bytes(e, g.M, g.N, g.K, use_bf16 ? 2 : 4), 2.0 * g.M * g.N * g.K);
-    g.coresident = e->gemm_coresident ? 1 : 0;
+    g.coresident = e->opt_gemm_cores == 0 ? 3 : e->opt_gemm_cores == 1 ? 2 : (e->gemm_coresident ? 1 : 0);
+    g.f32_fma_tile = e->opt_f32_mfma ? 0 : 1;
+    g.no_persist = e->opt_persist_gemm ? 0 : 1;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);
     return 0;
@@ -945,14 +953,12 @@ static int pick_splits(const nasr_engine *e, int M, int N, int K) {
     if (!e->bf16) return 1;
     const bool skinny = M <= gemm_skinny_max_m();
     int tasks = skinny ? (N / 16) * ((M + 63) / 64) : (N / gemm_tile_n(M, N, EPI_PART_F32)) * ((M + 127) / 128);
-    static const int large_splits = getenv("NASR_LARGE_SPLITS") ? atoi(getenv("NASR_LARGE_SPLITS")) : 0;      // experiment knob
-    if (!skinny && large_splits > 0) return large_splits;
     // partial traffic grows with the split factor, and with pipelined steps the CUs a launch leaves idle run another chain's
     // kernels: four splits only up to 40 tiles (three lanes, R = 13: 12 / 16 streams = 32 tiles 1.15 / 1.23 ms with 4 splits
     // against 1.23 / 1.30 with 2; 24 streams = 48 tiles 1.53 vs 1.50; 32 streams = 64 tiles 1.82 vs 1.68; 64 streams = 112 tiles:
     // 2 splits 2.76, 1 split 2.75, 4 splits 3.03)
     if (!skinny) return tasks <= 40 ? 4 : (tasks < 256 ? 2 : 1);
-    static const int skinny_cap = getenv("NASR_SKINNY_SPLITS_MAX") ? atoi(getenv("NASR_SKINNY_SPLITS_MAX")) : 8;      // experiment knob
+    constexpr int skinny_cap = 8;
     int s = 1;
     while (s < skinny_cap && tasks * s < 256 && (K / 32) / (s * 2) >= 4) s *= 2;
     return s;
@@ -1014,7 +1020,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         // K4: attention -> out projection.  M <= 2: fused (one head per blockIdx.y recomputes the tiny attention,
         // split-K over the 8 heads).  Larger M: the redundancy (64 workgroups per head) stops paying, so attention is
         // its own launch (one workgroup per (head, stream)) followed by the plain weight-streaming GEMM.
-        static const int fuse_max_m = getenv("NASR_FUSE_MAXM") ? atoi(getenv("NASR_FUSE_MAXM")) : 2;
+        constexpr int fuse_max_m = FUSE_MAX_M;
         int wo_splits = NH;
         if (M <= fuse_max_m) {
             memset(&f, 0, sizeof(f));
@@ -1043,8 +1049,7 @@ static int run_layers_fused(nasr_engine *e, const RowDesc *rows, int B, int T, i
         launch(f, "k_fused_ln_gemm", wbytes(2 * D, D), 2.0 * M * 2 * D * D);
         cur ^= 1;
         // K6: cached depthwise conv + LN + SiLU -> pointwise conv 2; same rule as K4
-        static const int pw2_splits_env = getenv("NASR_PW2_SPLITS") && atoi(getenv("NASR_PW2_SPLITS")) == 8 ? 8 : 4;   // experiment knob: 4 or 8 (the one-row kernel holds 2 k-tiles per wave)
-        const int pw2_splits = M <= fuse_max_m ? pw2_splits_env : 4;
+        const int pw2_splits = 4;
         if (M <= fuse_max_m) {
             memset(&f, 0, sizeof(f));
             f.pro = PRO_DWCONV; f.cv.glu = e->glu; f.cv.cc_pool = e->cc_pool[l]; f.cv.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
@@ -1109,17 +1114,10 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     // the first piece also carries the front end and the subsampling: with two pieces the boundary sits one layer early
     // (11 + 13 layers; measured against 12 + 12 and 10 + 14: batch 1 0.642 / 0.653 / 0.669 ms, 64 streams x R = 13 2.948 / 2.961 / 3.019);
     // with three it is 7 + 9 + 8 (batch 1: 0.500 ms; 8 + 8 + 8 0.522, 7 + 8 + 9 0.511, 7 + 10 + 7 0.526, 6 + 10 + 8 0.527)
-    static const int shift_env = getenv("NASR_SKEW_SHIFT") ? atoi(getenv("NASR_SKEW_SHIFT")) : -1;
-    const int shift = shift_env >= 0 ? shift_env : (nseg == 2 && nLayers >= 8 ? 1 : 0);
-    static const char *bounds_env = getenv("NASR_SKEW_BOUNDS");       // experiment: explicit first layers of pieces 1.., e.g. "7,15"
+    const int shift = nseg == 2 && nLayers >= 8 ? 1 : 0;
     auto bound = [&](int k) {
         if (k <= 0) return 0;
         if (k >= nseg) return nLayers;
-        if (bounds_env) {
-            const char *q = bounds_env;
-            for (int i = 1; i < k && q; i++) { q = strchr(q, ','); if (q) q++; }
-            if (q && atoi(q) > 0 && atoi(q) < nLayers) return atoi(q);
-        }
         if (nseg == 3 && nLayers >= 6) return k == 1 ? nLayers * 7 / 24 : nLayers * 16 / 24;
         // four pieces: 6 + 7 + 7 + 4 -- the last lane also runs the decode graphs (64 streams x 80 ms: 0.92 ms per step; 6 + 6 + 7 + 5
         // 0.95, 6 + 6 + 6 + 6 1.02, 7 + 6 + 6 + 5 1.00, 6 + 7 + 8 + 3 1.00; 64 x 1.12 s 2.67 / 2.68 / - / 2.77 / 2.72)
@@ -1168,7 +1166,7 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     // Up to 4 rows the 8-launch fused layer wins; above, its per-workgroup prologues (every workgroup redoes the
     // LayerNorm of all rows) cost more than the 6 extra launches of the unfused layer (measured at R = 0:
     // 8 rows 2.13 vs 1.89 ms, 16 rows 2.78 vs 1.96 ms per step).
-    static const int fused_rows = getenv("NASR_FUSED_ROWS") ? atoi(getenv("NASR_FUSED_ROWS")) : 4;
+    constexpr int fused_rows = 4;
     const bool fused = e->bf16 && e->opt_fused && !e->debug && M <= fused_rows;
     const int TS = G * T;                      // rows per stream in this launch
     if (G > 1 && e->debug) return fail("internal: multi-chunk steps are not available in debug mode");
@@ -1180,19 +1178,13 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
         // batch 1 0.492-0.497 ms per step against 0.498-0.500 at 7 + 9 + 8 layers (56 + 72 + 64) -- with three lanes the step is
         // no longer bound by its longest lane (tests/micro/stamps_timeline.py: the kernels of the three chains mostly alternate
         // instead of overlapping: 0 / 1 / 2 / 3 kernels in flight 29 / 40 / 20 / 10 % of the time).
-        static const char *b8_env = getenv("NASR_SKEW_BOUNDS8");          // experiment: explicit first launches of pieces 1.., e.g. "59,126"
         auto bound8 = [&](int k) {
             if (k <= 0) return 0;
             if (k >= nseg) return 8 * nLayers;
-            if (b8_env) {
-                const char *q = b8_env;
-                for (int i = 1; i < k && q; i++) { q = strchr(q, ','); if (q) q++; }
-                if (q && atoi(q) > 0 && atoi(q) < 8 * nLayers) return atoi(q);
-            }
-            if (nseg == 3 && nLayers >= 6 && !bounds_env) return (k == 1 ? 57 : 126) * nLayers / 24;
+            if (nseg == 3 && nLayers >= 6) return (k == 1 ? 57 : 126) * nLayers / 24;
             // four pieces: 48 + 56 + 60 + 28 launches (batch 1: 0.426 ms per step; 48 + 56 + 56 + 32 0.437, 50 + 56 + 56 + 30 0.433,
             // 48 + 54 + 62 + 28 0.434, 48 + 56 + 64 + 24 0.440; three lanes 0.454)
-            if (nseg == 4 && nLayers >= 8 && !bounds_env) return (k == 1 ? 48 : k == 2 ? 104 : 164) * nLayers / 24;
+            if (nseg == 4 && nLayers >= 8) return (k == 1 ? 48 : k == 2 ? 104 : 164) * nLayers / 24;
             return 8 * bound(k);
         };
         // The launches of a layer that touch PER-STREAM state shared by all steps -- K3 / K4 (the layer's K/V ring) and K6 (its conv
@@ -1204,7 +1196,7 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
         // alternate between the two forms while both are in flight could read or write that layer's ring out of order -- found in
         // round 3 by the soak test on 8 layers (cuts 16 | 34 | 54), never seen at 24; the cut is 162 now.
         auto snap8 = [&](int k, int b) {
-            if (k <= 0 || k >= nseg || b8_env) return b;
+            if (k <= 0 || k >= nseg) return b;
             const int lb = 8 * bound(k);
             return std::min(std::max(b, lb - 2), lb + 2);
         };
@@ -1307,12 +1299,12 @@ static int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *v
     if (e->hp.num_prompts > 0) {
         memset(&g, 0, sizeof(g));
         g.A = e->x; g.W = e->pk1a; g.M = M; g.N = 2048; g.K = D; g.lda = D; g.splits = 1;
-        g.epi = EPI_BIAS_F32; g.out_f32 = e->hfuse; g.ldo = 2048; g.bias = e->pk1_b;
+        g.epi = EPI_BIAS_F32; g.out_f32 = e->hfuse; g.ldo = 2048; g.bias = e->pk1_b; g.f32_fma_tile = e->opt_f32_mfma ? 0 : 1;
         { ProfScope ps(e, "k_gemm_f32", gemm_bytes(e, M, 2048, D, 4), 2.0 * M * 2048 * D); launch_gemm_f32(g, st); }
         launch_prompt_add_relu(e->hfuse, e->pk1p, rows, M, G * T, e->hp.num_prompts, st);
         memset(&g, 0, sizeof(g));
         g.A = e->hfuse; g.W = e->pk2_w; g.M = M; g.N = D; g.K = 2048; g.lda = 2048; g.splits = 1;
-        g.epi = EPI_BIAS_F32; g.out_f32 = e->x; g.ldo = D; g.bias = e->pk2_b;
+        g.epi = EPI_BIAS_F32; g.out_f32 = e->x; g.ldo = D; g.bias = e->pk2_b; g.f32_fma_tile = e->opt_f32_mfma ? 0 : 1;
         { ProfScope ps(e, "k_gemm_f32", gemm_bytes(e, M, D, 2048, 4), 2.0 * M * D * 2048); launch_gemm_f32(g, st); }
     }
     if (e->debug && tap_copy(e->tap_enc, (size_t)TMAX * D, 0)) return -1;
@@ -1500,6 +1492,17 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     else if (!strcmp(key, "graph")) e->opt_graph = value != 0;
     else if (!strcmp(key, "graph_cache")) { if (value < 1) return fail("graph_cache must be >= 1"); e->opt_graph_cache = value; }
     else if (!strcmp(key, "multichunk")) e->opt_multichunk = value != 0;
+    else if (!strcmp(key, "persistent_gemm")) e->opt_persist_gemm = value != 0;      // like "fused": set before the first step
+    else if (!strcmp(key, "gemm_cores")) { if (value < -1 || value > 1) return fail("gemm_cores must be -1, 0 or 1"); e->opt_gemm_cores = value; }
+    else if (!strcmp(key, "decode_graph_iterations")) { if (value < 1) return fail("decode_graph_iterations must be >= 1"); e->opt_decode_graph_iters = value; }
+    else if (!strcmp(key, "decode_lane")) {
+        ApiGuard api_guard;
+        HIPCHK(hipSetDevice(e->device));
+        if (pipe_drain(e)) return -1;
+        e->opt_decode_lane = value != 0;
+        release_lanes(e);                       // the lanes are picked again on the next pipelined step
+    }
+    else if (!strcmp(key, "f32_mfma")) e->opt_f32_mfma = value != 0;      // 0: f32 GEMMs above four rows on the FMA tile kernel (round 3's path); like "fused", set before the first step
     else if (!strcmp(key, "pipeline")) {
         ApiGuard api_guard;
         HIPCHK(hipSetDevice(e->device));
@@ -1608,10 +1611,9 @@ struct HostTimer {          // accumulates wall time of a scope into a double (d
     ~HostTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-static int pipe_blind_iterations(int frames) {
+static int pipe_blind_iterations(int frames, int cap) {     // cap: engine option "decode_graph_iterations" (12)
     // off the critical path an idle iteration is free: give one frame its worst case (10 symbols + the closing blank)
     const int worst = frames * MAX_SYMBOLS + 1;
-    static const int cap = getenv("NASR_PIPE_ITERS") ? atoi(getenv("NASR_PIPE_ITERS")) : 12;
     return std::max(decode_blind_iterations(frames), std::min(worst, cap));
 }
 
@@ -1658,7 +1660,7 @@ static int pick_lanes(nasr_engine *e) {
     for (hipStream_t c : rejected) hipStreamDestroy(c);
     // 4 queues: up to 3 pieces + the decode graphs on the fourth, or 4 pieces with the decode behind the last one; 3 queues: 2 + decode
     // or 3 with the decode behind; ... 1 (GPU_MAX_HW_QUEUES=1): everything on the engine's stream
-    if (getenv("NASR_DEC_LANE") && chosen.size() > 1) { hipStreamDestroy(chosen.back()); chosen.pop_back(); }   // experiment knob: one queue fewer
+    if (!e->opt_decode_lane && chosen.size() > 1) { hipStreamDestroy(chosen.back()); chosen.pop_back(); }   // option "decode_lane" = 0: one queue fewer, the decode graphs run behind the last encoder piece
     e->n_lanes = std::max(1, std::min((int)chosen.size(), (int)nasr_engine::MAXSEG));
     e->lane[0] = e->st;
     for (int k = 1; k < e->n_lanes; k++) e->lane[k] = chosen[(size_t)k];
@@ -1750,7 +1752,7 @@ static int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, 
             dp.encproj = P.encproj;
             launch_decode_begin(dp, cs);
             int it = 0;
-            for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, cs);
+            for (int k = 0, n = pipe_blind_iterations(T * G, e->opt_decode_graph_iters); k < n; k++) launch_decode_iter(dp, it++, cs);
             hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, cs, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
             HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, cs));
             return 0;
@@ -1767,9 +1769,7 @@ static int pipe_advance(nasr_engine *e, int p) {
     // the previous piece was launched a whole call earlier: normally it is done.  If not, the HOST waits: a stream wait would
     // put a barrier packet that finds its event pending into the lane's queue, and pending cross-queue barriers slow every
     // queue's dispatch down (tests/micro/pipe_probe.hip: 2.0 -> 2.6 us per kernel at 2 lanes, far worse with more queues)
-    static const bool stream_wait = getenv("NASR_SKEW_STREAMWAIT") != nullptr;
-    if (stream_wait) HIPCHK(hipStreamWaitEvent(e->lane[k], P.seg_done[k - 1], 0));
-    else if (hipEventQuery(P.seg_done[k - 1]) != hipSuccess) { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[k - 1])); }
+    if (hipEventQuery(P.seg_done[k - 1]) != hipSuccess) { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.seg_done[k - 1])); }
     { HostTimer ht(e->host_launch_s); HIPCHK(hipGraphLaunch(P.seg_graphs[k][P.key], e->lane[k])); }
     HIPCHK(hipEventRecord(P.seg_done[k], e->lane[k]));
     P.stage = k + 1;
@@ -1812,7 +1812,7 @@ static int pipe_finish(nasr_engine *e, int p) {
         DecParams dp;
         make_dec_params(e, (const RowDesc *)(P.g_desc + L.rows), B, TS, dp);
         dp.encproj = P.encproj;
-        int itn = pipe_blind_iterations(TS), round = 8;
+        int itn = pipe_blind_iterations(TS, e->opt_decode_graph_iters), round = 8;
         e->decode_fallbacks++;
         for (;;) {
             e->decode_fallback_rounds++;
@@ -1968,7 +1968,7 @@ static int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const i
 // later; every entry point that needs finished steps drains (bubbles run through the remaining stages).
 // ---------------------------------------------------------------------------------------------------------------------------
 static bool gp_eligible(const nasr_engine *e, int B, int T, int G) {
-    static const int fuse_max_m = getenv("NASR_FUSE_MAXM") ? atoi(getenv("NASR_FUSE_MAXM")) : 2;
+    constexpr int fuse_max_m = FUSE_MAX_M;
     return e->opt_pipeline == nasr_engine::GP_S && e->bf16 && e->opt_fused && !e->debug && B * T * G <= std::min(2, fuse_max_m) &&
            e->hp.n_layers % nasr_engine::GP_S == 0 && e->hp.num_prompts == 0 && e->n_lanes >= nasr_engine::GP_C && e->max_lanes >= nasr_engine::GP_C;
 }
@@ -2048,7 +2048,7 @@ static int gp_decode_graph(nasr_engine *e, int p, int B, int T, int G, hipGraphE
         dp.encproj = P.encproj;
         launch_decode_begin(dp, cs);
         int it = 0;
-        for (int k = 0, n = pipe_blind_iterations(T * G); k < n; k++) launch_decode_iter(dp, it++, cs);
+        for (int k = 0, n = pipe_blind_iterations(T * G, e->opt_decode_graph_iters); k < n; k++) launch_decode_iter(dp, it++, cs);
         hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, cs, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
         HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, cs));
         return 0;
@@ -2133,7 +2133,7 @@ static int gp_finish_decode(nasr_engine *e) {
         DecParams dp;
         make_dec_params(e, (const RowDesc *)(P.g_desc + L.rows), nB, P.T * P.G, dp);
         dp.encproj = P.encproj;
-        int itn = pipe_blind_iterations(P.T * P.G), round = 8;
+        int itn = pipe_blind_iterations(P.T * P.G, e->opt_decode_graph_iters), round = 8;
         e->decode_fallbacks++;
         for (;;) {
             e->decode_fallback_rounds++;

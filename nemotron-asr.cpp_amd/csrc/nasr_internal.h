@@ -35,6 +35,7 @@ constexpr int MEL_RING = 4096;        // mel ring frames per stream (power of tw
 constexpr int MAX_PUSH = 1280 * MAXNEW;   // samples per internal sub-push (MAXNEW encoder frames)
 constexpr int ABUF_CAP = MAX_PUSH + NFFT + 64;
 constexpr int MAX_KS   = 32;          // max depthwise kernel size supported
+constexpr int FUSE_MAX_M = 2;         // rows up to which attention / depthwise conv are fused into the following GEMM's prologue
 constexpr int TOK_CAP  = 4096;        // per-stream device token ring between collects
 
 typedef uint16_t bf16_t;
@@ -110,10 +111,16 @@ struct GemmParams {
     const RowDesc *rows;  int T;  // row m -> stream m / T, frame m % T
     // pipelined steps: this launch shares the chip with other launch chains' GEMMs -- the large-M kernels then use the variants
     // whose LDS ring lets two workgroups share a CU (same arithmetic in the same order: bit-identical to the default kernels)
-    int coresident;
+    int coresident;       // 0: synchronous step, 1: pipelined step (the rule of kernels_gemm.hip decides), 2 / 3: always / never (engine option "gemm_cores")
     // wave priority of the co-resident kernels (round-4 probe, tests/micro/cores_probe.hip): bit 0 = s_setprio 3 for the whole kernel,
     // bit 1 = back to 0 before the epilogue.  0 = leave the default (what ships unless the probe says otherwise).
     int prio;
+    // f32 GEMMs above four rows run on the f32-input MFMA (k_gemm_f32_mfma); 1 = the FMA tile kernel k_gemm_f32 instead (engine
+    // option "f32_mfma" = 0: the other side of the bit-identity test)
+    int f32_fma_tile;
+    // 1 = never the persistent tile loop (k_gemm_persist), whatever the size: engine option "persistent_gemm" = 0, the other side
+    // of its bit-identity test
+    int no_persist;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------

@@ -575,7 +575,7 @@ __device__ __forceinline__ void persist_tile_mn(int order, int i, int n_groups, 
     if (order == 1) { ng = u / band; m0 = (lo + u % band) * TM; }
     else { m0 = (u / band) * TM; ng = lo + u % band; }
 }
-__global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_groups, int m_chunks, int order) {
+__global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_groups, int m_chunks, int order, unsigned long long *stamps = nullptr) {
     const bool getenv_silu_storer = p.rows_per_batch == -7;      // probe switch: SiLU in the storer waves instead of the consumers
     extern __shared__ __attribute__((aligned(16))) char ring[];
     int band_lo, band_n;
@@ -673,6 +673,7 @@ __global__ __launch_bounds__(1024) void k_probe_persist(GemmParams p, int n_grou
     };
     for (int g = 0; g < NB; g++) {
         __builtin_amdgcn_s_barrier();
+        if (stamps && wave == 0 && lane == 0 && g < 160) stamps[(size_t)blockIdx.x * 160 + g] = __builtin_amdgcn_s_memrealtime();
         const unsigned so = (unsigned)(g % PS_NS) * G2_SLOT;
         if (g < G) {
             const unsigned wa = w_addr + so, ba = b_addr[0] + so;
@@ -716,9 +717,9 @@ static double run_persist(const GemmParams &p0, hipStream_t st, int reps, int or
     hipFuncSetAttribute((const void *)k_probe_persist, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks, order);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks, order, (unsigned long long *)nullptr);
     hipEventRecord(a, st);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks, order);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_probe_persist, grid, dim3(1024), lds, st, p, n_groups, m_chunks, order, (unsigned long long *)nullptr);
     hipEventRecord(b, st);
     hipEventSynchronize(b);
     float ms = 0;
@@ -815,7 +816,23 @@ int main() {
                 p3.T = 777;
                 const double t11n = run_persist(p3, st, 100);
                 printf("%-28s PERSISTENT: mismatches %zu | %6.2f us (%5.0f TFLOP/s) | without stores %6.2f us\n", s.name, bad3, t11, flops / t11 * 1e-6, t11n);
-                for (int order = 1; order <= 2; order++) {
+                if (getenv("PROBE_STAMPS")) {       // barrier-to-barrier intervals of consumer wave 0 in three workgroups (10 ns ticks), averaged per chunk index within a tile
+                    unsigned long long *ds; hipMalloc(&ds, (size_t)256 * 160 * 8); hipMemset(ds, 0, (size_t)256 * 160 * 8);
+                    GemmParams p6 = p2; p6.epi = s.epi;
+                    const int n_groups = p6.N / 128, m_chunks = (p6.M + TM - 1) / TM, lds = PS_STAGE + 65536;
+                    for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(k_probe_persist, dim3(256), dim3(1024), lds, st, p6, n_groups, m_chunks, 0, ds);
+                    hipStreamSynchronize(st);
+                    std::vector<unsigned long long> hs((size_t)256 * 160);
+                    hipMemcpy(hs.data(), ds, hs.size() * 8, hipMemcpyDeviceToHost);
+                    const int CPT = s.K / 64;
+                    for (int b : {0, 101, 255}) {
+                        printf("  stamps block %3d, chunk intervals in 10 ns ticks (tile boundaries every %d):", b, CPT);
+                        for (int g = 1; g < 160 && hs[(size_t)b * 160 + g]; g++) printf("%s%llu", (g % CPT == 1) ? " | " : " ", hs[(size_t)b * 160 + g] - hs[(size_t)b * 160 + g - 1]);
+                        printf("\n");
+                    }
+                    hipFree(ds);
+                }
+                for (int order = 1; order <= 2 && !getenv("PROBE_STAMPS"); order++) {
                     GemmParams p5 = p2; p5.epi = EPI_PART_F32;
                     hipMemset(out2, 0xff, n_out * 4);
                     run_persist(p5, st, 1, order);

@@ -1,6 +1,8 @@
-"""Bit-identity of GEMM kernel variants chosen by environment knobs: 16 streams x R = 13 (M = 224) and 64 streams x R = 13
-(M = 896) and 128 streams (M = 1 792) on a 3-layer bf16 engine, a few steps; prints one digest per knob setting (run: python gemm_variant_identity.py
-"NASR_GEMM_CORES=1" "NASR_GEMM_CORES=0" ...; the first digest is the build's default)."""
+"""Bit-identity of GEMM kernel variants: 16 / 64 / 128 / 256 / 512 streams x R = 13 (M = 224 ... 7 168) on a 3-layer bf16 engine, a few
+steps; prints one digest per setting.  A setting is a space-separated list of engine options ("opt:persistent_gemm=0 opt:gemm_cores=1":
+nasr_engine_set_option before the first step) and / or environment variables ("VAR=value"); the first digest is the build's default.
+    python gemm_variant_identity.py "opt:gemm_cores=1" "opt:gemm_cores=0" "opt:persistent_gemm=0"
+"""
 import hashlib
 import os
 import subprocess
@@ -18,11 +20,15 @@ def child():
     L, R = 3, 13
     W = synth.make_weights(n_layers=L)
     h = hashlib.sha256()
-    for B, pipeline in ((16, 0), (64, 0), (64, 4), (128, 0)):
+    n = synth.shift_samples(R)
+    pool = [synth.make_pcm(300 + b, 6 * n / 16000 + 0.01)[:6 * n] for b in range(128)]
+    for B, pipeline in ((16, 0), (64, 0), (64, 4), (128, 0), (256, 0), (512, 0), (512, 4)):
         eng = capi.Engine(W, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+        for kv in os.environ.get("NASR_VARIANT_OPTS", "").split():
+            k, v = kv.split("=", 1)
+            eng.set_option(k, int(v))
         eng.set_option("pipeline", pipeline)
-        n = synth.shift_samples(R)
-        pcms = [synth.make_pcm(300 + b, 6 * n / 16000 + 0.01)[:6 * n] for b in range(B)]
+        pcms = [np.roll(pool[b % 128], 977 * (b // 128)) for b in range(B)]
         sts = [eng.stream(R) for _ in range(B)]
         for k in range(6):
             for t in eng.step(sts, [p[k * n:(k + 1) * n] for p in pcms]):
@@ -45,7 +51,8 @@ if __name__ == "__main__":
     digests = []
     for setting in [""] + sys.argv[1:]:
         env = dict(os.environ, NASR_VARIANT_CHILD="1")
-        env.update(kv.split("=", 1) for kv in setting.split())
+        env.update(kv.split("=", 1) for kv in setting.split() if not kv.startswith("opt:"))
+        env["NASR_VARIANT_OPTS"] = " ".join(kv[4:] for kv in setting.split() if kv.startswith("opt:"))
         out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
         d = [l.split()[1] for l in out.stdout.splitlines() if l.startswith("DIGEST")]
         if not d:

@@ -543,14 +543,17 @@ def test_gemm_ring_variants_are_bit_identical():
     """The large-M GEMMs come in two ring depths: deep rings (one 96-128 KiB workgroup per CU: synchronous steps below 1 792 rows) and
     shallow ones of which two share a CU (k_gemm_tiled2_k32<4>, k_gemm_t64<3>: pipelined steps above 768 rows, every step from 1 792 rows).
     Same MFMAs in the same order: tokens, encoder output, K/V and conv caches of 16 / 64 / 128 streams x R = 13 (M = 224, 896, 1 792;
-    synchronous and four lanes) have ONE digest whether the choice is left to the engine or forced either way (NASR_GEMM_CORES)."""
+    synchronous and four lanes) have ONE digest whether the choice is left to the engine or forced either way (engine option "gemm_cores").
+    Round 4: 256 and 512 streams (M = 3 584, 7 168) are in the digest too, where the PERSISTENT tile loop (k_gemm_persist: loader, consumer
+    and storer waves, a tile parked beside the ring while the next one is multiplied) serves every GEMM with >= 1.75 tiles per CU -- the
+    same digest with engine option "persistent_gemm" = 0 (the per-tile kernels at every size)."""
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "NASR_GEMM_CORES=1", "NASR_GEMM_CORES=0"],
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "opt:gemm_cores=1", "opt:gemm_cores=0", "opt:persistent_gemm=0",
+                        "opt:persistent_gemm=0 opt:gemm_cores=0"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert r.stdout.count("==") == 3 and "!=" not in r.stdout
+    assert r.stdout.count("==") == 5 and "!=" not in r.stdout
 
 
 def test_lanes_option_gives_queues_back_and_keeps_results(W2):

@@ -401,6 +401,50 @@ def test_decode_many_rows_tokens_f32(W, om32):
     eng.close()
 
 
+@pytest.mark.parametrize("R,B", [(13, 8), (0, 8), (13, 64), (6, 3)])
+def test_f32_mfma_gemm_is_bit_identical_to_the_fma_tile(W, om32, R, B):
+    """Round 4: above four rows the f32 engine's GEMMs run on v_mfma_f32_32x32x2_f32 (k_gemm_f32_mfma: 128 x 128 and 64 x 64 tiles, both
+    reached here: M = 112 / 8 / 896 / 21 rows).  The f32 MFMA adds exact products to its accumulator one k after the other, so fed k
+    ascending from zero it must return the BITS of the FMA tile kernel (engine option "f32_mfma" = 0, round 3's path): encoder output
+    of every step, every layer's output, K / V / conv caches, decoder state and tokens are compared with ==, not with a tolerance; and
+    stream 0 against the oracle (tokens and frames exact: the reference's bar, tests/test_compute.cpp:2805-2817)."""
+    T = 1 + R
+    piece = synth.shift_samples(R)
+    n_steps = 4 if B == 64 else 6
+    pcms = [synth.make_pcm(70 + b, n_steps * piece / 16000.0 + 0.1)[:n_steps * piece] for b in range(B)]
+    runs = []
+    for mfma in (0, 1):
+        eng = capi.Engine(W, n_layers=N_LAYERS, dtype=capi.DTYPE_F32, max_streams=B)
+        eng.set_option("f32_mfma", mfma)
+        eng.set_debug(True)
+        sts = [eng.stream(R) for _ in range(B)]
+        toks, encs = [[] for _ in range(B)], []
+        for k in range(n_steps):
+            for b, t in enumerate(eng.step(sts, [p[k * piece:(k + 1) * piece] for p in pcms])):
+                toks[b] += t
+            if k >= 1:                 # the first push completes no chunk
+                encs.append(np.stack([s.tap(capi.TAP_ENCODER_OUT).reshape(-1, 1024)[:T].copy() for s in sts]))
+        spot = sorted({0, B // 2, B - 1})
+        state = [np.concatenate([sts[b].tap(capi.TAP_LAYER_OUT, l).ravel() for l in range(N_LAYERS)] +
+                                [sts[b].tap(tap, l).ravel() for l in range(N_LAYERS) for tap in (capi.TAP_K_CACHE, capi.TAP_V_CACHE)] +
+                                [sts[b].tap(capi.TAP_CONV_CACHE, l, cap=8 * 1024).ravel() for l in range(N_LAYERS)] +
+                                [sts[b].tap(capi.TAP_DEC_STATE).ravel()]) for b in spot]
+        frames = [sts[b].token_frames() for b in range(B)]
+        for b, t in enumerate(eng.finalize(sts)):
+            toks[b] += t
+        runs.append((toks, np.stack(encs), state, frames, [sts[b].token_frames() for b in range(B)]))
+        eng.close()
+    (t0, e0, s0, f0, ff0), (t1, e1, s1, f1, ff1) = runs
+    assert np.isfinite(e1).all() and np.abs(e1).max() > 0.1
+    assert np.array_equal(e0, e1), float(np.abs(e0 - e1).max())
+    for a, b in zip(s0, s1):
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
+    assert t0 == t1 and f0 == f1 and ff0 == ff1
+    ost = ob.OracleStream(om32, R)
+    ref = ost.process(pcms[0]) + ost.finalize()
+    assert t1[0] == ref and ff1[0] == ost.token_frames()
+
+
 def test_full_size_24_layers():
     """BASELINE.json's model size (24 layers, 1.2 GB of bf16 matrices).  (i) f32 engine vs f32 oracle on 2.4 s of PCM at
     R = 0 and R = 13: same tokens, frames, chunk counts, encoder output within the reference ladder scaled to 24
@@ -583,7 +627,7 @@ def test_smoke_entry():
 def test_pipelined_decode_fallback_path(tmp_path, dec_lane, hw_queues):
     """The decode graph of a pipelined step carries a fixed number of iterations; a burst of symbols beyond it is finished
     eagerly on the second stream before the next decode graph is launched.  With the budget cut to its minimum
-    (NASR_PIPE_ITERS=1, own process: the knob is read once) the fallback runs many times -- tokens still equal synchronous
+    (engine option "decode_graph_iterations" = 1) the fallback runs many times -- tokens still equal synchronous
     stepping and the f32 oracle."""
     import os
     import subprocess
@@ -605,6 +649,8 @@ pcms = [synth.make_pcm(80 + b, 6.0) for b in range(B)]
 res = {{}}
 for mode in (0, 1, 3):
     eng = capi.Engine(W, n_layers=2, dtype=capi.DTYPE_F32, max_streams=B)
+    eng.set_option("decode_graph_iterations", 1)
+    eng.set_option("decode_lane", {0 if dec_lane else 1})
     eng.set_option("pipeline", mode)
     sts = [eng.stream(R) for _ in range(B)]
     toks = [[] for _ in range(B)]
@@ -630,9 +676,7 @@ for b in range(B):
     assert res[1][b] == ref, "oracle mismatch on stream %d" % b
 print("TOKENS", sum(len(t) for t in res[1]))
 """)
-    env = dict(os.environ, NASR_PIPE_ITERS="1", NASR_STATS="1")
-    if dec_lane:        # no stream for the decode graphs: they (and their eager fallback rounds) run behind the last encoder piece
-        env["NASR_DEC_LANE"] = "1"
+    env = dict(os.environ, NASR_STATS="1")      # dec_lane: engine option "decode_lane" = 0 -- no stream for the decode graphs: they (and their eager fallback rounds) run behind the last encoder piece
     if hw_queues:       # fewer hardware queues than lanes: the engine finds fewer streams that overlap and runs fewer pieces
         env["GPU_MAX_HW_QUEUES"] = hw_queues
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
