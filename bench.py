@@ -66,6 +66,32 @@ HBM_MEASURED_GBS = 6290.0
 MFMA_MEASURED_TFLOPS = 1261.0
 REPEATS = 5
 ENGINE_OPTIONS = []          # filled from --engine-option
+SHM_DIRS = []                # /dev/shm directories of shared weights, removed when the first rank of the node exits
+
+
+def store_weights(d: Path, W: dict):
+    """name -> ndarray | (ggml type id, packed bytes, logical shape), one .npy per tensor + an index; written to a temporary
+    directory and renamed, so a reader never sees half a set"""
+    import shutil
+    tmp = d.with_name(d.name + ".tmp")
+    shutil.rmtree(tmp, ignore_errors=True)
+    shutil.rmtree(d, ignore_errors=True)
+    tmp.mkdir(parents=True)
+    index = []
+    for i, (name, v) in enumerate(W.items()):
+        arr = v[1] if isinstance(v, tuple) else v
+        np.save(tmp / f"{i}.npy", np.ascontiguousarray(arr))
+        index.append([name, int(v[0]), list(v[2])] if isinstance(v, tuple) else [name, None, None])
+    (tmp / "index.json").write_text(json.dumps(index))
+    tmp.rename(d)
+
+
+def load_weights(d: Path) -> dict:
+    out = {}
+    for i, (name, tid, shape) in enumerate(json.loads((d / "index.json").read_text())):
+        a = np.load(d / f"{i}.npy", mmap_mode="r")
+        out[name] = a if tid is None else (tid, a, tuple(shape))
+    return out
 
 
 def parse(argv=None):
@@ -106,6 +132,9 @@ def parse(argv=None):
     ap.add_argument("--extra-steps", type=int, default=200, help="timed steps per region of the extra configurations")
     ap.add_argument("--diarize", action="store_true",
                     help="BASELINE config 5 on the HEADLINE workload too: also time the diarization side-car on each step's audio")
+    ap.add_argument("--share-device", type=int, default=-1, metavar="D",
+                    help="rehearsal of the N > 1 path on a box with ONE GPU: every rank runs its engine on device D and the ranks meet over gloo "
+                         "(RCCL refuses two ranks on one device); the line says so in config.parallelism")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE",
                     help="nasr_engine_set_option on every engine of the run before its first step (gemm_cores, persistent_gemm, f32_mfma, ...)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks started by --gpus N (0: pick a free one)")
@@ -207,6 +236,7 @@ class Run:
         self.n_log = min(log_streams, B)
         self.tok_log = [[] for _ in range(self.n_log)]      # token ids of the first streams, in order (token_agreement)
         self.audio_per_step = B * self.n_step / synth.SAMPLE_RATE
+        self.local_regions = []
 
     def step(self, host=False):
         i = self.k % self.n_avail
@@ -252,6 +282,8 @@ def timed_regions(run, steps, barrier, max_over_ranks, host=False, repeats=REPEA
         barrier()
         if not prime:
             t1 = time.perf_counter()
+        if hasattr(run, "local_regions"):
+            run.local_regions.append(t1 - t0)       # this rank's own clock (per_rank in the line); `out` holds the max over ranks
         out.append(max_over_ranks(t1 - t0))
     return out
 
@@ -393,7 +425,7 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 free_port = sk.getsockname()[1]
             os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port))
-        if args.stub_engine:
+        if args.stub_engine or args.share_device >= 0:
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -404,7 +436,9 @@ def main():
 
     B, R = args.batch, args.right_context
     T = 1 + R
-    red_dev = "cpu" if args.stub_engine else "cuda"
+    red_dev = "cpu" if args.stub_engine or args.share_device >= 0 else "cuda"
+    if args.share_device >= 0:
+        local_rank = args.share_device          # every rank's engine on the one device there is
 
     def max_over_ranks(x):
         return sharding.max_over_ranks(dist, x, device=red_dev)
@@ -439,18 +473,39 @@ def main():
 
     t0 = time.time()
     speech = args.checkpoint == "speech" and args.layers == 24          # the fit belongs to the 24-layer encoder
-    W = synth.make_weights(n_layers=args.layers, margins="speech" if speech else "random")
+    node_rank0 = int(os.environ.get("LOCAL_RANK", "0")) == 0
+
+    def shared(tag, make):
+        """N > 1: the node's first rank builds the tensors once and parks them in /dev/shm, the others map them read-only
+        (round 3: every rank generated 2.4 GB of f32 weights + Q8_0 + dequantised copies of its own: ~5.5 GB x N on the host)."""
+        if dist is None or world == 1:
+            return make()
+        d = Path("/dev/shm") / f"nasr_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}"
+        if node_rank0:
+            store_weights(d, make())
+        dist.barrier()
+        out = load_weights(d)
+        dist.barrier()
+        if node_rank0:
+            SHM_DIRS.append(d)                  # removed at exit (files stay mapped in the ranks that still use them)
+        return out
+
+    W = shared(f"f32_{args.layers}_{int(speech)}", lambda: synth.make_weights(n_layers=args.layers, margins="speech" if speech else "random"))
     t_weights = time.time() - t0
     dtype = capi.DTYPE_BF16 if args.dtype == "bf16" else capi.DTYPE_F32
     engW, Wcpu = W, W
     if args.weights != "f32":
-        engW, Wcpu = synth.quantize_weights(W, args.weights)     # engine gets the packed blocks, the CPU baseline their values
+        if world == 1:
+            engW, Wcpu = synth.quantize_weights(W, args.weights)     # engine gets the packed blocks, the CPU baseline their values
+        else:
+            engW = shared(f"{args.weights}_{args.layers}_{int(speech)}", lambda: synth.quantize_weights(W, args.weights)[0])
     depth = 0 if args.sync_steps else args.pipeline_depth
     prime = PRIME if depth else 0
     prof_steps = 0 if args.no_profile_pass else min(args.steps, 50)
     need_s = (args.warmup + (args.regions + 3) * (args.steps + prime) * 2 + prof_steps + 4) * synth.shift_samples(R) * args.chunks_per_step / synth.SAMPLE_RATE
     audio_s = min(max(need_s, args.cpu_seconds + 2.0), 120.0)
-    run = Run(capi, synth, engW, args.layers, dtype, B, R, local_rank, sharding.stream_ids(rank, world, B), args.chunks_per_step,
+    run_ids = sharding.stream_ids(rank, world, B)
+    run = Run(capi, synth, engW, args.layers, dtype, B, R, local_rank, run_ids, args.chunks_per_step,
               pipeline=depth, audio_s=audio_s, speech=speech)
     del engW
     details = {}
@@ -458,7 +513,7 @@ def main():
     def barrier_for(r):
         def barrier():
             sharding.barrier(dist, r.eng.synchronize)
-            if dist is not None:
+            if dist is not None and red_dev == "cuda":
                 torch.cuda.synchronize()        # torch's own stream (RCCL barrier); the engine's stream is synchronised above
         return barrier
 
@@ -470,6 +525,13 @@ def main():
     regions = timed_regions(run, args.steps, barrier, max_over_ranks, repeats=args.regions, prime=prime)
     run.drain()
     tokens_timed, chunks_timed = run.tokens, run.streams[0].progress().chunks
+    per_rank = None
+    if dist is not None:                       # what every rank did in the same timed regions (N > 1: tokens must match a single-process run of the same streams)
+        mine = dict(rank=rank, device=local_rank, stream_ids=[run_ids[0], run_ids[-1]], tokens_emitted=tokens_timed, lanes=run.eng.counter("lanes"),
+                    ms_per_step=round(1e3 * statistics.median(run.local_regions[-args.regions:]) / args.steps, 4) if getattr(run, "local_regions", None) else None)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     head = summarize(regions, args.steps, run.audio_per_step, world)
     cold = head                                # synchronous steps: a region is idle-to-idle already
     if prime:
@@ -496,7 +558,7 @@ def main():
     roofline, kernels = None, []
     label = f"batch={B} R={R} {args.dtype}" + (f" from {args.weights}" if args.weights != "f32" else "")
     sync_step_s = None
-    if prof_steps and rank == 0:
+    if prof_steps:                               # on EVERY rank: a rank that skipped it would sit in the next barrier while rank 0 profiles
         roofline, kernels, sync_step_s = profile_pass(run, prof_steps, label, f"b{B}_R{R}", depth)
         run.drain()
     steps_pushed = run.k
@@ -561,7 +623,7 @@ def main():
         side_depth = 0 if args.sync_steps else min(args.pipeline_depth, 2)
         r.drain()
         dW = synth.make_diar_weights()
-        dvad = capi.Diar(dW, dtype=capi.DTYPE_BF16 | (0 if os.environ.get("NASR_DIAR_VAD_F32") else capi.DIAR_VAD_BF16), max_segments=max(8, 2 * r.B), device=local_rank)
+        dvad = capi.Diar(dW, dtype=capi.DTYPE_BF16 | (0 if os.environ.get("NASR_DIAR_VAD_F32") else capi.DIAR_VAD_F16), max_segments=max(8, 2 * r.B), device=local_rank)
         demb = capi.Diar(dW, dtype=capi.DTYPE_BF16, max_segments=max(8, 2 * r.B), device=local_rank) if split else dvad
         if side_depth:
             dvad.set_stream(r.eng.lend_stream())       # a hardware queue the ASR engine no longer uses
@@ -699,7 +761,14 @@ def main():
             run.close()
             run = None
         xB, xR = 64, 13
-        q8W, q8deq = synth.quantize_weights(W, "q8_0")
+        # one GPU: BASELINE configs[2], the engine fed Q8_0 tensors; N GPUs: configs[3] ("bf16, 512 streams sharded 8 x MI355X, 64 / GPU"): the
+        # f32 tensors, rounded to bf16 at upload -- the entry is named after what it feeds
+        xkey = "b64_R13_q8_0" if world == 1 else "b64_R13_bf16"
+        q8deq = None
+        if world == 1:
+            q8W, q8deq = synth.quantize_weights(W, "q8_0")
+        else:
+            q8W = W
         xrun = Run(capi, synth, q8W, args.layers, capi.DTYPE_BF16, xB, xR, local_rank, sharding.stream_ids(rank, world, xB), 1,
                    pipeline=depth, audio_s=60.0, speech=speech, log_streams=3)
         del q8W
@@ -711,25 +780,25 @@ def main():
         xr = timed_regions(xrun, args.extra_steps, xbar, max_over_ranks, prime=prime)
         xrun.drain()
         e = summarize(xr, args.extra_steps, xrun.audio_per_step, world)
-        details["b64_R13_q8_0"] = dict(runs_ms_per_step=e.pop("runs_ms_per_step"), steps_per_region=args.extra_steps, regions=REPEATS, tokens_emitted=xrun.tokens,
-                                       workload=f"nemotron-speech-streaming-0.6B ({args.layers} layers) bf16 from Q8_0 tensors, batch={xB} streams/GPU, 1.12 s "
+        details[xkey] = dict(runs_ms_per_step=e.pop("runs_ms_per_step"), steps_per_region=args.extra_steps, regions=REPEATS, tokens_emitted=xrun.tokens,
+                                       workload=f"nemotron-speech-streaming-0.6B ({args.layers} layers) bf16{' from Q8_0 tensors' if world == 1 else ''}, batch={xB} streams/GPU, 1.12 s "
                                                 f"lookahead (R=13), {world}xMI355X [BASELINE.json configs[{2 if world == 1 else 3}]]")
         xh = timed_regions(xrun, args.extra_steps, xbar, max_over_ranks, host=True, repeats=3, prime=prime)
         xrun.drain()
         e["host_pcm_ms_per_step"] = summarize(xh, args.extra_steps, xrun.audio_per_step, world)["ms_per_step"]
         sr = step_roofline(args.layers, xB, xR, statistics.median(xr) / args.extra_steps, 34.0 / 32.0)
         e["step_mfma_frac"] = sr["mfma_frac"]
-        details["b64_R13_q8_0"]["step_roofline"] = sr
+        details[xkey]["step_roofline"] = sr
         x_pushed = xrun.k
         x_logs = [list(t) for t in xrun.tok_log]
         x_frames = [xrun.streams[b].token_frames() for b in range(xrun.n_log)] if rank == 0 else []
-        if rank == 0 and prof_steps:
+        if prof_steps:                           # every rank (see above); rank 0 keeps the result
             xroof, xk, xs = profile_pass(xrun, 20, "batch=64 R=13 bf16 from q8_0", "b64_R13", depth, bound="mfma")
             e["synchronous_ms_per_step"] = round(1e3 * xs, 4)
             if xroof:
                 e["roofline"] = {k: xroof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us")}
-                details["b64_R13_q8_0"]["roofline"] = xroof
-            details["b64_R13_q8_0"]["kernels"] = [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in xk]
+                details[xkey]["roofline"] = xroof
+            details[xkey]["kernels"] = [dict(name=k["name"], launches=k["launches"], ms=round(k["total_ms"], 3)) for k in xk]
             xrun.drain()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # token agreement of the first streams against the F32 oracle on the dequantised weights
@@ -748,9 +817,9 @@ def main():
             e["token_agreement"] = dict(streams=len(rows), oracle_tokens=sum(r["oracle_tokens"] for r in rows), tokens_equal=all(r["tokens_equal"] for r in rows),
                                         aligned_ratio=round(sum(r["aligned_ratio"] * r["oracle_tokens"] for r in rows) / max(1, sum(r["oracle_tokens"] for r in rows)), 4),
                                         timing_shifts=sum(r["timing_shifts"] for r in rows), max_shift_margin=max(r["max_shift_margin"] for r in rows))
-            details["b64_R13_q8_0"]["token_agreement_rows"] = rows
+            details[xkey]["token_agreement_rows"] = rows
         del q8deq
-        configs["b64_R13_q8_0"] = e
+        configs[xkey] = e
         if rank == 0 and world == 1:
             configs["b64_R13_diarize"] = diarization_entry(xrun, 40)
         xrun.close()
@@ -792,7 +861,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": workload, "streams_per_gpu": B, "right_context": R, "parallelism": f"stream-sharded x{world}, no collectives",
+                       **({"rehearsal": f"all {world} ranks on device {args.share_device}, gloo barrier (one-GPU box)"} if args.share_device >= 0 else {}),
                        "pcm": "device-resident", "checkpoint": "speech" if speech else "random", "pipeline": depth, "tokens_emitted": tokens_timed},
+            "per_rank": per_rank,
             "configs": configs or None,
             "roofline": {k: roofline[k] for k in roof_keys if k in roofline} if roofline else None,
             "cpu_baseline": cpu,
@@ -824,6 +895,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    for d in SHM_DIRS:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

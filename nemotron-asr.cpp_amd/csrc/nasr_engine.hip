@@ -2641,6 +2641,7 @@ extern "C" int nasr_engine_get_counter(const nasr_engine *e, const char *name, i
     else if (!strcmp(name, "eager_steps")) *value = e->eager_steps;
     else if (!strcmp(name, "pipelined_steps")) *value = e->pipe_steps;
     else if (!strcmp(name, "grouped_steps")) *value = e->gp_steps;
+    else if (!strcmp(name, "lanes")) *value = e->pipe_ready ? e->n_lanes : 0;      // HIP streams found to overlap (0: not picked yet)
     else return fail("unknown counter '%s'", name);
     return 0;
 }

@@ -277,6 +277,36 @@ bool nemo_stream_collect_batch(nemo_stream_context *const *sctx, int B, std::str
     return true;
 }
 
+bool nemo_stream_finalize_batch(nemo_stream_context *const *sctx, int B, std::string *out) {
+    if (!sctx || B <= 0) return false;
+    std::vector<nasr_stream *> st((size_t)B);
+    std::vector<std::vector<int32_t>> buf((size_t)B, std::vector<int32_t>(256));
+    std::vector<int32_t *> ptr((size_t)B);
+    std::vector<int32_t> cap((size_t)B, 256), cnt((size_t)B);
+    for (int b = 0; b < B; b++) {
+        if (!sctx[b] || sctx[b]->nctx != sctx[0]->nctx) return false;
+        st[(size_t)b] = sctx[b]->stream;
+        ptr[(size_t)b] = buf[(size_t)b].data();
+    }
+    if (nasr_engine_finalize(sctx[0]->nctx->engine, st.data(), B, ptr.data(), cap.data(), cnt.data()) < 0) {
+        fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+        return false;
+    }
+    for (bool more = true; more;) {
+        more = false;
+        for (int b = 0; b < B; b++) {
+            const std::string text = absorb(sctx[b], buf[(size_t)b].data(), cnt[(size_t)b]);
+            if (out) out[b] += text;
+            more = more || cnt[(size_t)b] >= cap[(size_t)b];
+        }
+        if (more && nasr_engine_collect(sctx[0]->nctx->engine, st.data(), B, ptr.data(), cap.data(), cnt.data()) < 0) {
+            fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
+            return false;
+        }
+    }
+    return true;
+}
+
 std::string nemo_stream_finalize(nemo_stream_context *sctx) {
     if (!sctx) return "";
     int32_t tok[256], cap = 256, cnt = 0;

@@ -83,6 +83,10 @@ bool nemo_stream_process_batch(nemo_stream_context *const *sctx, int B, const in
 // what a batch former calls when its queue runs empty (nasr_engine_collect)
 bool nemo_stream_collect_batch(nemo_stream_context *const *sctx, int B, std::string *out);
 
+// MI355X extension: nemo_stream_finalize for B streams of one engine in ONE tail-flush launch sequence (a server ends many
+// sessions at once); out[b] += the text the flush (and, with pipelined steps, what was still in flight) produced
+bool nemo_stream_finalize_batch(nemo_stream_context *const *sctx, int B, std::string *out);
+
 // token ids -> text: U+2581 starts a word (reference src/nemo-ggml.cpp:1556-1583); ids outside the vocab are skipped
 std::string tokens_to_text(const std::vector<int> &tokens, const std::vector<std::string> &vocab);
 

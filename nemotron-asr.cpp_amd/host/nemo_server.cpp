@@ -4,9 +4,9 @@
 //
 // Reader threads only move bytes into one FIFO, as in the reference (src/nemo-server.cpp:288-358).  The worker
 // differs: the reference processes ONE data event of ONE stream at a time (src/nemo-server.cpp:230-239);
-// here the worker drains everything that is queued, concatenates each session's pending audio, groups the
-// sessions by right_context and issues ONE nemo_stream_process_batch per group -- the batch former that the
-// MI355X engine needs (B streams per launch sequence).  One worker thread owns each engine; with --devices there is
+// here the worker is a batch former (below): it drains what is queued, keeps each session's audio until it holds whole
+// chunks, and issues ONE nemo_stream_process_batch per right_context in which every stream completes the same number of
+// chunks -- the shape the MI355X engine replays as a hipGraph.  One worker thread owns each engine; with --devices there is
 // one engine + FIFO + worker ("lane") per GPU and stream s is served by lane s mod count, no cross-GPU traffic.
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -30,7 +30,12 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+
 #include "nemo_amd.h"
+#include "nemotron_asr_amd.h"
 
 namespace {
 
@@ -121,18 +126,50 @@ bool json_int(const std::string &j, const char *key, int &out) {
     return true;
 }
 
+// ---- the batch former --------------------------------------------------------------------------------------------------
+// The engine's fast path is a hipGraph replay (or, with --pipeline, graphs of consecutive calls side by side), and a call is
+// graph-eligible only if every stream in it completes the SAME number of chunks (csrc/nasr_engine.hip: try_graph_step); anything
+// else runs eagerly, chunk by chunk, after draining the pipeline.  Round 3's worker handed the engine whatever had arrived --
+// ragged pushes, sessions one chunk apart -- and delivered a fifth of the engine's throughput (profiles/r3_server_load_64_streams.json).
+// Now a session is only ever handed WHOLE chunks: how many chunks a session has completed is a pure function of the samples it
+// has been given (256 zeros of left padding, 512-sample frames at hop 160, a chunk = 9 + 8 T mel frames, then 8 T per chunk:
+// reference src/preprocessor.cpp:220-221, :320-328, src/nemo-stream.h:65-81), so the former knows for every session how many
+// samples complete its next g chunks.  Per right_context, the sessions that hold at least one whole chunk form ONE call in which
+// each completes G = the smallest number available among them (capped by the engine's row budget); the rest of their audio waits
+// for the next call.  A forming window holds the call back for at most kFormingWindowUs after the first chunk became complete, or
+// until every live session of that right_context has one -- live streams that push on the same clock land in the same call.
+constexpr int kFormingWindowUs = 200;
+
 struct Session {
     std::shared_ptr<Conn> conn;
     nemo_stream_context *sctx = nullptr;
-    std::vector<int16_t> pending;
+    std::vector<int16_t> pending;                // audio received and not yet handed to the engine, from `head` on
+    size_t head = 0;
+    int64_t handed = 0;                          // samples the engine has been given since the stream began
+    int T = 1;                                   // 1 + right_context
+    size_t avail() const { return pending.size() - head; }
+    // samples that must have been handed for k chunks to be complete
+    int64_t samples_for_chunks(int64_t k) const { return k <= 0 ? 0 : 160 * ((int64_t)(9 + 8 * T) + (k - 1) * 8 * T - 1) + 256; }
+    int64_t chunks_after(int64_t samples) const {          // chunks complete once `samples` have been handed
+        const int64_t frames = samples + 256 < 512 ? 0 : (samples + 256 - 512) / 160 + 1, first = 9 + 8 * T;
+        return frames < first ? 0 : (frames - first) / (8 * T) + 1;
+    }
+    int whole_chunks_pending() const { return (int)(chunks_after(handed + (int64_t)avail()) - chunks_after(handed)); }
+    void consume(size_t n) {
+        head += n; handed += (int64_t)n;
+        if (head == pending.size()) { pending.clear(); head = 0; }
+        else if (head > (1u << 20)) { pending.erase(pending.begin(), pending.begin() + (long)head); head = 0; }
+    }
 };
 
 void worker_loop(Lane *lane) {
     nemo_context *model = lane->model;
     std::map<uint32_t, Session> sessions;
-    uint64_t n_batches = 0, n_batched_streams = 0;
+    uint64_t n_batches = 0, n_batched_streams = 0, n_partial = 0, n_finalize = 0;
+    std::vector<uint32_t> ending;               // sessions whose STREAM_END has been read
     std::map<int, uint64_t> b_hist;               // streams per engine call -> calls (printed at exit: tests/server_load.py reads it)
     std::set<uint32_t> in_flight;               // --pipeline: sessions whose last steps may still be on the GPU
+    const int row_budget = std::max(model->max_streams * 14, 256);      // rows one launch sequence may carry (csrc/nasr_engine.hip: w_rows)
     auto drain = [&]() {                         // complete the steps in flight and send their text (FIFO empty, END, LANG)
         if (in_flight.empty()) return;
         std::vector<uint32_t> ids;
@@ -151,98 +188,193 @@ void worker_loop(Lane *lane) {
             else if (!out[b].empty()) s.conn->send_str(OP_TEXT, ids[b], out[b]);
         }
     };
-    auto flush = [&]() {
-        // group sessions with pending audio by right_context; one engine call per group
-        std::map<int, std::vector<uint32_t>> groups;
-        for (auto &kv : sessions)
-            if (!kv.second.pending.empty()) groups[kv.second.sctx->config.att_right_context].push_back(kv.first);
-        for (auto &g : groups) {
-            const int B = (int)g.second.size();
-            std::vector<nemo_stream_context *> sc((size_t)B);
-            std::vector<const int16_t *> pcm((size_t)B);
-            std::vector<int> ns((size_t)B);
-            std::vector<std::string> out((size_t)B);
-            for (int b = 0; b < B; b++) {
-                Session &s = sessions[g.second[(size_t)b]];
-                sc[(size_t)b] = s.sctx; pcm[(size_t)b] = s.pending.data(); ns[(size_t)b] = (int)s.pending.size();
-            }
-            const bool ok = nemo_stream_process_batch(sc.data(), B, pcm.data(), ns.data(), out.data());
-            n_batches++; n_batched_streams += (uint64_t)B; b_hist[B]++;
-            for (int b = 0; b < B; b++) {
-                Session &s = sessions[g.second[(size_t)b]];
-                s.pending.clear();
-                if (g_pipeline > 0) in_flight.insert(g.second[(size_t)b]);
-                if (!ok) s.conn->send_str(OP_ERROR, g.second[(size_t)b], "engine step failed");
-                else if (!out[(size_t)b].empty()) s.conn->send_str(OP_TEXT, g.second[(size_t)b], out[(size_t)b]);
-            }
+    // one engine call: session ids[b] is handed n[b] samples of its pending audio
+    auto call = [&](const std::vector<uint32_t> &ids, const std::vector<size_t> &n) {
+        const int B = (int)ids.size();
+        std::vector<nemo_stream_context *> sc((size_t)B);
+        std::vector<const int16_t *> pcm((size_t)B);
+        std::vector<int> ns((size_t)B);
+        std::vector<std::string> out((size_t)B);
+        for (int b = 0; b < B; b++) {
+            Session &s = sessions[ids[(size_t)b]];
+            sc[(size_t)b] = s.sctx; pcm[(size_t)b] = s.pending.data() + s.head; ns[(size_t)b] = (int)n[(size_t)b];
+        }
+        const bool ok = nemo_stream_process_batch(sc.data(), B, pcm.data(), ns.data(), out.data());
+        n_batches++; n_batched_streams += (uint64_t)B; b_hist[B]++;
+        for (int b = 0; b < B; b++) {
+            Session &s = sessions[ids[(size_t)b]];
+            s.consume(n[(size_t)b]);
+            if (g_pipeline > 0) in_flight.insert(ids[(size_t)b]);
+            if (!ok) s.conn->send_str(OP_ERROR, ids[(size_t)b], "engine step failed");
+            else if (!out[(size_t)b].empty()) s.conn->send_str(OP_TEXT, ids[(size_t)b], out[(size_t)b]);
         }
     };
+    // whole chunks: per right_context one call in which every session completes the same number of chunks.  Returns true if a
+    // session still holds a whole chunk afterwards (the caller comes back without waiting).
+    auto form_calls = [&]() {
+        bool more = false;
+        std::map<int, std::vector<uint32_t>> groups;
+        for (auto &kv : sessions)
+            if (kv.second.whole_chunks_pending() > 0) groups[kv.second.T].push_back(kv.first);
+        for (auto &g : groups) {
+            const int T = g.first;
+            std::vector<uint32_t> ids = g.second;
+            if ((int)ids.size() * T > row_budget) { ids.resize((size_t)(row_budget / T)); more = true; }
+            int G = INT32_MAX;
+            for (uint32_t id : ids) G = std::min(G, sessions[id].whole_chunks_pending());
+            G = std::max(1, std::min(G, std::min(row_budget / ((int)ids.size() * T), 248 / T)));      // 248: a call's samples stay below the engine's MAX_PUSH (256 frames) with the first chunk's extra 9 mel frames
+            std::vector<size_t> n(ids.size());
+            for (size_t b = 0; b < ids.size(); b++) {
+                Session &s = sessions[ids[b]];
+                n[b] = (size_t)(s.samples_for_chunks(s.chunks_after(s.handed) + G) - s.handed);
+                more = more || s.whole_chunks_pending() > G;
+            }
+            call(ids, n);
+        }
+        return more;
+    };
+    // what is left of one session (less than a chunk; END, LANG): handed as it is -- an eager step, once per stream
+    auto flush_session = [&](uint32_t id) {
+        Session &s = sessions[id];
+        while (s.whole_chunks_pending() > 0) form_calls();
+        if (s.avail() == 0) return;
+        n_partial++;
+        call({id}, {s.avail()});
+    };
+    auto all_ready = [&]() {                    // every live session holds a whole chunk (per right_context that has one ready)
+        std::set<int> ready_T;
+        for (auto &kv : sessions) if (kv.second.whole_chunks_pending() > 0) ready_T.insert(kv.second.T);
+        for (auto &kv : sessions) if (ready_T.count(kv.second.T) && kv.second.whole_chunks_pending() == 0) return false;
+        return true;
+    };
+    auto any_ready = [&]() { for (auto &kv : sessions) if (kv.second.whole_chunks_pending() > 0) return true; return false; };
+    auto apply = [&](Event &ev) {
+        auto it = sessions.find(ev.id);
+        switch (ev.type) {
+        case Ev::CREATE: {
+            nemo_cache_config cfg = nemo_cache_config::default_config();
+            cfg.att_right_context = ev.right_context;
+            Session s;
+            s.conn = ev.conn;
+            s.T = 1 + ev.right_context;
+            s.sctx = nemo_stream_init(model, &cfg);
+            if (!s.sctx) { ev.conn->send_str(OP_ERROR, ev.id, "failed to init stream"); break; }
+            if (!ev.text.empty() && ev.text != "auto") nemo_stream_set_language(s.sctx, ev.text.c_str());
+            sessions[ev.id] = std::move(s);
+        } break;
+        case Ev::DATA:
+            if (it != sessions.end()) it->second.pending.insert(it->second.pending.end(), ev.pcm.begin(), ev.pcm.end());
+            break;                           // stale data of a closed session is dropped, as in the reference
+        case Ev::LANG:
+            if (it == sessions.end()) break;
+            flush_session(ev.id);            // audio queued before the switch uses the old language
+            drain();
+            if (nemo_stream_set_language(it->second.sctx, ev.text.c_str())) {
+                char buf[160];
+                const int n = snprintf(buf, sizeof(buf), "{\"id\":%u,\"lang\":\"%s\",\"index\":%d}", ev.id, ev.text.c_str(), it->second.sctx->prompt_index);
+                it->second.conn->send(OP_LANG_SET, ev.id, buf, (uint32_t)n);
+            } else it->second.conn->send_str(OP_ERROR, ev.id, "unknown or unsupported language: " + ev.text);
+            break;
+        case Ev::END:
+            if (it != sessions.end()) ending.push_back(ev.id);     // ended together below: sessions that stop at the same time share their tail calls
+            break;
+        case Ev::CLOSE:
+            if (it == sessions.end()) break;
+            ending.erase(std::remove(ending.begin(), ending.end(), ev.id), ending.end());
+            in_flight.erase(ev.id);
+            nemo_stream_free(it->second.sctx);
+            sessions.erase(it);
+            break;
+        }
+    };
+    // STREAM_END of every session in `ending`: the whole chunks they still hold go through the usual calls, what is left of each
+    // (less than a chunk) in ONE call, then ONE tail flush for all of them (nasr_engine_finalize takes B streams)
+    auto end_sessions = [&]() {
+        if (ending.empty()) return;
+        std::vector<uint32_t> ids;
+        for (uint32_t id : ending) if (sessions.count(id) && std::find(ids.begin(), ids.end(), id) == ids.end()) ids.push_back(id);
+        ending.clear();
+        if (ids.empty()) return;
+        for (bool again = true; again;) {
+            again = false;
+            for (uint32_t id : ids) again = again || sessions[id].whole_chunks_pending() > 0;
+            if (again) form_calls();
+        }
+        std::vector<uint32_t> tail_ids;
+        std::vector<size_t> tail_n;
+        for (uint32_t id : ids) if (sessions[id].avail() > 0) { tail_ids.push_back(id); tail_n.push_back(sessions[id].avail()); }
+        if (!tail_ids.empty()) { n_partial++; call(tail_ids, tail_n); }
+        std::vector<nemo_stream_context *> sc;
+        for (uint32_t id : ids) { sc.push_back(sessions[id].sctx); in_flight.erase(id); }      // finalize completes the steps in flight itself
+        std::vector<std::string> out(ids.size());
+        const bool ok = nemo_stream_finalize_batch(sc.data(), (int)sc.size(), out.data());
+        n_finalize++;
+        for (size_t b = 0; b < ids.size(); b++) {
+            Session &s = sessions[ids[b]];
+            if (!ok) s.conn->send_str(OP_ERROR, ids[b], "engine finalize failed");
+            s.conn->send_str(OP_ENDED, ids[b], out[b]);
+            nemo_stream_free(s.sctx);
+            sessions.erase(ids[b]);
+        }
+    };
+    auto take = [&](std::deque<Event> &batch) {          // everything that is queued, without waiting
+        std::lock_guard<std::mutex> lk(lane->mtx);
+        if (lane->queue.empty()) return false;
+        batch.swap(lane->queue);
+        lane->queued_bytes = 0;
+        lane->space_cv.notify_all();
+        return true;
+    };
+    bool backlog = false;                       // a session still holds a whole chunk: no waiting
     for (;;) {
         std::deque<Event> batch;
-        {
+        if (backlog) take(batch);
+        else {
             std::unique_lock<std::mutex> lk(lane->mtx);
             lane->cv.wait(lk, [&] { return g_stop || !lane->queue.empty(); });
             if (g_stop && lane->queue.empty()) break;
-            batch.swap(lane->queue);             // take EVERYTHING that is queued: this is the batch former
+            batch.swap(lane->queue);
             lane->queued_bytes = 0;
             lane->space_cv.notify_all();
         }
-        for (Event &ev : batch) {
-            auto it = sessions.find(ev.id);
-            switch (ev.type) {
-            case Ev::CREATE: {
-                nemo_cache_config cfg = nemo_cache_config::default_config();
-                cfg.att_right_context = ev.right_context;
-                Session s;
-                s.conn = ev.conn;
-                s.sctx = nemo_stream_init(model, &cfg);
-                if (!s.sctx) { ev.conn->send_str(OP_ERROR, ev.id, "failed to init stream"); break; }
-                if (!ev.text.empty() && ev.text != "auto") nemo_stream_set_language(s.sctx, ev.text.c_str());
-                sessions[ev.id] = std::move(s);
-            } break;
-            case Ev::DATA:
-                if (it != sessions.end()) it->second.pending.insert(it->second.pending.end(), ev.pcm.begin(), ev.pcm.end());
-                break;                           // stale data of a closed session is dropped, as in the reference
-            case Ev::LANG:
-                if (it == sessions.end()) break;
-                flush();                         // audio queued before the switch uses the old language
-                drain();
-                if (nemo_stream_set_language(it->second.sctx, ev.text.c_str())) {
-                    char buf[160];
-                    const int n = snprintf(buf, sizeof(buf), "{\"id\":%u,\"lang\":\"%s\",\"index\":%d}", ev.id, ev.text.c_str(), it->second.sctx->prompt_index);
-                    it->second.conn->send(OP_LANG_SET, ev.id, buf, (uint32_t)n);
-                } else it->second.conn->send_str(OP_ERROR, ev.id, "unknown or unsupported language: " + ev.text);
-                break;
-            case Ev::END:
-                if (it == sessions.end()) break;
-                flush();
-                in_flight.erase(ev.id);           // finalize completes the steps in flight itself
-                it->second.conn->send_str(OP_ENDED, ev.id, nemo_stream_finalize(it->second.sctx));
-                nemo_stream_free(it->second.sctx);
-                sessions.erase(it);
-                break;
-            case Ev::CLOSE:
-                if (it == sessions.end()) break;
-                it->second.pending.clear();
-                in_flight.erase(ev.id);
-                nemo_stream_free(it->second.sctx);
-                sessions.erase(it);
-                break;
+        for (Event &ev : batch) apply(ev);
+        // the forming window: the first whole chunk is in; wait for the sessions that push on the same clock
+        if (!backlog && any_ready() && !all_ready()) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(kFormingWindowUs);
+            for (;;) {
+                std::deque<Event> more;
+                {
+                    std::unique_lock<std::mutex> lk(lane->mtx);
+                    if (!lane->cv.wait_until(lk, deadline, [&] { return g_stop || !lane->queue.empty(); })) break;
+                    if (lane->queue.empty()) break;
+                    more.swap(lane->queue);
+                    lane->queued_bytes = 0;
+                    lane->space_cv.notify_all();
+                }
+                for (Event &ev : more) apply(ev);
+                if (all_ready() || std::chrono::steady_clock::now() >= deadline) break;
             }
         }
-        flush();
-        if (g_pipeline > 0) {                    // nothing else queued: do not sit on finished text
+        end_sessions();
+        backlog = form_calls();
+        if (g_pipeline > 0 && !backlog) {        // nothing else to do: do not sit on finished text
             bool idle;
             { std::lock_guard<std::mutex> lk(lane->mtx); idle = lane->queue.empty(); }
             if (idle) drain();
         }
     }
     for (auto &kv : sessions) nemo_stream_free(kv.second.sctx);
-    fprintf(stderr, "worker: %llu engine calls, %.2f streams per call\n", (unsigned long long)n_batches,
-            n_batches ? (double)n_batched_streams / (double)n_batches : 0.0);
+    fprintf(stderr, "worker: %llu engine calls, %.2f streams per call, %llu partial-chunk calls, %llu tail flushes\n", (unsigned long long)n_batches,
+            n_batches ? (double)n_batched_streams / (double)n_batches : 0.0, (unsigned long long)n_partial, (unsigned long long)n_finalize);
     std::string h = "worker: B histogram";
     for (auto &kv : b_hist) h += " " + std::to_string(kv.first) + ":" + std::to_string(kv.second);
     fprintf(stderr, "%s\n", h.c_str());
+    std::string c = "worker: engine counters";       // which path the calls took (tests/server_load.py reads this line)
+    for (const char *name : {"graph_replays", "pipelined_steps", "grouped_steps", "eager_steps", "graph_shapes", "graph_evictions"}) {
+        int64_t v = 0;
+        if (nasr_engine_get_counter(model->engine, name, &v) == 0) c += std::string(" ") + name + ":" + std::to_string((long long)v);
+    }
+    fprintf(stderr, "%s\n", c.c_str());
 }
 
 bool recv_full(int fd, uint8_t *buf, size_t n) {
@@ -315,13 +447,14 @@ void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_f
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E]\n"
+        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E] [--cpu | --cuda]\n"
+                        "  --tcp: default 127.0.0.1:8300 (the reference's port, src/nemo-server.cpp:411; the reference binds every interface when no host is given, this server binds loopback unless told otherwise: --tcp 0.0.0.0:8300)\n"
                         "  --pipeline E: consecutive engine calls overlap on the GPU (E = 0..4; 4 pieces on 4 hardware queues is the throughput optimum, 0 the lowest latency); a stream's text arrives\n"
                         "                E calls later while the FIFO is busy and at once when it runs empty\n"
                         "  --devices: one engine + worker per listed GPU; stream s is served by entry s mod count\n", argv[0]);
         return 1;
     }
-    std::string tcp = "127.0.0.1:8765", unix_path;
+    std::string tcp = "127.0.0.1:8300", unix_path;
     std::vector<int> devices{0};
     int dtype = 1, max_streams = 64;
     for (int i = 2; i < argc; i++) {
@@ -341,6 +474,10 @@ int main(int argc, char **argv) {
         }
         else if (a == "--max-streams" && i + 1 < argc) max_streams = atoi(argv[++i]);
         else if (a == "--f32") dtype = 0;
+        else if (a == "--cpu" || a == "--cuda" || a == "--metal") {
+            // the reference server's backend switches (src/nemo-server.cpp:405-406): accepted so that its invocations run unchanged
+            fprintf(stderr, "note: %s has no effect, this build runs on the MI355X engine (HIP)\n", a.c_str());
+        }
         else if (a == "--pipeline" && i + 1 < argc) g_pipeline = atoi(argv[++i]);
         else { fprintf(stderr, "Unknown flag: %s\n", a.c_str()); return 1; }
     }

@@ -87,10 +87,10 @@ class StreamState:
         self.ended = None
 
 
-def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0):
-    streams = [StreamState(i, R, seconds) for i in range(n_streams)]
+def _exchange_python(streams, sock_path, R, mode, n_conns, timeout):
+    """the stdlib-socket client of round 3 (one Python process: it bounds the burst figures itself)"""
     conns = []
-    for c in range(min(n_conns, n_streams)):
+    for c in range(min(n_conns, len(streams))):
         s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         s.settimeout(timeout)
         s.connect(sock_path)
@@ -158,6 +158,39 @@ def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0):
     t_end = max([st.ended or time.perf_counter() for st in streams])
     for s in conns:
         s.close()
+    return t_end - (t0 + 0.05), errors
+
+
+def _exchange_native(streams, sock_path, R, mode, n_conns, timeout, workdir):
+    """bin/nemo-load-amd (host/nemo_load_client.cpp): one sender + one receiver thread per connection, PCM from files"""
+    d = Path(workdir) / f"pcm-{int(time.time() * 1e3) % 10 ** 7}"
+    d.mkdir(parents=True, exist_ok=True)
+    for i, st in enumerate(streams):
+        st.pcm.astype("<i2").tofile(d / f"stream_{i:04d}.s16")
+    rep_path = d / "report.json"
+    r = subprocess.run([str(BIN / "nemo-load-amd"), "--unix", sock_path, "--pcm-dir", str(d), "--streams", str(len(streams)), "--conns", str(n_conns),
+                        "--right-context", str(R), "--mode", mode, "--out", str(rep_path)], capture_output=True, text=True, timeout=timeout)
+    errors = [("client", r.returncode, r.stderr[-300:])] if r.returncode != 0 else []
+    rep = json.loads(rep_path.read_text()) if rep_path.exists() else {"per_stream": [], "wall_seconds": float("nan")}
+    for st, ps in zip(streams, rep["per_stream"]):
+        raw = ps["text"].encode()
+        st.sid, st.text, st.send_times = ps["sid"], ps["text"], ps["send_times"]
+        st.arrivals = [(t, len(raw[:nb].decode(errors="ignore"))) for t, nb in ps["arrivals"]]
+        st.ended = ps["ended"]
+        if ps["error"]:
+            errors.append((ps["sid"], "ERROR", ps["error"][:100]))
+    for f in d.iterdir():
+        f.unlink()
+    d.rmdir()
+    return rep["wall_seconds"], errors
+
+
+def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0, client="python", workdir="/tmp/nasr_load"):
+    streams = [StreamState(i, R, seconds) for i in range(n_streams)]
+    if client == "native":
+        wall, errors = _exchange_native(streams, sock_path, R, mode, n_conns, timeout, workdir)
+    else:
+        wall, errors = _exchange_python(streams, sock_path, R, mode, n_conns, timeout)
     # per-token latency: token k of a stream is emitted at the first frame wholly inside its phone; the chunk holding that
     # frame is complete once sample (chunk + 1) x 1280 T (+ the STFT's 400-sample reach) has been pushed
     lat, correct = [], 0
@@ -177,9 +210,8 @@ def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0):
             if ai < len(st.arrivals):
                 lat.append(st.arrivals[ai][0] - st.send_times[push])
     audio_s = sum(st.pcm.size for st in streams) / synth.SAMPLE_RATE
-    wall = t_end - (t0 + 0.05)
     lat = np.array(lat) if lat else np.zeros(1)
-    return dict(mode=mode, streams=n_streams, right_context=R, audio_seconds=round(audio_s, 1), wall_seconds=round(wall, 3),
+    return dict(mode=mode, client=client, streams=n_streams, right_context=R, audio_seconds=round(audio_s, 1), wall_seconds=round(wall, 3),
                 aggregate_rtfx=round(audio_s / wall, 1), transcripts_correct=correct, tokens=int(lat.size), errors=errors[:5],
                 token_latency_ms=dict(p50=round(1e3 * float(np.percentile(lat, 50)), 1), p99=round(1e3 * float(np.percentile(lat, 99)), 1),
                                       max=round(1e3 * float(lat.max()), 1)))
@@ -212,7 +244,18 @@ def stop_server(proc):
                 b, n = tok.split(":")
                 hist[int(b)] = hist.get(int(b), 0) + int(n)
     calls = sum(hist.values())
-    return dict(engine_calls=calls, streams_per_call_mean=round(sum(b * n for b, n in hist.items()) / max(calls, 1), 2),
+    counters, partial = {}, 0
+    for line in err.splitlines():
+        m = re.match(r"worker: engine counters(.*)", line)
+        if m:
+            for tok in m.group(1).split():
+                k, v = tok.split(":")
+                counters[k] = counters.get(k, 0) + int(v)
+        m = re.search(r"(\d+) partial-chunk calls", line)
+        if m:
+            partial += int(m.group(1))
+    return dict(engine_calls=calls, partial_chunk_calls=partial, engine_counters=counters,
+                eager_share=round(counters.get("eager_steps", 0) / max(calls, 1), 4), streams_per_call_mean=round(sum(b * n for b, n in hist.items()) / max(calls, 1), 2),
                 b_histogram={str(b): n for b, n in sorted(hist.items())}), err
 
 
@@ -226,6 +269,10 @@ def main():
     ap.add_argument("--model", default="")
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--workdir", default="/tmp/nasr_load")
+    ap.add_argument("--client", default="native", choices=["native", "python"])
+    ap.add_argument("--warmup-seconds", type=float, default=0.0,
+                    help="a first load of this many seconds per stream on the same server (graph captures, lane picking), not reported")
+    ap.add_argument("--conns", type=int, default=8)
     args = ap.parse_args()
     wd = Path(args.workdir)
     wd.mkdir(parents=True, exist_ok=True)
@@ -235,7 +282,9 @@ def main():
     sock_path = str(wd / f"asr-{int(time.time() * 1000) % 100000}.sock")
     proc = start_server(model, sock_path, args.streams, args.pipeline)
     try:
-        rep = run_load(sock_path, args.streams, args.seconds, args.right_context, args.mode)
+        if args.warmup_seconds > 0:
+            run_load(sock_path, args.streams, args.warmup_seconds, args.right_context, args.mode, n_conns=args.conns, client=args.client, workdir=args.workdir)
+        rep = run_load(sock_path, args.streams, args.seconds, args.right_context, args.mode, n_conns=args.conns, client=args.client, workdir=args.workdir)
     finally:
         srv, err = stop_server(proc)
     rep["server"] = srv
