@@ -132,6 +132,8 @@ def parse(argv=None):
     ap.add_argument("--extra-steps", type=int, default=200, help="timed steps per region of the extra configurations")
     ap.add_argument("--diarize", action="store_true",
                     help="BASELINE config 5 on the HEADLINE workload too: also time the diarization side-car on each step's audio")
+    ap.add_argument("--stream-offset", type=int, default=0,
+                    help="first stream id of rank 0 (to re-run one rank's streams of an N-rank job in a single process: rank r owns offset + r B ...)")
     ap.add_argument("--share-device", type=int, default=-1, metavar="D",
                     help="rehearsal of the N > 1 path on a box with ONE GPU: every rank runs its engine on device D and the ranks meet over gloo "
                          "(RCCL refuses two ranks on one device); the line says so in config.parallelism")
@@ -504,7 +506,7 @@ def main():
     prof_steps = 0 if args.no_profile_pass else min(args.steps, 50)
     need_s = (args.warmup + (args.regions + 3) * (args.steps + prime) * 2 + prof_steps + 4) * synth.shift_samples(R) * args.chunks_per_step / synth.SAMPLE_RATE
     audio_s = min(max(need_s, args.cpu_seconds + 2.0), 120.0)
-    run_ids = sharding.stream_ids(rank, world, B)
+    run_ids = [args.stream_offset + i for i in sharding.stream_ids(rank, world, B)]
     run = Run(capi, synth, engW, args.layers, dtype, B, R, local_rank, run_ids, args.chunks_per_step,
               pipeline=depth, audio_s=audio_s, speech=speech)
     del engW

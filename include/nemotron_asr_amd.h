@@ -204,10 +204,19 @@ enum {
  * reversible for the engine's lifetime.
  * "graph_cache" (>= 1, default 16): step shapes (streams in the call, lookahead, chunks per push, pieces) whose hipGraphs are kept;
  * beyond it the least recently used shape is dropped and re-captured when it comes back -- a server whose batch size changes from
- * call to call (reference: one stream per call, src/nemo-server.cpp:192-271) holds a bounded number of graph execs. */
+ * call to call (reference: one stream per call, src/nemo-server.cpp:192-271) holds a bounded number of graph execs.
+ * Kernel-selection switches for A/B runs and bit-identity tests (round 4: these were environment variables read inside the product path;
+ * set them before the first step, results never depend on them): "gemm_cores" (-1 = the engine's rule, 0 / 1 = never / always the
+ * large-M GEMM kernels of which two share a CU), "persistent_gemm" (0: never the persistent tile loop), "f32_mfma" (0: f32 GEMMs above
+ * four rows on the FMA tile kernel instead of the f32 MFMA), "decode_graph_iterations" (>= 1, default 12: decode iterations a
+ * pipelined step's decode graph carries before the eager fallback), "decode_lane" (0: the decode graphs run behind the last encoder
+ * piece instead of on a stream of their own). */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* diagnostics: "graph_execs" (hipGraphExec objects alive), "graph_shapes" (distinct cached step shapes), "graph_evictions",
- * "graph_replays", "eager_steps", "pipelined_steps".  Returns 0, or -1 for an unknown name. */
+ * "graph_replays" (calls served by a hipGraph, pipelined ones included), "eager_steps" (calls that were not graph-eligible: ragged
+ * pushes, streams that complete different chunk counts), "pipelined_steps", "grouped_steps", "lanes" (HIP streams the engine found
+ * to overlap; 0 before the first pipelined step).  Returns 0, or -1 for an unknown name.  Like every entry point that takes an
+ * engine, call it from the thread that steps that engine: it reads the graph caches without a lock. */
 int nasr_engine_get_counter(const nasr_engine *e, const char *name, int64_t *value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);
@@ -221,8 +230,10 @@ int nasr_engine_profile_read(nasr_engine *e, nasr_kernel_stat *out, int cap); /*
 /* raw hipStream_t of the engine (for external event timing) */
 void *nasr_engine_hip_stream(nasr_engine *e);
 /* Hands the last of the engine's side-by-side HIP streams -- and with it a hardware queue that no encoder lane will use -- to
- * another GPU client of the process (nasr_diar_set_stream).  The engine runs one encoder piece fewer at most, still owns the
- * stream and destroys it in nasr_engine_destroy: the borrower must be destroyed first.  *out receives a hipStream_t. */
+ * another GPU client of the process (nasr_diar_set_stream).  The engine runs one encoder piece fewer at most and still owns the
+ * stream.  Borrowers inside this library are counted: destroy them first.  If the engine goes first, nasr_engine_destroy says so
+ * on stderr and in nasr_last_error(), and the stream stays alive until its last borrower lets go (nothing dangles in either
+ * order).  *out receives a hipStream_t. */
 int nasr_engine_lend_stream(nasr_engine *e, void **out);
 /* device malloc/free/copy helpers so a host written without HIP can keep PCM resident */
 int nasr_device_alloc(nasr_engine *e, void **out, int64_t bytes);
@@ -242,8 +253,9 @@ typedef struct nasr_diar nasr_diar;
  * convolutions run on the bf16 MFMA with bf16 activation planes (3 workgroups per CU instead of 1; P(speech) within a few 1e-3).
  * max_windows / max_segments size the scratch (larger calls are tiled). */
 #define NASR_DIAR_VAD_BF16 0x100
-/* the same kernel with IEEE-half planes and weights on the f16 MFMA (same rate, 11 significand bits instead of 8: P(speech) within
- * 1e-3, and the onset / offset segments of the f32 network on the config-5 audio -- tests/test_gpu_diar.py); values saturate at 65 504 */
+/* the same kernel with IEEE-half planes and weights on the f16 MFMA (same rate, 11 significand bits instead of 8: an eighth of the
+ * bf16 planes' rounding -- logit error 0.006 against 0.04, P(speech) within 1e-4 of the f32 kernel on the synthetic network;
+ * segment-level comparison in profiles/r4_vad_16bit_segments.md, tests/test_gpu_diar.py); values saturate at 65 504 */
 #define NASR_DIAR_VAD_F16  0x200
 int  nasr_diar_create(nasr_diar **out, int device_id, int dtype, const nasr_weight_desc *weights, int n_weights,
                       int max_windows, int max_segments);

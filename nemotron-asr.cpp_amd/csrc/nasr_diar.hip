@@ -47,6 +47,7 @@ struct nasr_diar {
     int device = 0;
     hipStream_t st = nullptr;
     bool st_borrowed = false;        // nasr_diar_set_stream: the stream belongs to somebody else
+    bool st_lent = false;            // ... to an engine of this library (nasr_engine_lend_stream): released through the borrow count
     std::vector<void *> allocs;
     std::map<std::string, std::vector<float>> host;     // tensors by name (only during create)
     bool has_vad = false, has_spk = false;
@@ -317,6 +318,7 @@ static void diar_destroy_impl(nasr_diar *d) {
     if (d->pin) hipHostFree(d->pin);
     if (d->pin_audio) hipHostFree(d->pin_audio);
     if (d->st && !d->st_borrowed) hipStreamDestroy(d->st);
+    else if (d->st && d->st_lent) lent_stream_release(d->st);
     delete d;
 }
 
@@ -335,9 +337,11 @@ extern "C" int nasr_diar_set_stream(nasr_diar *d, void *hip_stream) {
     if (d->st) {
         hipStreamSynchronize(d->st);
         if (!d->st_borrowed) hipStreamDestroy(d->st);
+        else if (d->st_lent) lent_stream_release(d->st);
     }
     d->st = (hipStream_t)hip_stream;
     d->st_borrowed = true;
+    d->st_lent = lent_stream_acquire(d->st);       // a stream an engine lent: counted, so that neither side leaves the other a dangling handle
     return 0;
 }
 

@@ -298,5 +298,14 @@ void launch_spk_asp(const float *x, const float *logits, int C, const int *lens,
                     float *pool, int S, hipStream_t st);
 int set_error(const char *msg);      // fills nasr_last_error() of the calling thread, returns -1
 
+// ---- streams an engine has lent to another client of the library (nasr_engine_lend_stream -> nasr_diar_set_stream) ----------------
+// Round-2 advisor / round-3 verdict: the engine owns a lent stream and destroyed it in nasr_engine_destroy whatever the borrower was
+// doing.  The library now counts borrowers: an engine that goes first says so loudly (stderr + nasr_last_error) and leaves the stream
+// to its borrowers -- the last one to let go destroys it.  Nothing dangles in either order.
+void lent_stream_register(hipStream_t s);        // the engine lends s
+bool lent_stream_acquire(hipStream_t s);         // a borrower starts using s (false: not a lent stream, the caller's own)
+void lent_stream_release(hipStream_t s);         // a borrower is done with s; destroys s if its engine is gone and nobody else holds it
+int  lent_stream_engine_gone(hipStream_t s);     // the lender is being destroyed: borrowers still holding s (0: the engine destroys s itself)
+
 
 }  // namespace nasr

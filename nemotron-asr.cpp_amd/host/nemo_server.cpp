@@ -128,7 +128,7 @@ bool json_int(const std::string &j, const char *key, int &out) {
 
 // ---- the batch former --------------------------------------------------------------------------------------------------
 // The engine's fast path is a hipGraph replay (or, with --pipeline, graphs of consecutive calls side by side), and a call is
-// graph-eligible only if every stream in it completes the SAME number of chunks (csrc/nasr_engine.hip: try_graph_step); anything
+// graph-eligible only if every stream in it completes the SAME number of chunks (csrc/nasr_abi.hip: try_graph_step); anything
 // else runs eagerly, chunk by chunk, after draining the pipeline.  Round 3's worker handed the engine whatever had arrived --
 // ragged pushes, sessions one chunk apart -- and delivered a fifth of the engine's throughput (profiles/r3_server_load_64_streams.json).
 // Now a session is only ever handed WHOLE chunks: how many chunks a session has completed is a pure function of the samples it
@@ -162,6 +162,35 @@ struct Session {
     }
 };
 
+// Every batch size a lane can meet is a step shape of its own (hipGraphs per (streams, lookahead, chunks)), and capturing one takes
+// ~20 ms -- the p99 of a live load whose calls carry 57..64 streams was those captures (profiles/r4_server_load.md).  --prewarm R[,R..]
+// runs one chunk of silence through B = max_streams .. 1 scratch sessions per listed right_context before the socket opens, so the
+// shapes of the streaming cadence (G = 1) exist when the first client connects; the graph cache is sized to keep them all.
+void prewarm(nemo_context *model, int right_context) {
+    const int N = model->max_streams, T = 1 + right_context;
+    nemo_cache_config cfg = nemo_cache_config::default_config();
+    cfg.att_right_context = right_context;
+    std::vector<nemo_stream_context *> sc;
+    for (int i = 0; i < N; i++) {
+        nemo_stream_context *s = nemo_stream_init(model, &cfg);
+        if (!s) break;
+        sc.push_back(s);
+    }
+    const size_t first = (size_t)160 * (size_t)(9 + 8 * T - 1) + 256, shift = (size_t)1280 * (size_t)T;
+    const std::vector<int16_t> silence(first, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int B = (int)sc.size(); B >= 1; B--) {          // the first call gives every session its first chunk, each later one another chunk to B of them
+        std::vector<const int16_t *> pcm((size_t)B, silence.data());
+        std::vector<int> ns((size_t)B, (int)(B == (int)sc.size() ? first : shift));
+        std::vector<std::string> out((size_t)B);
+        if (!nemo_stream_process_batch(sc.data(), B, pcm.data(), ns.data(), out.data())) break;
+    }
+    if (!sc.empty()) { std::vector<std::string> out(sc.size()); nemo_stream_collect_batch(sc.data(), (int)sc.size(), out.data()); }
+    for (nemo_stream_context *s : sc) nemo_stream_free(s);
+    fprintf(stderr, "prewarm: right_context %d, %zu step shapes in %.2f s\n", right_context, sc.size(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+}
+
 void worker_loop(Lane *lane) {
     nemo_context *model = lane->model;
     std::map<uint32_t, Session> sessions;
@@ -169,7 +198,7 @@ void worker_loop(Lane *lane) {
     std::vector<uint32_t> ending;               // sessions whose STREAM_END has been read
     std::map<int, uint64_t> b_hist;               // streams per engine call -> calls (printed at exit: tests/server_load.py reads it)
     std::set<uint32_t> in_flight;               // --pipeline: sessions whose last steps may still be on the GPU
-    const int row_budget = std::max(model->max_streams * 14, 256);      // rows one launch sequence may carry (csrc/nasr_engine.hip: w_rows)
+    const int row_budget = std::max(model->max_streams * 14, 256);      // rows one launch sequence may carry (csrc/nasr_engine.hip: w_rows, nasr_engine_create)
     auto drain = [&]() {                         // complete the steps in flight and send their text (FIFO empty, END, LANG)
         if (in_flight.empty()) return;
         std::vector<uint32_t> ids;
@@ -223,6 +252,7 @@ void worker_loop(Lane *lane) {
             int G = INT32_MAX;
             for (uint32_t id : ids) G = std::min(G, sessions[id].whole_chunks_pending());
             G = std::max(1, std::min(G, std::min(row_budget / ((int)ids.size() * T), 248 / T)));      // 248: a call's samples stay below the engine's MAX_PUSH (256 frames) with the first chunk's extra 9 mel frames
+            while (G & (G - 1)) G &= G - 1;       // a power of two: every (streams, chunks) pair is a step shape with graphs of its own (~20 ms to capture); a backlog is worked off in 8 + 4 + 2 + 1 rather than in 13 different sizes
             std::vector<size_t> n(ids.size());
             for (size_t b = 0; b < ids.size(); b++) {
                 Session &s = sessions[ids[b]];
@@ -338,8 +368,9 @@ void worker_loop(Lane *lane) {
             lane->space_cv.notify_all();
         }
         for (Event &ev : batch) apply(ev);
-        // the forming window: the first whole chunk is in; wait for the sessions that push on the same clock
-        if (!backlog && any_ready() && !all_ready()) {
+        // the forming window: the first whole chunk is in; wait for the sessions that push on the same clock (with a backlog too: a
+        // call that leaves out the sessions whose next frame is a few hundred microseconds away is another, smaller step shape)
+        if (any_ready() && !all_ready()) {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(kFormingWindowUs);
             for (;;) {
                 std::deque<Event> more;
@@ -447,7 +478,8 @@ void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_f
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E] [--cpu | --cuda]\n"
+        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E] [--prewarm R[,R...]] [--cpu | --cuda]\n"
+                        "  --prewarm: capture the step graphs of every batch size 1..max-streams for these right_context values before listening (~20 ms each)\n"
                         "  --tcp: default 127.0.0.1:8300 (the reference's port, src/nemo-server.cpp:411; the reference binds every interface when no host is given, this server binds loopback unless told otherwise: --tcp 0.0.0.0:8300)\n"
                         "  --pipeline E: consecutive engine calls overlap on the GPU (E = 0..4; 4 pieces on 4 hardware queues is the throughput optimum, 0 the lowest latency); a stream's text arrives\n"
                         "                E calls later while the FIFO is busy and at once when it runs empty\n"
@@ -457,6 +489,7 @@ int main(int argc, char **argv) {
     std::string tcp = "127.0.0.1:8300", unix_path;
     std::vector<int> devices{0};
     int dtype = 1, max_streams = 64;
+    std::vector<int> prewarm_rc;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--tcp" && i + 1 < argc) tcp = argv[++i];
@@ -479,6 +512,13 @@ int main(int argc, char **argv) {
             fprintf(stderr, "note: %s has no effect, this build runs on the MI355X engine (HIP)\n", a.c_str());
         }
         else if (a == "--pipeline" && i + 1 < argc) g_pipeline = atoi(argv[++i]);
+        else if (a == "--prewarm" && i + 1 < argc) {
+            for (const char *p = argv[++i]; *p;) {
+                prewarm_rc.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
         else { fprintf(stderr, "Unknown flag: %s\n", a.c_str()); return 1; }
     }
     for (int dev : devices) {
@@ -486,6 +526,9 @@ int main(int argc, char **argv) {
         ln->model = nemo_init_with_device(argv[1], dev, dtype, max_streams);
         if (!ln->model) { fprintf(stderr, "Failed to load ASR model on device %d\n", dev); return 1; }
         if (g_pipeline > 0 && !nemo_set_pipeline(ln->model, g_pipeline)) return 1;
+        // one step shape per batch size and right_context in use, plus the multi-chunk shapes of a backlog: none is evicted in steady state
+        if (nasr_engine_set_option(ln->model->engine, "graph_cache", std::max(16, (max_streams + 8) * std::max(1, (int)prewarm_rc.size()))) < 0) return 1;
+        for (int rc : prewarm_rc) prewarm(ln->model, rc);
         g_lanes.push_back(std::move(ln));
     }
     int fd;

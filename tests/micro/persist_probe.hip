@@ -11,16 +11,20 @@ using namespace nasr;
 int main(int argc, char **argv) {
     init_gemm_kernel_attributes();
     std::vector<int> Ms;
-    for (int i = 1; i < argc; i++) Ms.push_back(atoi(argv[i]));
+    // "cold": every launch reads another weight matrix (48 x 8 MiB, cycled: more than the 256 MiB of MALL) and another activation
+    // buffer (4 x), as the engine's GEMMs do -- a layer's weights come from HBM once per step and the activations were just written
+    bool cold = false;
+    for (int i = 1; i < argc; i++) { if (!strcmp(argv[i], "cold")) cold = true; else Ms.push_back(atoi(argv[i])); }
     if (Ms.empty()) Ms = {1792, 3584, 7168, 15360};
     const int Mmax = 15360;
     bf16_t *A, *W, *act; float *outf, *bias;
-    CHK(hipMalloc(&A, (size_t)Mmax * 4096 * 2)); CHK(hipMalloc(&W, (size_t)4096 * 4096 * 2));
+    const int NW = cold ? 12 : 1, NA = cold ? 3 : 1;          // 12 x 32 MiB of weights (4 matrices of 8 MiB each), 3 activation buffers
+    CHK(hipMalloc(&A, (size_t)NA * Mmax * 4096 * 2)); CHK(hipMalloc(&W, (size_t)NW * 4096 * 4096 * 2));
     CHK(hipMalloc(&act, (size_t)Mmax * 4096 * 2)); CHK(hipMalloc(&outf, (size_t)Mmax * 4096 * 4)); CHK(hipMalloc(&bias, 4096 * 4));
     std::vector<bf16_t> h((size_t)4096 * 4096);
     for (size_t i = 0; i < h.size(); i++) h[i] = (bf16_t)(0x3c00 + (i * 2654435761u >> 24 & 0x7f) + ((i & 8) ? 0x8000 : 0));
-    CHK(hipMemcpy(W, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    for (size_t off = 0; off < (size_t)Mmax * 4096; off += h.size()) CHK(hipMemcpy(A + off, h.data(), std::min(h.size(), (size_t)Mmax * 4096 - off) * 2, hipMemcpyHostToDevice));
+    for (int i = 0; i < NW; i++) CHK(hipMemcpy(W + (size_t)i * h.size(), h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    for (size_t off = 0; off < (size_t)NA * Mmax * 4096; off += h.size()) CHK(hipMemcpy(A + off, h.data(), std::min(h.size(), (size_t)NA * Mmax * 4096 - off) * 2, hipMemcpyHostToDevice));
     CHK(hipMemset(bias, 0, 4096 * 4));
     hipStream_t st; CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     struct Shape { const char *name; int N, K, epi; } shapes[] = {{"W1  N=4096 K=1024 SiLU->bf16", 4096, 1024, EPI_SILU_ACT}, {"W2  N=1024 K=4096 f32", 1024, 4096, EPI_PART_F32},
@@ -40,7 +44,10 @@ int main(int argc, char **argv) {
                 CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
                 const int reps = 40;
                 CHK(hipEventRecord(a, st));
-                for (int i = 0; i < reps; i++) launch_gemm_bf16(g, st);
+                for (int i = 0; i < reps; i++) {
+                    if (cold) { g.W = W + (size_t)(i % (4 * NW)) * ((size_t)1024 * 4096); g.A = A + (size_t)(i % NA) * Mmax * 4096; }
+                    launch_gemm_bf16(g, st);
+                }
                 CHK(hipEventRecord(b, st));
                 CHK(hipEventSynchronize(b));
                 float ms = 0;
@@ -48,7 +55,7 @@ int main(int argc, char **argv) {
                 us[mode] = 1e3 * ms / reps;
             }
             const double fl = 2.0 * M * s.N * s.K * 1e-6;
-            printf("M = %5d  %-34s persistent %7.2f us (%5.0f TFLOP/s) | per-tile, two per CU %7.2f us (%5.0f) | per-tile, deep rings %7.2f us (%5.0f)\n", M, s.name,
+            printf("%sM = %5d  %-34s persistent %7.2f us (%5.0f TFLOP/s) | per-tile, two per CU %7.2f us (%5.0f) | per-tile, deep rings %7.2f us (%5.0f)\n", cold ? "[cold] " : "", M, s.name,
                    us[0], fl / us[0], us[1], fl / us[1], us[2], fl / us[2]);
         }
     return 0;

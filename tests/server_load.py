@@ -244,18 +244,23 @@ def stop_server(proc):
                 b, n = tok.split(":")
                 hist[int(b)] = hist.get(int(b), 0) + int(n)
     calls = sum(hist.values())
-    counters, partial = {}, 0
+    counters, partial, tails = {}, 0, 0
     for line in err.splitlines():
         m = re.match(r"worker: engine counters(.*)", line)
         if m:
             for tok in m.group(1).split():
                 k, v = tok.split(":")
                 counters[k] = counters.get(k, 0) + int(v)
-        m = re.search(r"(\d+) partial-chunk calls", line)
+        m = re.search(r"(\d+) partial-chunk calls, (\d+) tail flushes", line)
         if m:
             partial += int(m.group(1))
-    return dict(engine_calls=calls, partial_chunk_calls=partial, engine_counters=counters,
-                eager_share=round(counters.get("eager_steps", 0) / max(calls, 1), 4), streams_per_call_mean=round(sum(b * n for b, n in hist.items()) / max(calls, 1), 2),
+            tails += int(m.group(2))
+    eager = counters.get("eager_steps", 0)
+    return dict(engine_calls=calls, partial_chunk_calls=partial, tail_flushes=tails, engine_counters=counters,
+                eager_share=round(eager / max(calls, 1), 4),
+                # what is eager by construction: the sub-chunk remainder of sessions that end (one call per group of sessions that end
+                # together) and the tail flush behind it; everything else should be a graph replay
+                eager_outside_stream_end=max(0, eager - partial - tails), streams_per_call_mean=round(sum(b * n for b, n in hist.items()) / max(calls, 1), 2),
                 b_histogram={str(b): n for b, n in sorted(hist.items())}), err
 
 
@@ -270,6 +275,7 @@ def main():
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--workdir", default="/tmp/nasr_load")
     ap.add_argument("--client", default="native", choices=["native", "python"])
+    ap.add_argument("--prewarm", action="store_true", help="start the server with --prewarm <right-context>")
     ap.add_argument("--warmup-seconds", type=float, default=0.0,
                     help="a first load of this many seconds per stream on the same server (graph captures, lane picking), not reported")
     ap.add_argument("--conns", type=int, default=8)
@@ -280,7 +286,7 @@ def main():
     if not model.exists():
         write_model(model, args.layers)
     sock_path = str(wd / f"asr-{int(time.time() * 1000) % 100000}.sock")
-    proc = start_server(model, sock_path, args.streams, args.pipeline)
+    proc = start_server(model, sock_path, args.streams, args.pipeline, extra=("--prewarm", str(args.right_context)) if args.prewarm else ())
     try:
         if args.warmup_seconds > 0:
             run_load(sock_path, args.streams, args.warmup_seconds, args.right_context, args.mode, n_conns=args.conns, client=args.client, workdir=args.workdir)

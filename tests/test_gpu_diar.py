@@ -310,3 +310,31 @@ def test_side_car_on_a_stream_lent_by_the_asr_engine(Wv):
         st.destroy()
         eng.close()
     assert len(toks[0]) > 0 and toks[0] == toks[1]
+
+
+def test_engine_destroyed_before_its_borrower_leaves_nothing_dangling(Wv, capfd):
+    """Round-2 advisor / round-3 verdict: the side-car held a raw hipStream_t that nasr_engine_destroy destroyed under it.  Borrowers
+    are counted now: the engine going first is reported (stderr + nasr_last_error) and the stream lives on until the side-car lets
+    go -- the side-car keeps working on it, with the same results."""
+    audios = [_audio(1, 10080 + 160 * 37 + 55)]
+    d0 = capi.Diar(Wv)
+    ref = d0.vad(audios)
+    d0.close()
+    eng = capi.Engine(synth.make_weights(n_layers=1), n_layers=1, dtype=capi.DTYPE_BF16, max_streams=1)
+    eng.set_option("pipeline", 4)
+    diar = capi.Diar(Wv)
+    diar.set_stream(eng.lend_stream())
+    assert np.array_equal(diar.vad(audios)[0], ref[0])
+    eng.close()                                    # the lender first
+    err = capfd.readouterr().err
+    assert "still held by 1 client" in err, err
+    assert np.array_equal(diar.vad(audios)[0], ref[0])        # the stream is still there
+    diar.close()                                   # the last borrower destroys it
+    # the usual order stays silent
+    eng = capi.Engine(synth.make_weights(n_layers=1), n_layers=1, dtype=capi.DTYPE_BF16, max_streams=1)
+    eng.set_option("pipeline", 4)
+    diar = capi.Diar(Wv)
+    diar.set_stream(eng.lend_stream())
+    diar.close()
+    eng.close()
+    assert "still held" not in capfd.readouterr().err
