@@ -1,0 +1,82 @@
+// fuzz_harness -- CPU-only harness for the sanitizer build (make -C host san -> bin/host_fuzz_san, built with
+// -fsanitize=address,undefined): feeds the byte-level parsers of the host side whatever files it is given.  No GPU, no engine.
+//   host_fuzz_san gguf   FILE...   every file through the GGUF reader: open, every KV looked at, every tensor's bytes summed
+//   host_fuzz_san frames FILE...   every file as a byte stream of wire frames (server_protocol.h): headers decoded, payload bounds
+//                                  checked as the server's reader does, STREAM_START payloads through the JSON helpers, PUSH sizes
+//                                  through the batch former's chunk arithmetic
+// Prints one line per file ("ok ..." or "rejected: ...") and exits 0: a malformed input must be REJECTED, never crash -- what the test
+// (tests/test_sanitizers.py) asserts is that the sanitizers stay silent over a corpus of mutated files.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "gguf_reader.h"
+#include "server_protocol.h"
+
+static int run_gguf(const char *path) {
+    nasr_host::GgufFile f;
+    std::string err;
+    if (!f.open(path, err)) { printf("rejected: %s: %s\n", path, err.c_str()); return 0; }
+    unsigned long long sum = 0;
+    uint32_t v = 0;
+    for (const char *k : {"nemo.n_layers", "nemo.d_model", "nemo.vocab_size", "nemo.num_prompts", "general.alignment"}) sum += f.get_u32(k, v) ? v : 0;
+    if (const nasr_host::GgufValue *vv = f.find("tokenizer.ggml.tokens")) for (const std::string &s : vv->arr_s) sum += s.size();
+    if (const nasr_host::GgufValue *vv = f.find("tokenizer.vocab")) sum += vv->s.size();
+    for (const nasr_host::GgufTensor &t : f.tensors()) {
+        sum += (unsigned long long)t.ne[0] + (unsigned long long)t.n_dims;
+        if (t.data && t.nbytes) { sum += t.data[0]; sum += t.data[t.nbytes - 1]; sum += t.data[t.nbytes / 2]; }     // first / middle / last byte: inside the mapping?
+    }
+    printf("ok: %s: %zu kv, %zu tensors, checksum %llu\n", path, f.n_kv(), f.tensors().size(), sum);
+    return 0;
+}
+
+static int run_frames(const char *path) {
+    using namespace nasr_proto;
+    std::ifstream in(path, std::ios::binary);
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    size_t off = 0, n_frames = 0, rejected = 0;
+    long long chunks = 0, handed = 0;
+    int T = 1;
+    while (off + kHeader <= b.size()) {
+        uint8_t op;
+        uint32_t id, len;
+        decode_header(b.data() + off, op, id, len);
+        off += kHeader;
+        if (len > kMaxPayload) { rejected++; break; }                     // the server answers ERROR and closes
+        if (len > b.size() - off) { rejected++; break; }                  // short read: connection closed
+        const uint8_t *payload = b.data() + off;
+        off += len;
+        n_frames++;
+        switch (op) {
+        case OP_STREAM_START: {
+            const std::string cfg(payload, payload + len);
+            std::string lang;
+            int rc = 0;
+            json_str(cfg, "lang", lang);
+            json_int(cfg, "right_context", rc);
+            if (!valid_right_context(rc)) { rejected++; break; }
+            T = 1 + rc;
+            handed = 0;
+        } break;
+        case OP_PUSH: {
+            handed += len / 2;
+            chunks = chunks_after(handed, T);
+            if (samples_for_chunks(chunks, T) > handed) { printf("BUG: chunk arithmetic\n"); return 1; }
+            if (samples_for_chunks(chunks + 1, T) <= handed) { printf("BUG: chunk arithmetic\n"); return 1; }
+        } break;
+        default: break;
+        }
+        (void)id;
+    }
+    printf("ok: %s: %zu frames, %zu rejected, %lld chunks\n", path, n_frames, rejected, chunks);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE...\n", argv[0]); return 2; }
+    int rc = 0;
+    for (int i = 2; i < argc; i++) rc |= !strcmp(argv[1], "gguf") ? run_gguf(argv[i]) : run_frames(argv[i]);
+    return rc;
+}

@@ -36,12 +36,11 @@
 
 #include "nemo_amd.h"
 #include "nemotron_asr_amd.h"
+#include "server_protocol.h"
 
 namespace {
 
-enum : uint8_t { OP_STREAM_START = 0x01, OP_PUSH = 0x02, OP_STREAM_END = 0x03, OP_SET_LANG = 0x04,
-                 OP_STARTED = 0x81, OP_ACK = 0x82, OP_TEXT = 0x83, OP_ENDED = 0x84, OP_LANG_SET = 0x85, OP_ERROR = 0x8F };
-constexpr size_t kHeader = 9;
+using namespace nasr_proto;
 constexpr size_t kMaxQueuedBytes = 64u << 20;   // back-pressure, as the reference (64 MiB)
 
 struct Conn {
@@ -102,30 +101,6 @@ void enqueue(Event &&ev) {
     ln.cv.notify_one();
 }
 
-// minimal JSON field extraction for {"lang":"xx","right_context":N}
-bool json_str(const std::string &j, const char *key, std::string &out) {
-    const std::string k = std::string("\"") + key + "\"";
-    size_t p = j.find(k);
-    if (p == std::string::npos) return false;
-    p = j.find(':', p + k.size());
-    if (p == std::string::npos) return false;
-    p = j.find('"', p);
-    if (p == std::string::npos) return false;
-    const size_t e = j.find('"', p + 1);
-    if (e == std::string::npos) return false;
-    out = j.substr(p + 1, e - p - 1);
-    return true;
-}
-bool json_int(const std::string &j, const char *key, int &out) {
-    const std::string k = std::string("\"") + key + "\"";
-    size_t p = j.find(k);
-    if (p == std::string::npos) return false;
-    p = j.find(':', p + k.size());
-    if (p == std::string::npos) return false;
-    out = atoi(j.c_str() + p + 1);
-    return true;
-}
-
 // ---- the batch former --------------------------------------------------------------------------------------------------
 // The engine's fast path is a hipGraph replay (or, with --pipeline, graphs of consecutive calls side by side), and a call is
 // graph-eligible only if every stream in it completes the SAME number of chunks (csrc/nasr_abi.hip: try_graph_step); anything
@@ -148,12 +123,8 @@ struct Session {
     int64_t handed = 0;                          // samples the engine has been given since the stream began
     int T = 1;                                   // 1 + right_context
     size_t avail() const { return pending.size() - head; }
-    // samples that must have been handed for k chunks to be complete
-    int64_t samples_for_chunks(int64_t k) const { return k <= 0 ? 0 : 160 * ((int64_t)(9 + 8 * T) + (k - 1) * 8 * T - 1) + 256; }
-    int64_t chunks_after(int64_t samples) const {          // chunks complete once `samples` have been handed
-        const int64_t frames = samples + 256 < 512 ? 0 : (samples + 256 - 512) / 160 + 1, first = 9 + 8 * T;
-        return frames < first ? 0 : (frames - first) / (8 * T) + 1;
-    }
+    int64_t samples_for_chunks(int64_t k) const { return nasr_proto::samples_for_chunks(k, T); }
+    int64_t chunks_after(int64_t samples) const { return nasr_proto::chunks_after(samples, T); }
     int whole_chunks_pending() const { return (int)(chunks_after(handed + (int64_t)avail()) - chunks_after(handed)); }
     void consume(size_t n) {
         head += n; handed += (int64_t)n;
@@ -424,10 +395,10 @@ void reader_loop(int fd) {
     for (;;) {
         uint8_t h[kHeader];
         if (!recv_full(fd, h, kHeader)) break;
-        const uint8_t op = h[0];
-        const uint32_t id = (uint32_t)h[1] | ((uint32_t)h[2] << 8) | ((uint32_t)h[3] << 16) | ((uint32_t)h[4] << 24);
-        const uint32_t len = (uint32_t)h[5] | ((uint32_t)h[6] << 8) | ((uint32_t)h[7] << 16) | ((uint32_t)h[8] << 24);
-        if (len > (256u << 20)) { conn->send_str(OP_ERROR, id, "payload too large"); break; }
+        uint8_t op;
+        uint32_t id, len;
+        decode_header(h, op, id, len);
+        if (len > kMaxPayload) { conn->send_str(OP_ERROR, id, "payload too large"); break; }
         std::vector<uint8_t> payload(len);
         if (len && !recv_full(fd, payload.data(), len)) break;
         Event ev;
@@ -439,6 +410,10 @@ void reader_loop(int fd) {
             ev.type = Ev::CREATE; ev.id = nid; ev.right_context = g_default_rc;
             json_str(cfg, "lang", ev.text);
             json_int(cfg, "right_context", ev.right_context);
+            if (!valid_right_context(ev.right_context)) {      // reference src/nemo-stream.h:15-20: the four latency modes
+                conn->send_str(OP_ERROR, 0, "right_context must be 0, 1, 6 or 13");
+                break;
+            }
             char buf[48];
             const int n = snprintf(buf, sizeof(buf), "{\"id\":%u}", nid);
             conn->send(OP_STARTED, nid, buf, (uint32_t)n);

@@ -1,0 +1,59 @@
+// server_protocol.h -- the parts of the server that are pure functions of bytes: the reference's wire format
+// (src/server-protocol.h:24-41: 9-byte frame = u8 opcode, u32le stream id, u32le payload length), the two JSON fields of a
+// STREAM_START payload, and the chunk arithmetic of the batch former.  Shared by nemo_server.cpp and the sanitizer / fuzz harness
+// (host/fuzz_harness.cpp, tests/test_sanitizers.py), which feeds them mutated frames without a GPU.
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <string>
+
+namespace nasr_proto {
+
+enum : uint8_t { OP_STREAM_START = 0x01, OP_PUSH = 0x02, OP_STREAM_END = 0x03, OP_SET_LANG = 0x04,
+                 OP_STARTED = 0x81, OP_ACK = 0x82, OP_TEXT = 0x83, OP_ENDED = 0x84, OP_LANG_SET = 0x85, OP_ERROR = 0x8F };
+constexpr size_t kHeader = 9;
+constexpr uint32_t kMaxPayload = 256u << 20;
+
+inline void decode_header(const uint8_t *h, uint8_t &op, uint32_t &id, uint32_t &len) {
+    op = h[0];
+    id = (uint32_t)h[1] | ((uint32_t)h[2] << 8) | ((uint32_t)h[3] << 16) | ((uint32_t)h[4] << 24);
+    len = (uint32_t)h[5] | ((uint32_t)h[6] << 8) | ((uint32_t)h[7] << 16) | ((uint32_t)h[8] << 24);
+}
+inline bool valid_right_context(int rc) { return rc == 0 || rc == 1 || rc == 6 || rc == 13; }
+
+// minimal JSON field extraction for {"lang":"xx","right_context":N}
+inline bool json_str(const std::string &j, const char *key, std::string &out) {
+    const std::string k = std::string("\"") + key + "\"";
+    size_t p = j.find(k);
+    if (p == std::string::npos) return false;
+    p = j.find(':', p + k.size());
+    if (p == std::string::npos) return false;
+    p = j.find('"', p);
+    if (p == std::string::npos) return false;
+    const size_t e = j.find('"', p + 1);
+    if (e == std::string::npos) return false;
+    out = j.substr(p + 1, e - p - 1);
+    return true;
+}
+inline bool json_int(const std::string &j, const char *key, int &out) {
+    const std::string k = std::string("\"") + key + "\"";
+    size_t p = j.find(k);
+    if (p == std::string::npos) return false;
+    p = j.find(':', p + k.size());
+    if (p == std::string::npos) return false;
+    out = atoi(j.c_str() + p + 1);
+    return true;
+}
+
+
+// ---- chunk arithmetic (reference src/preprocessor.cpp:220-221, :320-328, src/nemo-stream.h:65-81): 256 zeros of left padding, 512-sample
+// frames at hop 160, the first chunk = 9 + 8 T mel frames, then 8 T per chunk (T = 1 + right_context) -------------------------------
+// samples that must have been handed for k chunks to be complete
+inline int64_t samples_for_chunks(int64_t k, int T) { return k <= 0 ? 0 : 160 * ((int64_t)(9 + 8 * T) + (k - 1) * 8 * T - 1) + 256; }
+// chunks complete once `samples` have been handed
+inline int64_t chunks_after(int64_t samples, int T) {
+    const int64_t frames = samples + 256 < 512 ? 0 : (samples + 256 - 512) / 160 + 1, first = 9 + 8 * T;
+    return frames < first ? 0 : (frames - first) / (8 * T) + 1;
+}
+
+}  // namespace nasr_proto
