@@ -182,10 +182,10 @@ class _StubEngine:
 
 def pmc_traffic(kernel_symbol_part, tag):
     """HBM bytes per launch of a kernel from the rocprofv3 --pmc passes committed under profiles/ for THIS build
-    (profiles/r3_pmc_traffic_<tag>.json, written by tests/prof_r3.sh: FETCH_SIZE x 2 + WRITE_SIZE as
+    (profiles/r4_pmc_traffic_<tag>.json, written by tests/prof_r4.sh: FETCH_SIZE x 2 + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside this process; null when no
     summary for the configuration / kernel is committed."""
-    f = next((c for c in (ROOT / "profiles" / f"r3_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r2_pmc_traffic_{tag}.json") if c.exists()), None)
+    f = next((c for c in (ROOT / "profiles" / f"r4_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r3_pmc_traffic_{tag}.json") if c.exists()), None)
     if f is None:
         return None
     try:
@@ -753,6 +753,39 @@ def main():
             f32_entry.update(tokens_equal_oracle=fa["tokens_equal"], frames_equal_oracle=fa["tokens_equal"] and fa["timing_shifts"] == 0,
                              oracle_tokens=fa["oracle_tokens"])
             frun.close()
+            # ---- the same exact-parity configuration at configs[2]'s batch, on the near-tie (random) checkpoint: 64 streams x R = 13,
+            # f32 GEMMs on the f32 MFMA (round 4).  Timing here; tokens of 8 streams against the oracle here, of all 64 in
+            # tests/test_gpu_configs.py::test_f32_engine_64_streams_is_token_exact_on_the_near_tie_checkpoint
+            del om
+            Wr = synth.make_weights(n_layers=args.layers, margins="random")
+            xR, xB, n_f = 13, 64, 12
+            f64 = Run(capi, synth, Wr, args.layers, capi.DTYPE_F32, xB, xR, local_rank, list(range(xB)), 1, pipeline=depth, audio_s=20.0, speech=False, log_streams=8)
+            for _ in range(4):
+                f64.step()
+            f64.drain()
+            f6 = timed_regions(f64, n_f, barrier_for(f64), max_over_ranks, repeats=3, prime=min(prime, 4))
+            f64.drain()
+            e64 = summarize(f6, n_f, f64.audio_per_step, world)
+            e64.pop("runs_ms_per_step")
+            omr = ob.OracleModel(Wr, args.layers)
+            n_cmp = 3                                   # pushes compared per stream (the first completes no chunk)
+            eq, n_tok = True, 0
+            for b in range(f64.n_log):
+                ost = ob.OracleStream(omr, xR)
+                rt = []
+                for k in range(n_cmp):
+                    rt += ost.process(f64.pcm_host[b][k * f64.n_step:(k + 1) * f64.n_step])
+                rf = ost.token_frames()
+                gt = [(t, f) for t, f in zip(f64.tok_log[b], f64.streams[b].token_frames()) if f < (n_cmp - 1) * (1 + xR)]
+                eq = eq and gt == list(zip(rt, rf))
+                n_tok += len(rt)
+            e64.update(tokens_and_frames_equal_oracle=bool(eq), streams_checked=f64.n_log, oracle_tokens=n_tok, checkpoint="random (near-tie)")
+            details["f32_engine_b64_R13"] = e64
+            f32_entry["b64_R13_ms_per_step"] = e64["ms_per_step"]
+            f32_entry["b64_R13_tokens_equal_oracle"] = bool(eq)
+            f64.close()
+            del omr, Wr
+            om = None
         del om
         cpu_ref = reference_cli_baseline(p[:int(args.cpu_seconds * synth.SAMPLE_RATE)], R)
 

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
 // with idle storers); and SiLU in the consumers stalled the MFMAs 1.3 us per tile.  Here the epilogue is a template parameter, the
 // per-tile pointers are computed once, the pack is branch-free and SiLU is the storers' work.
 // ------------------------------------------------------------------------------------
-constexpr int PS_NS = 3, PS_STAGE = PS_NS * G2_SLOT, PS_LDS = PS_STAGE + 65536, PS_PF = 6;
+constexpr int PS_NS = 3, PS_STAGE = PS_NS * G2_SLOT, PS_LDS = PS_STAGE + 65536;
 __device__ __forceinline__ unsigned ps_stage_off(int row, int cg) { return PS_STAGE + row * 512 + ((cg ^ (row & 31)) << 4); }
 __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // f32_to_bf16 without a branch (same values, NaN kept NaN)
     const uint32_t u = __float_as_uint(f);
@@ -713,40 +713,8 @@ __global__ __launch_bounds__(1024) void k_gemm_persist(GemmParams p, int n_group
         }
     };
     int in_tile = 0;                                             // chunks of the current tile multiplied so far (second halves pending)
-    // L2 prefetch, PS_PF chunks ahead of the ring (round 4, profiles/r4_persistent_gemm.md).  The ring holds two chunks in flight:
-    // 0.85 us of cover where a line that comes from HBM takes ~2 us -- the engine's GEMMs read weights that left every cache a layer ago
-    // and activations the previous kernel wrote through to memory, and with such operands the loop ran 20-30 % below its rate on
-    // cache-resident ones (persist_probe "cold": W2 at 7 168 rows 73 us against 56).  The consumers never wait on vmcnt, so they can
-    // touch the lines of chunk g + PS_PF without ever paying for the latency: consumer lane cl (0..511) owns line cl & 255 of the
-    // chunk's 256 (128 activation rows x 128 B, 16 weight tiles x 8 lines), waves 0-3 serve even chunks, waves 4-7 odd ones.  The
-    // load lands in v127, which nothing else uses (the kernel has 128 VGPRs under its 1024-thread bound and allocates from v0 up).
-    const int pf_line = (wave * 64 + lane) & 255, pf_half = wave >> 2;
-    int pf_t = PS_PF / CPT, pf_kc = PS_PF - pf_t * CPT, pf_cur = -1;
-    const char *pf_base = nullptr;
-    int pf_stride = 0;
     for (int g = 0; g < NB; g++) {
         __builtin_amdgcn_s_barrier();
-        if (g + PS_PF < G) {
-            if (((g + PS_PF) & 1) == pf_half) {
-                if (pf_t != pf_cur) {
-                    pf_cur = pf_t;
-                    int m0, ng;
-                    tile_mn(pf_t, m0, ng);
-                    if (pf_line < 128) {
-                        int m = m0 + pf_line;
-                        if (m >= p.M) m = p.M - 1;
-                        pf_base = a_row_ptr(p, m, 2);
-                        pf_stride = 128;
-                    } else {
-                        const int j = pf_line - 128, tl = j >> 3;
-                        pf_base = (const char *)p.W + ((size_t)(ng * 8 + (tl >> 1)) * KT + (tl & 1)) * 1024 + (j & 7) * 128;
-                        pf_stride = 2048;
-                    }
-                }
-                asm volatile("global_load_dword v127, %0, off" ::"v"(pf_base + (size_t)pf_kc * pf_stride) : "v127", "memory");
-            }
-            if (++pf_kc == CPT) { pf_kc = 0; pf_t++; }
-        }
         const unsigned so = (unsigned)(g % PS_NS) * G2_SLOT;
         if (g < G) {
             const unsigned wa = w_addr + so, ba = b_addr[0] + so;

@@ -30,7 +30,8 @@ import __graft_entry__ as ge  # noqa: E402
 ge.load_package()
 from nemotron_asr_amd import synth  # noqa: E402
 
-ALPHAS = (0.1, 0.2, 0.3, 0.5)
+import os
+ALPHAS = tuple(float(x) for x in os.environ["MARGIN_ALPHAS"].split(",")) if os.environ.get("MARGIN_ALPHAS") else (0.1, 0.2, 0.3, 0.5)      # MARGIN_ALPHAS=0.4: one more column, merged with the rest
 SCALES = (8.0, 4.0, 2.0)
 N_CAL, CAL_SECONDS, LAMBDA = 24, 30.0, 3.0
 N_TOK, TOK_SECONDS = 16, 30.0          # streams compared per cell at R = 0; R = 13 runs 64 streams
@@ -117,7 +118,7 @@ def phase_gpu(out: Path):
                                    bf16_logit_noise_rms=A * noise[f"R{R}"]["score_noise_rms"], bf16_logit_noise_max=A * noise[f"R{R}"]["score_noise_max"])
             rep[f"{tag(alpha)}_A{A:g}"] = cell
             print(json.dumps(cell), f"{time.time() - t0:.0f} s", flush=True)
-            (out / "gpu.json").write_text(json.dumps(rep, indent=1))
+            (out / ("gpu.json" if not os.environ.get("MARGIN_ALPHAS") else f"gpu_{tag(ALPHAS[0])}.json")).write_text(json.dumps(rep, indent=1))
     synth.SPEECH_LOGIT_SCALE = 8.0
 
 
@@ -125,7 +126,7 @@ def phase_cpu(out: Path):
     from oracle import binding as ob
     rep = {}
     t0 = time.time()
-    cells = [(a, 8.0) for a in ALPHAS] + [(0.3, 4.0)]
+    cells = [(a, 8.0) for a in ALPHAS] + ([(0.3, 4.0)] if 0.3 in ALPHAS else [])
     for alpha, A in cells:
         z = np.load(out / f"readout_{tag(alpha)}.npz")
         synth.SPEECH_LOGIT_SCALE = A
@@ -146,12 +147,17 @@ def phase_cpu(out: Path):
         del om
         rep[f"{tag(alpha)}_A{A:g}"] = row
         print(alpha, A, json.dumps(row), f"{time.time() - t0:.0f} s", flush=True)
-        (out / "cpu.json").write_text(json.dumps(rep, indent=1))
+        (out / ("cpu.json" if not os.environ.get("MARGIN_ALPHAS") else f"cpu_{tag(ALPHAS[0])}.json")).write_text(json.dumps(rep, indent=1))
     synth.SPEECH_LOGIT_SCALE = 8.0
 
 
 def phase_merge(out: Path, dest: Path):
-    gpu, cpu = json.loads((out / "gpu.json").read_text()), json.loads((out / "cpu.json").read_text())
+    gpu, cpu = {}, {}
+    for f in sorted(out.glob("gpu*.json")):
+        gpu.update(json.loads(f.read_text()))
+    for f in sorted(out.glob("cpu*.json")):
+        cpu.update(json.loads(f.read_text()))
+    gpu = dict(sorted(gpu.items(), key=lambda kv: (kv[1]["alpha"], -kv[1]["logit_scale"])))
     cells = {}
     for key, cell in gpu.items():
         a_tag, A = key.split("_A")

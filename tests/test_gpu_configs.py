@@ -181,13 +181,16 @@ def _agreement(om, R, pcms, n, toks, frames):
     return rows
 
 
-def test_bf16_token_agreement_vs_f32_oracle(W24):
-    """24 layers, R = 13: 8 streams x 30 s through the bf16 engine (graph path, M = 112 rows) against the F32 oracle.
+@pytest.mark.parametrize("R,B,n_push,pipeline", [(13, 8, 27, 0), (0, 1, 375, 4)])
+def test_bf16_token_agreement_vs_f32_oracle(W24, R, B, n_push, pipeline):
+    """24 layers on the near-tie (random) checkpoint against the F32 oracle: 8 streams x 30 s at R = 13 (graph path, M = 112 rows) and
+    -- round 4 -- configs[1]'s own shape, ONE stream x R = 0 x 30 s on four lanes (fused one-row path).
     Reported: tokens, common prefix, aligned agreement; asserted: every stream's first divergence happens at a decision
-    whose top-2 margin in the oracle is below EPS_MARGIN, and the aligned agreement over all streams is above 0.5."""
-    L, R, B = 24, 13, 8
-    n, pcms = _pieces(R, 27, 700, B)                     # 27 x 1.12 s = 30.2 s per stream
+    whose top-2 margin in the oracle is below EPS_MARGIN, and (R = 13) the aligned agreement over all streams is above 0.5."""
+    L = 24
+    n, pcms = _pieces(R, n_push, 700, B)                 # 27 x 1.12 s = 30.2 s / 375 x 80 ms = 30 s per stream
     eng = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    eng.set_option("pipeline", pipeline)
     toks, frames = _run_engine_tokens(eng, R, pcms, n)
     eng.close()
     om = ob.OracleModel(W24, L)
@@ -195,12 +198,41 @@ def test_bf16_token_agreement_vs_f32_oracle(W24):
     del om
     tot_ref = sum(r["ref_tokens"] for r in rows)
     rate = sum(r["aligned_ratio"] * r["ref_tokens"] for r in rows) / max(tot_ref, 1)
-    _report("bf16_token_agreement", dict(rows=rows, aligned_rate=rate, eps_margin=EPS_MARGIN))
-    assert tot_ref > 50, tot_ref
+    _report(f"bf16_token_agreement_b{B}_R{R}", dict(rows=rows, aligned_rate=rate, eps_margin=EPS_MARGIN))
+    assert tot_ref > (50 if B > 1 else 10), tot_ref
     for r in rows:
         d = r["first_divergence"]
         assert d is None or (d["decision"] >= 0 and d["margin"] < EPS_MARGIN), r
-    assert rate > 0.5, rows
+    assert B == 1 or rate > 0.5, rows
+
+
+def test_f32_engine_64_streams_is_token_exact_on_the_near_tie_checkpoint(W24):
+    """Round 4 (missing #2): the configuration whose parity does not depend on a friendly checkpoint, at configs[2]'s
+    batch.  64 streams x R = 13, 24 layers, NASR_DTYPE_F32 -- every GEMM of the step (M = 896) on v_mfma_f32_32x32x2_f32
+    (k_gemm_f32_mfma, bit-identical to the FMA tile kernel: tests/test_gpu_parity.py) -- on the RANDOM checkpoint, where 1-3 % of
+    the greedy decisions are near-ties: tokens AND emission frames of all 64 streams equal the F32 oracle's, pipelined as
+    benchmarked (reference bar: exact tokens, tests/test_compute.cpp:2805-2817).  bench.py times this configuration
+    (f32_engine.b64_R13_ms_per_step)."""
+    L, R, B = 24, 13, 64
+    n, pcms = _pieces(R, 3, 1200, B)                     # 3 pushes of 1.12 s + the tail flush: 2 chunks + a partial one per stream
+    eng = capi.Engine(W24, n_layers=L, dtype=capi.DTYPE_F32, max_streams=B)
+    eng.set_option("pipeline", 4)
+    toks, frames = _run_engine_tokens(eng, R, pcms, n)
+    eng.close()
+    om = ob.OracleModel(W24, L)
+    total, bad = 0, []
+    for b, pcm in enumerate(pcms):
+        ost = ob.OracleStream(om, R)
+        ref = []
+        for o in range(0, pcm.size, n):
+            ref += ost.process(pcm[o:o + n])
+        ref += ost.finalize()
+        total += len(ref)
+        if toks[b] != ref or frames[b] != ost.token_frames():
+            bad.append(b)
+    del om
+    _report("f32_engine_b64_R13_tokens", dict(streams=B, oracle_tokens=total, streams_that_differ=bad))
+    assert total > 100 and not bad, (total, bad)
 
 
 def test_q8_0_token_agreement_vs_ggml_q8_semantics(Q24):
