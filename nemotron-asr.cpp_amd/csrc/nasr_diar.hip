@@ -614,6 +614,7 @@ static void spk_gemm(nasr_diar *d, const void *A, int lda, const void *W, int M,
     memset(&g, 0, sizeof(g));
     g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = lda; g.splits = 1;
     g.epi = relu ? EPI_BIAS_RELU_F32 : EPI_BIAS_F32; g.out_f32 = out; g.ldo = N; g.bias = bias;
+    g.no_persist = 1;        // the persistent tile loop does not pay with cold weights (profiles/r4_persistent_gemm.md)
     g.coresident = 1;        // M = 160 rows per sub-segment: several tiles per CU, two workgroups per CU overlap fill / multiply / store (96 segments: 3.66 -> 3.41 ms per call)
     if (d->bf16) launch_gemm_bf16(g, d->st);
     else launch_gemm_f32(g, d->st);

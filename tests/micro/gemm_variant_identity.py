@@ -1,7 +1,7 @@
 """Bit-identity of GEMM kernel variants: 16 / 64 / 128 / 256 / 512 streams x R = 13 (M = 224 ... 7 168) on a 3-layer bf16 engine, a few
 steps; prints one digest per setting.  A setting is a space-separated list of engine options ("opt:persistent_gemm=0 opt:gemm_cores=1":
 nasr_engine_set_option before the first step) and / or environment variables ("VAR=value"); the first digest is the build's default.
-    python gemm_variant_identity.py "opt:gemm_cores=1" "opt:gemm_cores=0" "opt:persistent_gemm=0"
+    python gemm_variant_identity.py "opt:gemm_cores=1" "opt:gemm_cores=0" "opt:persistent_gemm=1"
 """
 import hashlib
 import os

@@ -578,12 +578,12 @@ def test_gemm_ring_variants_are_bit_identical():
     synchronous and four lanes) have ONE digest whether the choice is left to the engine or forced either way (engine option "gemm_cores").
     Round 4: 256 and 512 streams (M = 3 584, 7 168) are in the digest too, where the PERSISTENT tile loop (k_gemm_persist: loader, consumer
     and storer waves, a tile parked beside the ring while the next one is multiplied) serves every GEMM with >= 1.75 tiles per CU -- the
-    same digest with engine option "persistent_gemm" = 0 (the per-tile kernels at every size)."""
+    same digest with engine option "persistent_gemm" = 1 (off by default: it does not pay inside the engine, profiles/r4_persistent_gemm.md)."""
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "opt:gemm_cores=1", "opt:gemm_cores=0", "opt:persistent_gemm=0",
-                        "opt:persistent_gemm=0 opt:gemm_cores=0"], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "opt:gemm_cores=1", "opt:gemm_cores=0", "opt:persistent_gemm=1",
+                        "opt:persistent_gemm=1 opt:gemm_cores=0"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert r.stdout.count("==") == 5 and "!=" not in r.stdout
 
