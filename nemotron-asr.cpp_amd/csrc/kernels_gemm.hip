@@ -750,6 +750,123 @@ __global__ __launch_bounds__(1024) void k_gemm_persist(GemmParams p, int n_group
     }
 }
 
+// ------------------------------------------------------------------------------------
+// 256-row tiles for GEMMs with more than one wave of them (round 4; M >= 1 792: 128+ streams x R = 13, buffered audio, TitaNet-L).
+// At 128 x 128 a 64-deep chunk moves 32 KiB for 2.1 MFLOP: at the MFMA rate the chip sustains that is ~19 TB/s of operand traffic out
+// of L2 / MALL / HBM, and with weights that come from HBM (every GEMM of the engine: a layer's matrices are read once per step) the
+// loop waits for memory however its fills and epilogues are hidden (profiles/r4_persistent_gemm.md).  A 256 (m) x BN (n) tile moves
+// (256 + BN) / (2 BN) as many operand bytes per flop: 0.5 at BN = 256, 0.75 at BN = 128.
+//   8 waves = 2 halves of the rows x 4 quarters of the columns: 128 m x BN / 4 n per wave (BN = 256: 32 accumulators of 16 x 16);
+//   32-deep chunks (256 x 64 B activation panel + BN / 16 weight tiles of 1 KiB) by LDS-DMA into a 4-slot ring, three in flight;
+//   per chunk a wave reads BN / 64 weight and 8 activation fragments for 8 BN / 64 MFMAs (0.375 ds_read_b128 per MFMA at BN = 256);
+//   epilogue staged through the ring in four 64-row quarters, then the same per-row stores as the other kernels.
+// Same v_mfma_f32_16x16x32_bf16, k ascending from zero per accumulator: the bits of every other kernel of this file
+// (tests/micro/gemm_variant_identity.py, engine option "wide_tiles" = 0 / 1).
+// ------------------------------------------------------------------------------------
+constexpr int WD_BM = 256, WD_NS = 4;
+template <int BN> struct WideCfg {
+    static constexpr int SLOT = (WD_BM + BN) * 64;            // bytes per 32-deep chunk
+    static constexpr int NT = BN / 64;                        // weight fragments (16-row tiles) per wave and chunk
+    static constexpr int DMA = (16 + BN / 16) / 8;            // LDS-DMA instructions per wave and chunk: 16 for the panel, BN / 16 weight tiles
+    static constexpr int STG_LD = BN + 4;                     // floats per staged row
+    static constexpr size_t LDS = (size_t)WD_NS * SLOT > (size_t)64 * (BN + 4) * 4 ? (size_t)WD_NS * SLOT : (size_t)64 * (BN + 4) * 4;
+};
+template <int BN>
+__global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, int m_chunks) {
+    using C = WideCfg<BN>;
+    constexpr int P = WD_NS - 1, NT = C::NT, DMA = C::DMA;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int mc = id % m_chunks, ng = id / m_chunks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nq = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, m0 = mc * WD_BM;
+    // this wave's share of a chunk's DMA: instruction j = wave * DMA + u; j < 16: panel rows [16 j, 16 j + 16), else weight tile j - 16
+    const char *src[DMA];
+    unsigned dst[DMA];
+    int step[DMA];
+#pragma unroll
+    for (int u = 0; u < DMA; u++) {
+        const int j = wave * DMA + u;
+        if (j < 16) {
+            const int row = j * 16 + (lane >> 2);
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            src[u] = a_row_ptr(p, m, 2) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
+            dst[u] = (unsigned)(j * 1024);
+            step[u] = 64;
+        } else {
+            const int t = j - 16;
+            src[u] = (const char *)p.W + (size_t)(ng * (BN / 16) + t) * KT * 1024 + lane * 16;
+            dst[u] = (unsigned)(WD_BM * 64 + t * 1024);
+            step[u] = 1024;
+        }
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kt, int slot) {
+        const unsigned sb = ring_base + slot * C::SLOT;
+#pragma unroll
+        for (int u = 0; u < DMA; u++) glds16(src[u] + (size_t)kt * step[u], sb + dst[u]);
+    };
+    f32x4 acc[NT][8];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        if (i < KT) issue(i, i);
+    int slot = 0;
+    for (int i = 0; i < KT; i++) {
+        const int left = KT - 1 - i;                            // chunks allowed to stay in flight: min(left, P - 1)
+        if (left >= P - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA * (P - 1)) : "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
+        if (i + P < KT) issue(i + P, slot == 0 ? WD_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
+        const char *sp = ring + slot * C::SLOT;
+        uint4 wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) wf[j] = *(const uint4 *)(sp + WD_BM * 64 + (nq * NT + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) {
+            const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * 128 + mt * 16 + r, q));
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
+        }
+        slot = slot + 1 == WD_NS ? 0 : slot + 1;
+    }
+    // epilogue: four quarters of 64 rows through an f32 tile [64][BN + 4] in the ring
+    float *stage = (float *)ring;
+    for (int qr = 0; qr < 4; qr++) {
+        __syncthreads();                       // the ring (or the previous quarter) is no longer read
+        if (mh == (qr >> 1)) {
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int mt4 = 0; mt4 < 4; mt4++) {
+                    const f32x4 &a = acc[j][(qr & 1) * 4 + mt4];
+                    *(float4 *)(stage + (mt4 * 16 + r) * C::STG_LD + (nq * NT + j) * 16 + q * 4) = make_float4(a[0], a[1], a[2], a[3]);
+                }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * (BN / 4); e += 512) {
+            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4, m = m0 + qr * 64 + row, n0 = ng * BN + c4;
+            if (m >= p.M) continue;
+            const float4 v = *(const float4 *)(stage + row * C::STG_LD + c4);
+            if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
+            else if (p.epi == EPI_SILU_ACT) store_wt_u2((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0, pack4_bf16(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)));
+            else epi_quad<true>(p, 0, m, n0, v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
 static size_t gemm_lds_bytes(int ns) {     // the ring, or the f32 tile the epilogue parks in it, whichever is larger
     const size_t ring = (size_t)ns * G2_SLOT, stage = (size_t)TM * STG_LD * 4;
     return ring > stage ? ring : stage;
@@ -776,6 +893,8 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<128>::LDS);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
     hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
@@ -839,6 +958,19 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             else
                 hipLaunchKernelGGL(k_gemm_t64<4>, dim3(n_groups * m_chunks * p.splits), dim3(512), 4 * T64_SLOT, st, p, n_groups, m_chunks);
             return;
+        }
+        // more than one wave of tiles: 256-row tiles (half / three quarters of the operand bytes per flop), where they still fill the chip
+        if (!p.no_wide && p.splits == 1 && p.M >= 1792 && (p.K & 31) == 0 && (p.epi != EPI_QKV || p.T > 0)) {
+            const int mw = (p.M + WD_BM - 1) / WD_BM;
+            const long min_tiles = (long)g_num_cus * 7 / 8;
+            if (p.N % 256 == 0 && (long)(p.N / 256) * mw >= min_tiles) {
+                hipLaunchKernelGGL(k_gemm_wide<256>, dim3((p.N / 256) * mw), dim3(512), WideCfg<256>::LDS, st, p, p.N / 256, mw);
+                return;
+            }
+            if (p.N % 128 == 0 && (long)(p.N / 128) * mw >= min_tiles) {
+                hipLaunchKernelGGL(k_gemm_wide<128>, dim3((p.N / 128) * mw), dim3(512), WideCfg<128>::LDS, st, p, p.N / 128, mw);
+                return;
+            }
         }
         // several 128 x 128 tiles per CU: the persistent tile loop (one workgroup per CU; ring fills and epilogues off the critical path).
         // From 1.75 tiles per CU: below that a workgroup has no second tile to hide anything under.

@@ -4,7 +4,9 @@
 
 namespace nasr {
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1 / (1 + e^-x) on v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): a 128 x 128 SiLU epilogue is 32 of
+// these per thread (round 4: 1.3 us per tile in the persistent kernel's stamps).  1 + e^-x = inf gives 0, as the division did.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 __device__ __forceinline__ const char *a_row_ptr(const GemmParams &p, int m, int elt) {

@@ -121,6 +121,8 @@ struct GemmParams {
     // 1 = never the persistent tile loop (k_gemm_persist), whatever the size: engine option "persistent_gemm" = 0, the other side
     // of its bit-identity test
     int no_persist;
+    // 1 = never the 256-row tiles (k_gemm_wide): engine option "wide_tiles" = 0, the other side of their bit-identity test
+    int no_wide;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
