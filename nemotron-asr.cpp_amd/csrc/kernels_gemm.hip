@@ -894,7 +894,6 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256>::LDS);
-    hipFuncSetAttribute((const void *)k_gemm_wide<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<128>::LDS);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
     hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
@@ -959,16 +958,15 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 hipLaunchKernelGGL(k_gemm_t64<4>, dim3(n_groups * m_chunks * p.splits), dim3(512), 4 * T64_SLOT, st, p, n_groups, m_chunks);
             return;
         }
-        // more than one wave of tiles: 256-row tiles (half / three quarters of the operand bytes per flop), where they still fill the chip
-        if (!p.no_wide && p.splits == 1 && p.M >= 1792 && (p.K & 31) == 0 && (p.epi != EPI_QKV || p.T > 0)) {
+        // more than one wave of tiles: 256 x 256 tiles (half the operand bytes per flop) where their rounds fill the chip -- the last round at
+        // least 5 / 8 full, or three rounds and more (persist_probe, cold operands, us per launch against the per-tile pair: 7 168 rows W1 448
+        // tiles 78 / 83, pw1 224 tiles 38 / 45, QKV 336 tiles 69 / 70: a wash, left alone; 15 360 rows N = 1024 240 tiles 109 / 160).  The
+        // 256 x 128 form measured worse than the per-tile kernels with cold operands (W2 at 7 168 rows 92 / 77) and is not used.
+        if (!p.no_wide && p.splits == 1 && p.M >= 1792 && (p.K & 31) == 0 && p.N % 256 == 0) {
             const int mw = (p.M + WD_BM - 1) / WD_BM;
-            const long min_tiles = (long)g_num_cus * 7 / 8;
-            if (p.N % 256 == 0 && (long)(p.N / 256) * mw >= min_tiles) {
-                hipLaunchKernelGGL(k_gemm_wide<256>, dim3((p.N / 256) * mw), dim3(512), WideCfg<256>::LDS, st, p, p.N / 256, mw);
-                return;
-            }
-            if (p.N % 128 == 0 && (long)(p.N / 128) * mw >= min_tiles) {
-                hipLaunchKernelGGL(k_gemm_wide<128>, dim3((p.N / 128) * mw), dim3(512), WideCfg<128>::LDS, st, p, p.N / 128, mw);
+            const long tiles = (long)(p.N / 256) * mw, last = tiles % g_num_cus;
+            if (tiles >= (long)g_num_cus * 7 / 8 && (last == 0 || last * 8 >= (long)g_num_cus * 5 || tiles >= (long)g_num_cus * 3)) {
+                hipLaunchKernelGGL(k_gemm_wide<256>, dim3((unsigned)tiles), dim3(512), WideCfg<256>::LDS, st, p, p.N / 256, mw);
                 return;
             }
         }
