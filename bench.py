@@ -897,7 +897,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "streams_per_gpu": B, "right_context": R, "parallelism": f"stream-sharded x{world}, no collectives",
                        **({"rehearsal": f"all {world} ranks on device {args.share_device}, gloo barrier (one-GPU box)"} if args.share_device >= 0 else {}),
-                       "pcm": "device-resident", "checkpoint": "speech" if speech else "random", "pipeline": depth, "tokens_emitted": tokens_timed},
+                       "pcm": "device-resident", "checkpoint": "speech" if speech else "random", "pipeline": depth, "tokens_emitted": tokens_timed,
+                       "bracket": (f"primed: {prime} untimed steps fill the pipeline, K timed calls, no drain inside the region (idle-to-idle: cold_ms_per_step; "
+                                   f"one chunk at a time: synchronous_ms_per_step)") if prime else "idle-to-idle, synchronous steps"},
             "per_rank": per_rank,
             "configs": configs or None,
             "roofline": {k: roofline[k] for k in roof_keys if k in roofline} if roofline else None,

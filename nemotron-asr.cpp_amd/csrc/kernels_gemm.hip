@@ -755,7 +755,8 @@ __global__ __launch_bounds__(1024) void k_gemm_persist(GemmParams p, int n_group
 // At 128 x 128 a 64-deep chunk moves 32 KiB for 2.1 MFLOP: at the MFMA rate the chip sustains that is ~19 TB/s of operand traffic out
 // of L2 / MALL / HBM, and with weights that come from HBM (every GEMM of the engine: a layer's matrices are read once per step) the
 // loop waits for memory however its fills and epilogues are hidden (profiles/r4_persistent_gemm.md).  A 256 (m) x BN (n) tile moves
-// (256 + BN) / (2 BN) as many operand bytes per flop: 0.5 at BN = 256, 0.75 at BN = 128.
+// (256 + BN) / (2 BN) as many operand bytes per flop: 0.5 at BN = 256 (the form that ships; BN = 128, 0.75, measured worse than the
+// per-tile pair with cold operands and is not launched: profiles/r4_wide_tiles.md).
 //   8 waves = 2 halves of the rows x 4 quarters of the columns: 128 m x BN / 4 n per wave (BN = 256: 32 accumulators of 16 x 16);
 //   32-deep chunks (256 x 64 B activation panel + BN / 16 weight tiles of 1 KiB) by LDS-DMA into a 4-slot ring, three in flight;
 //   per chunk a wave reads BN / 64 weight and 8 activation fragments for 8 BN / 64 MFMAs (0.375 ds_read_b128 per MFMA at BN = 256);
