@@ -453,8 +453,9 @@ void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_f
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E] [--prewarm R[,R...]] [--cpu | --cuda]\n"
-                        "  --prewarm: capture the step graphs of every batch size 1..max-streams for these right_context values before listening (~20 ms each)\n"
+        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E] [--prewarm R[,R...] | --no-prewarm] [--cpu | --cuda]\n"
+                        "  --prewarm: capture the step graphs of every batch size 1..max-streams for these right_context values before listening (~20 ms each);\n"
+                        "             with --pipeline the default right_context is prewarmed unless --no-prewarm\n"
                         "  --tcp: default 127.0.0.1:8300 (the reference's port, src/nemo-server.cpp:411; the reference binds every interface when no host is given, this server binds loopback unless told otherwise: --tcp 0.0.0.0:8300)\n"
                         "  --pipeline E: consecutive engine calls overlap on the GPU (E = 0..4; 4 pieces on 4 hardware queues is the throughput optimum, 0 the lowest latency); a stream's text arrives\n"
                         "                E calls later while the FIFO is busy and at once when it runs empty\n"
@@ -465,6 +466,7 @@ int main(int argc, char **argv) {
     std::vector<int> devices{0};
     int dtype = 1, max_streams = 64;
     std::vector<int> prewarm_rc;
+    bool no_prewarm = false;
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--tcp" && i + 1 < argc) tcp = argv[++i];
@@ -487,6 +489,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "note: %s has no effect, this build runs on the MI355X engine (HIP)\n", a.c_str());
         }
         else if (a == "--pipeline" && i + 1 < argc) g_pipeline = atoi(argv[++i]);
+        else if (a == "--no-prewarm") no_prewarm = true;
         else if (a == "--prewarm" && i + 1 < argc) {
             for (const char *p = argv[++i]; *p;) {
                 prewarm_rc.push_back(atoi(p));
@@ -496,6 +499,7 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "Unknown flag: %s\n", a.c_str()); return 1; }
     }
+    if (prewarm_rc.empty() && !no_prewarm && g_pipeline > 0) prewarm_rc.push_back(g_default_rc);     // a throughput server: the default lookahead's shapes are ready when the socket opens
     for (int dev : devices) {
         std::unique_ptr<Lane> ln(new Lane());
         ln->model = nemo_init_with_device(argv[1], dev, dtype, max_streams);

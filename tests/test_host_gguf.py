@@ -227,7 +227,7 @@ def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
     assert srv.exists(), "run __graft_entry__.build()"
     path = str(tmp_path / "asr.sock")
     # two lanes (engine + FIFO + worker each) on the one GPU of the test box: stream s is served by lane s mod 2
-    proc = subprocess.Popen([str(srv), str(model), "--unix", path] + ([dtype_flag] if dtype_flag else []) + ["--max-streams", "8", "--devices", "0,0"]
+    proc = subprocess.Popen([str(srv), str(model), "--unix", path] + ([dtype_flag] if dtype_flag else []) + ["--max-streams", "8", "--devices", "0,0", "--cuda"]      # --cuda / --cpu: the reference's backend flags (src/nemo-server.cpp:405-406), accepted and ignored
                             + (["--pipeline", str(pipeline)] if pipeline else []), stderr=subprocess.PIPE, text=True)
     try:
         for _ in range(600):
@@ -285,6 +285,9 @@ def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
         _send(conns[1], 0x7E, 0)
         op, _, payload = _recv(conns[1])
         assert op == 0x8F and b"opcode" in payload
+        _send(conns[1], 0x01, 0, b'{"right_context": 5}')            # not one of the reference's latency modes (src/nemo-stream.h:15-20)
+        op, _, payload = _recv(conns[1])
+        assert op == 0x8F and b"right_context" in payload
         _send(conns[1], 0x01, 0, b"{}")
         op, sid, _ = _recv(conns[1])
         assert op == 0x81
@@ -303,7 +306,8 @@ def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
             proc.wait(timeout=20)
         except subprocess.TimeoutExpired:
             proc.kill()
-    assert "streams per call" in proc.stderr.read()
+    err = proc.stderr.read()
+    assert "streams per call" in err and "engine counters" in err and "--cuda has no effect" in err
 
 
 @pytest.mark.gpu
