@@ -698,7 +698,7 @@ def main():
         diar = diarization_entry(run, min(args.steps, 50))
 
     # ---- CPU baseline: the oracle (a port of the reference's algorithm), bounded sample; token agreement -------------
-    cpu, agreement, cpu_ref, f32_entry = None, None, None, None
+    cpu, agreement, cpu_ref, f32_entry, random_ckpt = None, None, None, None, None
     headline_is_default = (B, R, args.dtype, args.layers, args.chunks_per_step, args.weights) == (1, 0, "bf16", 24, 1, "f32")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
@@ -767,6 +767,17 @@ def main():
             f64.drain()
             e64 = summarize(f6, n_f, f64.audio_per_step, world)
             e64.pop("runs_ms_per_step")
+            # the headline shape on the near-tie checkpoint too (round-3 advisor: `value` moved to the speech checkpoint in round 3; same
+            # shapes and kernels, another token density): a stable key for cross-round comparisons
+            rrun = Run(capi, synth, Wr, args.layers, dtype, B, R, local_rank, run_ids, 1, pipeline=depth, audio_s=20.0, speech=False)
+            for _ in range(max(args.warmup, 6)):
+                rrun.step()
+            rrun.drain()
+            rr = timed_regions(rrun, args.steps, barrier_for(rrun), max_over_ranks, repeats=3, prime=prime)
+            rrun.drain()
+            random_ckpt = summarize(rr, args.steps, rrun.audio_per_step, world)
+            random_ckpt.pop("runs_ms_per_step")
+            rrun.close()
             omr = ob.OracleModel(Wr, args.layers)
             n_cmp = 3                                   # pushes compared per stream (the first completes no chunk)
             eq, n_tok = True, 0
@@ -907,6 +918,7 @@ def main():
             "f32_engine": f32_entry,
             "token_agreement": agreement,
             "cold_ms_per_step": cold["ms_per_step"],
+            "random_checkpoint": random_ckpt,
             "synchronous_ms_per_step": round(1e3 * sync_step_s, 4) if sync_step_s else None,
             "host_pcm_ms_per_step": host_pcm["ms_per_step"] if host_pcm else None,
             "pipeline8_ms_per_step": grouped_ms,

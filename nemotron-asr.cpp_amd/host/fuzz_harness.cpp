@@ -75,7 +75,15 @@ static int run_frames(const char *path) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE...\n", argv[0]); return 2; }
+    if (argc >= 4 && !strcmp(argv[1], "chunks")) {      // chunks T S...: chunks complete after S samples, and the samples that complete them (host logic test)
+        const int T = atoi(argv[2]);
+        for (int i = 3; i < argc; i++) {
+            const long long S = atoll(argv[i]), k = nasr_proto::chunks_after(S, T);
+            printf("%lld %lld %lld\n", S, k, (long long)nasr_proto::samples_for_chunks(k, T));
+        }
+        return 0;
+    }
+    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE... | chunks T SAMPLES...\n", argv[0]); return 2; }
     int rc = 0;
     for (int i = 2; i < argc; i++) rc |= !strcmp(argv[1], "gguf") ? run_gguf(argv[i]) : run_frames(argv[i]);
     return rc;

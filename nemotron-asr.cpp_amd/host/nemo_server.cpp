@@ -107,7 +107,7 @@ void enqueue(Event &&ev) {
 // else runs eagerly, chunk by chunk, after draining the pipeline.  Round 3's worker handed the engine whatever had arrived --
 // ragged pushes, sessions one chunk apart -- and delivered a fifth of the engine's throughput (profiles/r3_server_load_64_streams.json).
 // Now a session is only ever handed WHOLE chunks: how many chunks a session has completed is a pure function of the samples it
-// has been given (256 zeros of left padding, 512-sample frames at hop 160, a chunk = 9 + 8 T mel frames, then 8 T per chunk:
+// has been given (256 zeros of left padding, 512-sample frames at hop 160, 9 zero frames of pre-encode cache, 8 T new frames per chunk:
 // reference src/preprocessor.cpp:220-221, :320-328, src/nemo-stream.h:65-81), so the former knows for every session how many
 // samples complete its next g chunks.  Per right_context, the sessions that hold at least one whole chunk form ONE call in which
 // each completes G = the smallest number available among them (capped by the engine's row budget); the rest of their audio waits
@@ -147,7 +147,7 @@ void prewarm(nemo_context *model, int right_context) {
         if (!s) break;
         sc.push_back(s);
     }
-    const size_t first = (size_t)160 * (size_t)(9 + 8 * T - 1) + 256, shift = (size_t)1280 * (size_t)T;
+    const size_t first = (size_t)nasr_proto::samples_for_chunks(1, T), shift = (size_t)1280 * (size_t)T;      // the first chunk, one more chunk
     const std::vector<int16_t> silence(first, 0);
     const auto t0 = std::chrono::steady_clock::now();
     for (int B = (int)sc.size(); B >= 1; B--) {          // the first call gives every session its first chunk, each later one another chunk to B of them
@@ -222,7 +222,7 @@ void worker_loop(Lane *lane) {
             if ((int)ids.size() * T > row_budget) { ids.resize((size_t)(row_budget / T)); more = true; }
             int G = INT32_MAX;
             for (uint32_t id : ids) G = std::min(G, sessions[id].whole_chunks_pending());
-            G = std::max(1, std::min(G, std::min(row_budget / ((int)ids.size() * T), 248 / T)));      // 248: a call's samples stay below the engine's MAX_PUSH (256 frames) with the first chunk's extra 9 mel frames
+            G = std::max(1, std::min(G, std::min(row_budget / ((int)ids.size() * T), 248 / T)));      // 248: a call's samples stay below the engine's MAX_PUSH (256 encoder frames)
             while (G & (G - 1)) G &= G - 1;       // a power of two: every (streams, chunks) pair is a step shape with graphs of its own (~20 ms to capture); a backlog is worked off in 8 + 4 + 2 + 1 rather than in 13 different sizes
             std::vector<size_t> n(ids.size());
             for (size_t b = 0; b < ids.size(); b++) {

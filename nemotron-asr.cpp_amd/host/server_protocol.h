@@ -46,14 +46,16 @@ inline bool json_int(const std::string &j, const char *key, int &out) {
 }
 
 
-// ---- chunk arithmetic (reference src/preprocessor.cpp:220-221, :320-328, src/nemo-stream.h:65-81): 256 zeros of left padding, 512-sample
-// frames at hop 160, the first chunk = 9 + 8 T mel frames, then 8 T per chunk (T = 1 + right_context) -------------------------------
+// ---- chunk arithmetic (reference src/preprocessor.cpp:220-221, :320-328, src/nemo-stream.h:65-81, src/nemo-stream.cpp:73-74): the audio
+// buffer starts with 256 zeros of left padding, frames are 512 samples at hop 160, the mel buffer starts with the 9 literal-zero frames
+// of the pre-encode cache, a chunk takes 9 + 8 T mel frames and advances by 8 T (T = 1 + right_context) -- so chunk k is complete once
+// 8 T k frames exist.  Checked against the oracle's stream manager in tests/test_sanitizers.py. -------------------------------------
 // samples that must have been handed for k chunks to be complete
-inline int64_t samples_for_chunks(int64_t k, int T) { return k <= 0 ? 0 : 160 * ((int64_t)(9 + 8 * T) + (k - 1) * 8 * T - 1) + 256; }
+inline int64_t samples_for_chunks(int64_t k, int T) { return k <= 0 ? 0 : 160 * (k * 8 * T - 1) + 256; }
 // chunks complete once `samples` have been handed
 inline int64_t chunks_after(int64_t samples, int T) {
-    const int64_t frames = samples + 256 < 512 ? 0 : (samples + 256 - 512) / 160 + 1, first = 9 + 8 * T;
-    return frames < first ? 0 : (frames - first) / (8 * T) + 1;
+    const int64_t frames = samples + 256 < 512 ? 0 : (samples + 256 - 512) / 160 + 1;
+    return frames / (8 * T);
 }
 
 }  // namespace nasr_proto

@@ -180,3 +180,30 @@ print("TOKENS " + json.dumps(dict(tokens=toks, vad=round(p, 5))))
     assert abs(a["vad"] - b["vad"]) < 1e-4
     for ta, tb in zip(a["tokens"], b["tokens"]):
         assert len(ta) > 3 and abs(len(ta) - len(tb)) <= 3 and ta[:3] == tb[:3], (ta, tb)
+
+
+def test_batch_former_chunk_arithmetic_equals_the_oracles_stream_manager(harness):
+    """The server hands a session whole chunks only, computed from the samples it has been handed (host/server_protocol.h:
+    chunks_after / samples_for_chunks).  That arithmetic against the oracle's stream manager (reference src/nemo-stream.cpp:1145-1206:
+    chunks processed after n samples), every lookahead, ragged cumulative sample counts incl. the exact boundaries."""
+    from oracle import binding as ob
+    W = synth.make_weights(n_layers=1)
+    om = ob.OracleModel(W, 1)
+    rng = np.random.default_rng(2)
+    for R in (0, 1, 6, 13):
+        T = 1 + R
+        cuts = sorted(set([0, 1, 255, 256, 257, 1279, 1280] + [int(x) for x in rng.integers(0, 90000, 40)]
+                          + [160 * (9 + 8 * T + k * 8 * T - 1) + 256 + d for k in range(4) for d in (-1, 0, 1)]))
+        cuts = [c for c in cuts if c >= 0]
+        pcm = synth.make_pcm(3, cuts[-1] / 16000.0 + 0.1)
+        ost, prev, want = ob.OracleStream(om, R), 0, []
+        for c in cuts:
+            ost.process(pcm[prev:c])
+            prev = c
+            want.append(ost.total_chunks)
+        r = subprocess.run([str(harness), "chunks", str(T)] + [str(c) for c in cuts], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV), timeout=60)
+        assert r.returncode == 0, r.stderr[-500:]
+        rows = [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()]
+        assert [k for _, k, _ in rows] == want, (R, list(zip(cuts, want, [k for _, k, _ in rows]))[:8])
+        for S, k, need in rows:
+            assert need <= S and (k == 0 or need > 0)
