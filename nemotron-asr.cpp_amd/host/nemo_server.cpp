@@ -342,7 +342,9 @@ void worker_loop(Lane *lane) {
         // the forming window: the first whole chunk is in; wait for the sessions that push on the same clock (with a backlog too: a
         // call that leaves out the sessions whose next frame is a few hundred microseconds away is another, smaller step shape)
         if (any_ready() && !all_ready()) {
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(kFormingWindowUs);
+            // under a backlog the GPU still has the previous calls to work off (--pipeline keeps four in flight): waiting longer for the
+            // sessions whose next frames are on the wire costs nothing and keeps the calls at the full batch size (one step shape)
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(backlog ? 5 * kFormingWindowUs : kFormingWindowUs);
             for (;;) {
                 std::deque<Event> more;
                 {
@@ -505,8 +507,9 @@ int main(int argc, char **argv) {
         ln->model = nemo_init_with_device(argv[1], dev, dtype, max_streams);
         if (!ln->model) { fprintf(stderr, "Failed to load ASR model on device %d\n", dev); return 1; }
         if (g_pipeline > 0 && !nemo_set_pipeline(ln->model, g_pipeline)) return 1;
-        // one step shape per batch size and right_context in use, plus the multi-chunk shapes of a backlog: none is evicted in steady state
-        if (nasr_engine_set_option(ln->model->engine, "graph_cache", std::max(16, (max_streams + 8) * std::max(1, (int)prewarm_rc.size()))) < 0) return 1;
+        // one step shape per batch size and right_context in use, and as many again for the multi-chunk shapes of a backlog (chunk counts are
+        // powers of two): none is evicted in steady state
+        if (nasr_engine_set_option(ln->model->engine, "graph_cache", std::max(16, 2 * (max_streams + 8) * std::max(1, (int)prewarm_rc.size()))) < 0) return 1;
         for (int rc : prewarm_rc) prewarm(ln->model, rc);
         g_lanes.push_back(std::move(ln));
     }

@@ -275,7 +275,7 @@ def main():
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--workdir", default="/tmp/nasr_load")
     ap.add_argument("--client", default="native", choices=["native", "python"])
-    ap.add_argument("--prewarm", action="store_true", help="start the server with --prewarm <right-context>")
+    ap.add_argument("--no-prewarm", action="store_true", help="start the server with --no-prewarm (default: --prewarm <right-context>)")
     ap.add_argument("--warmup-seconds", type=float, default=0.0,
                     help="a first load of this many seconds per stream on the same server (graph captures, lane picking), not reported")
     ap.add_argument("--conns", type=int, default=8)
@@ -286,7 +286,7 @@ def main():
     if not model.exists():
         write_model(model, args.layers)
     sock_path = str(wd / f"asr-{int(time.time() * 1000) % 100000}.sock")
-    proc = start_server(model, sock_path, args.streams, args.pipeline, extra=("--prewarm", str(args.right_context)) if args.prewarm else ())
+    proc = start_server(model, sock_path, args.streams, args.pipeline, extra=("--no-prewarm",) if args.no_prewarm else ("--prewarm", str(args.right_context)))
     try:
         if args.warmup_seconds > 0:
             run_load(sock_path, args.streams, args.warmup_seconds, args.right_context, args.mode, n_conns=args.conns, client=args.client, workdir=args.workdir)

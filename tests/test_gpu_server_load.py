@@ -21,7 +21,7 @@ def test_server_under_load_16_streams(tmp_path):
     reports = {}
     for mode, seconds, R in (("realtime", 8.0, 0), ("burst", 12.0, 13)):
         sock = str(tmp_path / f"asr-{mode}.sock")
-        proc = sl.start_server(model, sock, 16, 4)
+        proc = sl.start_server(model, sock, 16, 4, extra=("--prewarm", str(R)))
         try:
             rep = sl.run_load(sock, 16, seconds, R, mode, n_conns=4, client="native" if mode == "burst" else "python", workdir=str(tmp_path))
         finally:
