@@ -76,8 +76,8 @@ def expected_text(events):
 
 
 class StreamState:
-    def __init__(self, idx, R, seconds):
-        self.idx, self.R = idx, R
+    def __init__(self, idx, R, seconds, delay=0.0):
+        self.idx, self.R, self.delay = idx, R, delay
         self.pcm, self.events = synth.make_speech_pcm(idx, seconds)
         self.n_push = synth.shift_samples(R)
         self.sid = None
@@ -99,7 +99,7 @@ def _exchange_python(streams, sock_path, R, mode, n_conns, timeout):
     by_sid = {}
     for c, sock in enumerate(conns):
         for st in by_conn[c]:
-            send_frame(sock, OP_START, 0, json.dumps({"lang": "auto", "right_context": R}).encode())
+            send_frame(sock, OP_START, 0, json.dumps({"lang": "auto", "right_context": st.R}).encode())
             op, sid, payload = recv_frame(sock)
             assert op == OP_STARTED, (hex(op), payload)
             st.sid = sid
@@ -128,23 +128,31 @@ def _exchange_python(streams, sock_path, R, mode, n_conns, timeout):
             errors.append((c, "receiver", repr(ex)))
 
     def sender(c, t_start):
+        # every stream of the connection on its own clock: first push at t_start + delay, then one push per n_push samples of real time
+        # (realtime) or as fast as the socket takes them (burst); STREAM_END right behind a stream's last push
         sock, mine = conns[c], by_conn[c]
-        n_total = max(st.pcm.size for st in mine)
-        period = mine[0].n_push / synth.SAMPLE_RATE
-        k = 0
-        while k * mine[0].n_push < n_total:
+        nxt = {st.idx: 0 for st in mine}
+        live = list(mine)
+        while live:
             if mode == "realtime":
-                delay = t_start + k * period - time.perf_counter()
-                if delay > 0:
-                    time.sleep(delay)
-            for st in mine:
+                due = lambda st: t_start + st.delay + nxt[st.idx] * st.n_push / synth.SAMPLE_RATE
+                st = min(live, key=due)
+                d = due(st) - time.perf_counter()
+                if d > 0:
+                    time.sleep(d)
+                batch = [st]
+            else:
+                batch = list(live)
+            for st in batch:
+                k = nxt[st.idx]
                 piece = st.pcm[k * st.n_push:(k + 1) * st.n_push]
                 if piece.size:
                     st.send_times.append(time.perf_counter())
                     send_frame(sock, OP_PUSH, st.sid, piece.tobytes())
-            k += 1
-        for st in mine:
-            send_frame(sock, OP_END, st.sid)
+                nxt[st.idx] = k + 1
+                if (k + 1) * st.n_push >= st.pcm.size:
+                    send_frame(sock, OP_END, st.sid)
+                    live.remove(st)
 
     rx = [threading.Thread(target=receiver, args=(c,)) for c in range(len(conns))]
     for t in rx:
@@ -185,8 +193,10 @@ def _exchange_native(streams, sock_path, R, mode, n_conns, timeout, workdir):
     return rep["wall_seconds"], errors
 
 
-def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0, client="python", workdir="/tmp/nasr_load"):
-    streams = [StreamState(i, R, seconds) for i in range(n_streams)]
+def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0, client="python", workdir="/tmp/nasr_load", streams=None):
+    """streams: a prepared list of StreamState (own lookahead, length and start delay per stream: Python client only); default: n_streams alike"""
+    streams = streams if streams is not None else [StreamState(i, R, seconds) for i in range(n_streams)]
+    n_streams = len(streams)
     if client == "native":
         wall, errors = _exchange_native(streams, sock_path, R, mode, n_conns, timeout, workdir)
     else:
@@ -194,8 +204,8 @@ def run_load(sock_path, n_streams, seconds, R, mode, n_conns=8, timeout=300.0, c
     # per-token latency: token k of a stream is emitted at the first frame wholly inside its phone; the chunk holding that
     # frame is complete once sample (chunk + 1) x 1280 T (+ the STFT's 400-sample reach) has been pushed
     lat, correct = [], 0
-    T = 1 + R
     for st in streams:
+        T = 1 + st.R
         want, ends = expected_text(st.events)
         correct += st.text == want
         if st.text != want:

@@ -53,3 +53,22 @@ def test_server_under_load_16_streams(tmp_path):
         ref = ost.process(pcm) + ost.finalize()
         text = "".join((" " + vocab[t][1:]) if vocab[t].startswith("▁") else vocab[t] for t in ref)
         assert text == sl.expected_text(ev)[0]
+
+
+def test_server_with_mixed_lookaheads_and_sessions_that_come_and_go(tmp_path):
+    """The batch former under what a real population does: 12 live streams with lookahead 0, 1 and 13 mixed on 3 connections, starting 0 ... 2.2 s
+    apart and 3 ... 7 s long, so that sessions join and leave while others are mid-stream and every call groups whoever holds a whole chunk
+    of its lookahead.  Only the default lookahead is prewarmed (the other shapes are captured on the way).  Every transcript == the phone
+    sequence of its audio; nothing runs eagerly but stream ends."""
+    model = sl.write_model(tmp_path / "speech-q8_0.gguf", 24, "q8_0")
+    sock = str(tmp_path / "asr-mixed.sock")
+    streams = [sl.StreamState(40 + i, (0, 13, 1, 0, 13, 0)[i % 6], 3.0 + (i * 0.37) % 4.0, delay=0.2 * i) for i in range(12)]
+    proc = sl.start_server(model, sock, 16, 4)
+    try:
+        rep = sl.run_load(sock, 12, 0.0, 0, "realtime", n_conns=3, client="python", streams=streams)
+    finally:
+        srv, err = sl.stop_server(proc)
+    assert not rep["errors"], rep
+    assert rep["transcripts_correct"] == 12, (rep, [(st.R, st.text[:40]) for st in streams])
+    assert srv["eager_outside_stream_end"] <= 2, srv
+    assert rep["token_latency_ms"]["p99"] < 400.0, rep          # shapes are captured on the way: a first call of a new batch size costs ~20 ms
