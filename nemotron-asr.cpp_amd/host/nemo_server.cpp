@@ -12,6 +12,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <sys/un.h>
 #include <unistd.h>
 
@@ -172,20 +173,23 @@ void worker_loop(Lane *lane) {
     const int row_budget = std::max(model->max_streams * 14, 256);      // rows one launch sequence may carry (csrc/nasr_engine.hip: w_rows, nasr_engine_create)
     auto drain = [&]() {                         // complete the steps in flight and send their text (FIFO empty, END, LANG)
         if (in_flight.empty()) return;
-        std::vector<uint32_t> ids;
-        std::vector<nemo_stream_context *> sc;
+        std::map<int, std::vector<uint32_t>> by_T;         // one collect per right_context: an engine call takes streams of one lookahead
         for (uint32_t id : in_flight) {
             auto it = sessions.find(id);
-            if (it != sessions.end()) { ids.push_back(id); sc.push_back(it->second.sctx); }
+            if (it != sessions.end()) by_T[it->second.T].push_back(id);
         }
         in_flight.clear();
-        if (sc.empty()) return;
-        std::vector<std::string> out(sc.size());
-        const bool ok = nemo_stream_collect_batch(sc.data(), (int)sc.size(), out.data());
-        for (size_t b = 0; b < sc.size(); b++) {
-            Session &s = sessions[ids[b]];
-            if (!ok) s.conn->send_str(OP_ERROR, ids[b], "engine collect failed");
-            else if (!out[b].empty()) s.conn->send_str(OP_TEXT, ids[b], out[b]);
+        for (auto &g : by_T) {
+            const std::vector<uint32_t> &ids = g.second;
+            std::vector<nemo_stream_context *> sc;
+            for (uint32_t id : ids) sc.push_back(sessions[id].sctx);
+            std::vector<std::string> out(sc.size());
+            const bool ok = nemo_stream_collect_batch(sc.data(), (int)sc.size(), out.data());
+            for (size_t b = 0; b < sc.size(); b++) {
+                Session &s = sessions[ids[b]];
+                if (!ok) s.conn->send_str(OP_ERROR, ids[b], "engine collect failed");
+                else if (!out[b].empty()) s.conn->send_str(OP_TEXT, ids[b], out[b]);
+            }
         }
     };
     // one engine call: session ids[b] is handed n[b] samples of its pending audio
@@ -301,21 +305,26 @@ void worker_loop(Lane *lane) {
             for (uint32_t id : ids) again = again || sessions[id].whole_chunks_pending() > 0;
             if (again) form_calls();
         }
-        std::vector<uint32_t> tail_ids;
-        std::vector<size_t> tail_n;
-        for (uint32_t id : ids) if (sessions[id].avail() > 0) { tail_ids.push_back(id); tail_n.push_back(sessions[id].avail()); }
-        if (!tail_ids.empty()) { n_partial++; call(tail_ids, tail_n); }
-        std::vector<nemo_stream_context *> sc;
-        for (uint32_t id : ids) { sc.push_back(sessions[id].sctx); in_flight.erase(id); }      // finalize completes the steps in flight itself
-        std::vector<std::string> out(ids.size());
-        const bool ok = nemo_stream_finalize_batch(sc.data(), (int)sc.size(), out.data());
-        n_finalize++;
-        for (size_t b = 0; b < ids.size(); b++) {
-            Session &s = sessions[ids[b]];
-            if (!ok) s.conn->send_str(OP_ERROR, ids[b], "engine finalize failed");
-            s.conn->send_str(OP_ENDED, ids[b], out[b]);
-            nemo_stream_free(s.sctx);
-            sessions.erase(ids[b]);
+        std::map<int, std::vector<uint32_t>> by_T;         // the tail calls per right_context
+        for (uint32_t id : ids) by_T[sessions[id].T].push_back(id);
+        for (auto &g : by_T) {
+            const std::vector<uint32_t> &gi = g.second;
+            std::vector<uint32_t> tail_ids;
+            std::vector<size_t> tail_n;
+            for (uint32_t id : gi) if (sessions[id].avail() > 0) { tail_ids.push_back(id); tail_n.push_back(sessions[id].avail()); }
+            if (!tail_ids.empty()) { n_partial++; call(tail_ids, tail_n); }
+            std::vector<nemo_stream_context *> sc;
+            for (uint32_t id : gi) { sc.push_back(sessions[id].sctx); in_flight.erase(id); }      // finalize completes the steps in flight itself
+            std::vector<std::string> out(gi.size());
+            const bool ok = nemo_stream_finalize_batch(sc.data(), (int)sc.size(), out.data());
+            n_finalize++;
+            for (size_t b = 0; b < gi.size(); b++) {
+                Session &s = sessions[gi[b]];
+                if (!ok) s.conn->send_str(OP_ERROR, gi[b], "engine finalize failed");
+                s.conn->send_str(OP_ENDED, gi[b], out[b]);
+                nemo_stream_free(s.sctx);
+                sessions.erase(gi[b]);
+            }
         }
     };
     auto take = [&](std::deque<Event> &batch) {          // everything that is queued, without waiting
@@ -546,6 +555,10 @@ int main(int argc, char **argv) {
         if (cfd < 0) { if (g_stop) break; continue; }
         int one = 1;
         setsockopt(cfd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        // replies are sent from the worker thread: a client that stops reading must not stall every other session behind a full socket
+        // buffer -- after 5 s without progress the send fails and the connection is marked closed (its sessions end with the reader)
+        timeval snd{5, 0};
+        setsockopt(cfd, SOL_SOCKET, SO_SNDTIMEO, &snd, sizeof(snd));
         std::thread(reader_loop, cfd).detach();
     }
     g_stop = true;
