@@ -311,6 +311,93 @@ def test_server_batches_streams(tmp_path, dtype_flag, pipeline):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [0, 4])
+def test_server_language_switch_mid_stream_on_a_multilingual_model(tmp_path, pipeline):
+    """SET_LANG through the socket (reference src/nemo-server.cpp: the audio queued before the switch uses the old language).  A multilingual GGUF
+    (4 prompts), f32 engine, two streams started with different languages; stream 0 switches twice mid-stream at sample positions that fall INSIDE a
+    chunk (the batch former hands over the sub-chunk remainder before the switch), stream 1 never.  Text == the oracle driven the same way
+    (process what was sent, set_prompt, go on); LANG_SET frames carry the prompt index; both with synchronous and pipelined engine calls."""
+    import socket
+    import time
+    from oracle import binding as ob
+    n_layers, P, R = 2, 4, 1
+    W = synth.make_weights(n_layers=n_layers, num_prompts=P)
+    vocab = gguf_io.synthetic_vocab()
+    langs = {"en": 0, "de": 1, "fr": 2, "auto": 3}
+    model = tmp_path / "multi.gguf"
+    gguf_io.write_gguf(model, W, gguf_io.default_hparams(n_layers=n_layers, num_prompts=P), vocab, prompt_dict=langs)
+    path = str(tmp_path / "asr.sock")
+    proc = subprocess.Popen([str(BIN / "nemo-server-amd"), str(model), "--unix", path, "--f32", "--max-streams", "4", "--right-context", str(R)]
+                            + (["--pipeline", str(pipeline)] if pipeline else []), stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(600):
+            if Path(path).exists() or proc.poll() is not None:
+                break
+            time.sleep(0.1)
+        assert proc.poll() is None, proc.stderr.read()
+        c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        c.settimeout(60)
+        c.connect(path)
+        start = ["en", "de"]
+        ids, text, lang_set = [], {}, []
+        for lg in start:
+            _send(c, 0x01, 0, json.dumps({"lang": lg}).encode())
+            op, sid, _ = _recv(c)
+            assert op == 0x81
+            ids.append(sid)
+            text[sid] = ""
+        pcms = [synth.make_pcm(90 + b, 5.0) for b in range(2)]
+        piece, off = 3000, [0, 0]                       # 3 000-sample pushes: not a multiple of the 2 560-sample chunk shift
+        switches = {7: "fr", 15: "en"}                  # before push k of stream 0
+        plan = []                                       # what stream 0 saw: (samples before the switch, language)
+        k = 0
+        while any(off[b] < pcms[b].size for b in range(2)):
+            if k in switches:
+                _send(c, 0x04, ids[0], switches[k].encode())
+                plan.append((off[0], switches[k]))
+            for b in range(2):
+                if off[b] < pcms[b].size:
+                    _send(c, 0x02, ids[b], pcms[b][off[b]:off[b] + piece].tobytes())
+                    off[b] += piece
+            k += 1
+        for b in range(2):
+            _send(c, 0x03, ids[b])
+        ended = set()
+        while len(ended) < 2:
+            op, sid, payload = _recv(c)
+            assert op in (0x82, 0x83, 0x84, 0x85), (hex(op), payload)
+            if op == 0x85:
+                lang_set.append(json.loads(payload))
+            elif op in (0x83, 0x84):
+                text[sid] += payload.decode()
+                if op == 0x84:
+                    ended.add(sid)
+        c.close()
+        assert [(m["id"], m["lang"], m["index"]) for m in lang_set] == [(ids[0], "fr", 2), (ids[0], "en", 0)]
+        om = ob.OracleModel(W, n_layers, num_prompts=P)
+        for b in range(2):
+            ost = ob.OracleStream(om, R, langs[start[b]])
+            ref, prev = [], 0
+            for cut, lg in (plan if b == 0 else []):
+                ref += ost.process(pcms[b][prev:cut])
+                ost.set_prompt(langs[lg])
+                prev = cut
+            ref += ost.process(pcms[b][prev:]) + ost.finalize()
+            want = "".join((" " + vocab[t][1:]) if vocab[t].startswith("\u2581") else vocab[t] for t in ref)
+            assert len(ref) > 3 and text[ids[b]] == want, (b, text[ids[b]][:80], want[:80])
+    except BaseException:
+        proc.terminate()
+        print("server stderr:\n" + proc.stderr.read())
+        raise
+    finally:
+        proc.terminate()
+        try:
+            proc.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+
+
+@pytest.mark.gpu
 def test_diarize_cli_end_to_end(tmp_path):
     """diarize.gguf ("vad.*" + "spk.*", layouts of scripts/convert_diarize_to_gguf.py) -> C++ loader -> side-car engine:
     window probabilities through the onset/offset rule, sub-segment embeddings == the oracle's."""
