@@ -207,7 +207,8 @@ enum {
  * call to call (reference: one stream per call, src/nemo-server.cpp:192-271) holds a bounded number of graph execs.
  * Kernel-selection switches for A/B runs and bit-identity tests (round 4: these were environment variables read inside the product path;
  * set them before the first step, results never depend on them): "gemm_cores" (-1 = the engine's rule, 0 / 1 = never / always the
- * large-M GEMM kernels of which two share a CU), "persistent_gemm" (1: GEMMs with several 128 x 128 tiles per CU on the persistent tile loop; default 0), "f32_mfma" (0: f32 GEMMs above
+ * large-M GEMM kernels of which two share a CU), "persistent_gemm" (1: GEMMs with several 128 x 128 tiles per CU on the persistent tile loop; default 0),
+ * "wide_tiles" (default 1: 256- / 224-row tiles from 1 792 rows where their rounds fill the chip; 256: the 256-row form only; 0: off), "f32_mfma" (0: f32 GEMMs above
  * four rows on the FMA tile kernel instead of the f32 MFMA), "decode_graph_iterations" (>= 1, default 12: decode iterations a
  * pipelined step's decode graph carries before the eager fallback), "decode_lane" (0: the decode graphs run behind the last encoder
  * piece instead of on a stream of their own). */

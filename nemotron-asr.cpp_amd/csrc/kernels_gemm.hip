@@ -764,18 +764,24 @@ __global__ __launch_bounds__(1024) void k_gemm_persist(GemmParams p, int n_group
 // Same v_mfma_f32_16x16x32_bf16, k ascending from zero per accumulator: the bits of every other kernel of this file
 // (tests/micro/gemm_variant_identity.py, engine option "wide_tiles" = 0 / 1).
 // ------------------------------------------------------------------------------------
-constexpr int WD_BM = 256, WD_NS = 4;
-template <int BN> struct WideCfg {
-    static constexpr int SLOT = (WD_BM + BN) * 64;            // bytes per 32-deep chunk
+constexpr int WD_NS = 4;
+// MT = 16-row m-tiles per wave: the tile has BM = 32 MT rows.  MT = 8 (256 rows) and MT = 7 (224 rows = 16 streams x R = 13: 7 168 rows
+// are 32 of them, so that N = 4096 gives 512 tiles = two FULL rounds of the chip where 256-row tiles give 1.75, and N = 2048 one
+// round of 256 smaller tiles instead of 224 larger ones) -- launch_gemm_bf16 takes the one whose rounds x rows is smaller.
+template <int BN, int MT> struct WideCfg {
+    static constexpr int BM = 32 * MT;
+    static constexpr int SLOT = (BM + BN) * 64;               // bytes per 32-deep chunk
     static constexpr int NT = BN / 64;                        // weight fragments (16-row tiles) per wave and chunk
-    static constexpr int DMA = (16 + BN / 16) / 8;            // LDS-DMA instructions per wave and chunk: 16 for the panel, BN / 16 weight tiles
+    static constexpr int NP = BM / 16;                        // LDS-DMA pieces of the activation panel (16 rows x 64 B each)
+    static constexpr int PIECES = NP + BN / 16;               // + the weight tiles of 1 KiB
+    static constexpr int DMA = (PIECES + 7) / 8;              // LDS-DMA instructions per wave and chunk (a wave without a piece of its own repeats the last one)
     static constexpr int STG_LD = BN + 4;                     // floats per staged row
     static constexpr size_t LDS = (size_t)WD_NS * SLOT > (size_t)64 * (BN + 4) * 4 ? (size_t)WD_NS * SLOT : (size_t)64 * (BN + 4) * 4;
 };
-template <int BN>
+template <int BN, int MT>
 __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, int m_chunks) {
-    using C = WideCfg<BN>;
-    constexpr int P = WD_NS - 1, NT = C::NT, DMA = C::DMA;
+    using C = WideCfg<BN, MT>;
+    constexpr int P = WD_NS - 1, NT = C::NT, DMA = C::DMA, BM = C::BM;
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int nblk = gridDim.x;
     int id = blockIdx.x;
@@ -786,15 +792,16 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
     const int mc = id % m_chunks, ng = id / m_chunks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nq = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
-    const int KT = p.K >> 5, m0 = mc * WD_BM;
-    // this wave's share of a chunk's DMA: instruction j = wave * DMA + u; j < 16: panel rows [16 j, 16 j + 16), else weight tile j - 16
+    const int KT = p.K >> 5, m0 = mc * BM;
+    // this wave's share of a chunk's DMA: instruction j = wave * DMA + u; j < NP: panel rows [16 j, 16 j + 16), else weight tile j - NP
     const char *src[DMA];
     unsigned dst[DMA];
     int step[DMA];
 #pragma unroll
     for (int u = 0; u < DMA; u++) {
-        const int j = wave * DMA + u;
-        if (j < 16) {
+        int j = wave * DMA + u;
+        if (j >= C::PIECES) j = C::PIECES - 1;          // the same bytes to the same place a second time: keeps every wave's vmcnt arithmetic equal
+        if (j < C::NP) {
             const int row = j * 16 + (lane >> 2);
             int m = m0 + row;
             if (m >= p.M) m = p.M - 1;
@@ -802,9 +809,9 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
             dst[u] = (unsigned)(j * 1024);
             step[u] = 64;
         } else {
-            const int t = j - 16;
+            const int t = j - C::NP;
             src[u] = (const char *)p.W + (size_t)(ng * (BN / 16) + t) * KT * 1024 + lane * 16;
-            dst[u] = (unsigned)(WD_BM * 64 + t * 1024);
+            dst[u] = (unsigned)(BM * 64 + t * 1024);
             step[u] = 1024;
         }
     }
@@ -814,11 +821,11 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
 #pragma unroll
         for (int u = 0; u < DMA; u++) glds16(src[u] + (size_t)kt * step[u], sb + dst[u]);
     };
-    f32x4 acc[NT][8];
+    f32x4 acc[NT][MT];
 #pragma unroll
     for (int j = 0; j < NT; j++)
 #pragma unroll
-        for (int mt = 0; mt < 8; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < P; i++)
         if (i < KT) issue(i, i);
@@ -833,32 +840,36 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
         const char *sp = ring + slot * C::SLOT;
         uint4 wf[NT];
 #pragma unroll
-        for (int j = 0; j < NT; j++) wf[j] = *(const uint4 *)(sp + WD_BM * 64 + (nq * NT + j) * 1024 + lane * 16);
+        for (int j = 0; j < NT; j++) wf[j] = *(const uint4 *)(sp + BM * 64 + (nq * NT + j) * 1024 + lane * 16);
 #pragma unroll
-        for (int mt = 0; mt < 8; mt++) {
-            const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * 128 + mt * 16 + r, q));
+        for (int mt = 0; mt < MT; mt++) {
+            const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
             const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
 #pragma unroll
             for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
         }
         slot = slot + 1 == WD_NS ? 0 : slot + 1;
     }
-    // epilogue: four quarters of 64 rows through an f32 tile [64][BN + 4] in the ring
+    // epilogue: each half of the rows in two parts (64 rows, then the rest: 64 or 48) through an f32 tile [64][BN + 4] in the ring
     float *stage = (float *)ring;
+#pragma unroll
     for (int qr = 0; qr < 4; qr++) {
-        __syncthreads();                       // the ring (or the previous quarter) is no longer read
+        constexpr int HALF = BM / 2;
+        const int part = qr & 1, rows0 = (qr >> 1) * HALF + part * 64, nrows = part ? HALF - 64 : 64;
+        __syncthreads();                       // the ring (or the previous part) is no longer read
         if (mh == (qr >> 1)) {
 #pragma unroll
             for (int j = 0; j < NT; j++)
 #pragma unroll
                 for (int mt4 = 0; mt4 < 4; mt4++) {
-                    const f32x4 &a = acc[j][(qr & 1) * 4 + mt4];
+                    if (part * 4 + mt4 >= MT) continue;
+                    const f32x4 &a = acc[j][part * 4 + mt4];
                     *(float4 *)(stage + (mt4 * 16 + r) * C::STG_LD + (nq * NT + j) * 16 + q * 4) = make_float4(a[0], a[1], a[2], a[3]);
                 }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < 64 * (BN / 4); e += 512) {
-            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4, m = m0 + qr * 64 + row, n0 = ng * BN + c4;
+        for (int e = threadIdx.x; e < nrows * (BN / 4); e += 512) {
+            const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4, m = m0 + rows0 + row, n0 = ng * BN + c4;
             if (m >= p.M) continue;
             const float4 v = *(const float4 *)(stage + row * C::STG_LD + c4);
             if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
@@ -894,7 +905,8 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
-    hipFuncSetAttribute((const void *)k_gemm_wide<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 8>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
     hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
@@ -964,10 +976,27 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         // tiles 78 / 83, pw1 224 tiles 38 / 45, QKV 336 tiles 69 / 70: a wash, left alone; 15 360 rows N = 1024 240 tiles 109 / 160).  The
         // 256 x 128 form measured worse than the per-tile kernels with cold operands (W2 at 7 168 rows 92 / 77) and is not used.
         if (!p.no_wide && p.splits == 1 && p.M >= 1792 && (p.K & 31) == 0 && p.N % 256 == 0) {
-            const int mw = (p.M + WD_BM - 1) / WD_BM;
-            const long tiles = (long)(p.N / 256) * mw, last = tiles % g_num_cus;
-            if (tiles >= (long)g_num_cus * 7 / 8 && (last == 0 || last * 8 >= (long)g_num_cus * 5 || tiles >= (long)g_num_cus * 3)) {
-                hipLaunchKernelGGL(k_gemm_wide<256>, dim3((unsigned)tiles), dim3(512), WideCfg<256>::LDS, st, p, p.N / 256, mw);
+            // 256- or 224-row tiles: whichever needs fewer rounds x rows (7 168 rows: N = 4096 two full rounds of 224-row tiles instead of
+            // 1.75 of 256-row ones, N = 2048 one round of 256 smaller tiles; 15 360 rows stay at 256).  Cold operands, us per launch, 256 / 224 rows:
+            // W1 at 7 168 rows 78.8 / 74.9, pw1 38.4 / 35.4, W1 at 3 584 rows 43.8 / 41.0; synchronous steps 512 streams 18.08 -> 17.82 ms, 256
+            // streams 9.56 -> 9.42.  Pipelined steps LOSE 0.5-0.8 % (16.22 -> 16.35, 8.41 -> 8.45: the CUs a partial round leaves idle run
+            // another lane's kernels, full rounds leave none), so they keep the 256-row form (profiles/r4_wide_tiles.md).
+            int best_mt = 0;
+            long best_cost = 0, best_tiles = 0;
+            for (int mt = 8; mt >= (p.coresident == 1 ? 8 : 7); mt--) {
+                const int bm = 32 * mt, mw = (p.M + bm - 1) / bm;
+                const long tiles = (long)(p.N / 256) * mw, last = tiles % g_num_cus;
+                if (!(tiles >= (long)g_num_cus * 7 / 8 && (last == 0 || last * 8 >= (long)g_num_cus * 5 || tiles >= (long)g_num_cus * 3))) continue;
+                const long cost = (tiles + g_num_cus - 1) / g_num_cus * bm;
+                if (!best_mt || cost < best_cost) { best_mt = mt; best_cost = cost; best_tiles = tiles; }
+            }
+            if (p.wide_rows == 256 && best_mt) { best_mt = 8; best_tiles = (long)(p.N / 256) * ((p.M + 255) / 256); }      // engine option "wide_tiles" = 256: round 4's first form only
+            if (best_mt == 8) {
+                hipLaunchKernelGGL((k_gemm_wide<256, 8>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 8>::LDS), st, p, p.N / 256, (p.M + 255) / 256);
+                return;
+            }
+            if (best_mt == 7) {
+                hipLaunchKernelGGL((k_gemm_wide<256, 7>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 return;
             }
         }

@@ -123,6 +123,8 @@ struct GemmParams {
     int no_persist;
     // 1 = never the 256-row tiles (k_gemm_wide): engine option "wide_tiles" = 0, the other side of their bit-identity test
     int no_wide;
+    // 256 = of the wide tiles only the 256-row form (engine option "wide_tiles" = 256: A/B against the 224-row form); 0 = the launcher's rule
+    int wide_rows;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------

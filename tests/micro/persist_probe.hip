@@ -32,13 +32,13 @@ int main(int argc, char **argv) {
         {"spk N=3072 K=1024 bias+relu f32", 3072, 1024, EPI_BIAS_RELU_F32}, {"QKV-shaped N=3072 K=1024 f32", 3072, 1024, EPI_PART_F32}};
     for (int M : Ms)
         for (const Shape &s : shapes) {
-            double us[4];
-            for (int mode = 0; mode < 4; mode++) {          // 0: persistent allowed, 1: per-tile kernels (co-resident rule), 2: per-tile, deep rings forced, 3: 256-row tiles (k_gemm_wide) where the launcher takes them
+            double us[5];
+            for (int mode = 0; mode < 5; mode++) {          // 0: persistent allowed, 1: per-tile kernels (co-resident rule), 2: per-tile, deep rings forced, 3: wide tiles (k_gemm_wide: 256 or 224 rows, the launcher's rule), 4: wide tiles, 256 rows only
                 GemmParams g;
                 memset(&g, 0, sizeof(g));
                 g.A = A; g.W = W; g.M = M; g.N = s.N; g.K = s.K; g.lda = s.K; g.splits = 1; g.epi = s.epi;
                 g.out_f32 = outf; g.ldo = s.epi == EPI_GLU ? s.N / 2 : s.N; g.out_act = act; g.ldo_act = s.N; g.bias = bias;
-                g.no_persist = mode >= 1; g.coresident = mode == 2 ? 3 : 0; g.no_wide = mode != 3;
+                g.no_persist = mode >= 1; g.coresident = mode == 2 ? 3 : 0; g.no_wide = mode < 3; g.wide_rows = mode == 4 ? 256 : 0;
                 for (int i = 0; i < 3; i++) launch_gemm_bf16(g, st);
                 hipEvent_t a, b;
                 CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
@@ -55,8 +55,8 @@ int main(int argc, char **argv) {
                 us[mode] = 1e3 * ms / reps;
             }
             const double fl = 2.0 * M * s.N * s.K * 1e-6;
-            printf("%sM = %5d  %-34s persistent %7.2f us (%5.0f TFLOP/s) | per-tile, two per CU %7.2f us (%5.0f) | per-tile, deep rings %7.2f us (%5.0f) | 256-row tiles %7.2f us (%5.0f)\n", cold ? "[cold] " : "", M, s.name,
-                   us[0], fl / us[0], us[1], fl / us[1], us[2], fl / us[2], us[3], fl / us[3]);
+            printf("%sM = %5d  %-34s persistent %7.2f us (%5.0f TFLOP/s) | per-tile, two per CU %7.2f us (%5.0f) | per-tile, deep rings %7.2f us (%5.0f) | wide tiles %7.2f us (%5.0f) | wide, 256 rows only %7.2f us (%5.0f)\n", cold ? "[cold] " : "", M, s.name,
+                   us[0], fl / us[0], us[1], fl / us[1], us[2], fl / us[2], us[3], fl / us[3], us[4], fl / us[4]);
         }
     return 0;
 }
