@@ -123,6 +123,27 @@ __device__ __forceinline__ int panel_off(int row, int chunk) {  // byte offset i
 //  * the DMA is issued from inline asm (M0 = wave-uniform LDS base), so hipcc does not see a pending
 //    LDS write and does not drain vmcnt(0) in front of every ds_read; completion is counted by hand
 //    (8 DMA instructions per wave per chunk).
+
+// Which tile a workgroup computes.  ids are contiguous per XCD (the remap at the top of every kernel); split-K slices outermost.
+// Rounds 1-3 ran the row chunk fastest: an XCD then sweeps ALL activation panels once per column group -- 14.7 MB at 7 168 rows x
+// K = 1 024, 58 MB for W2, against 4 MB of L2 -- and every sweep comes from the Infinity Cache again (W2 at 7 168 rows: 470 MB per launch
+// in 77 us = 6 TB/s: the kernel ran at the Infinity Cache's rate, not the MFMA's).  Now: bands of w column groups with the column group
+// fastest; the ids of an XCD are a compact w x (tiles / 8 / w) block, and the tiles that run at a time share w weight panels and a few
+// activation panels.  Cold operands, us per launch at 7 168 rows, rows-fastest -> bands: W2 77.8 -> 62.3 (965 TFLOP/s), Wo 25.6 -> 20.0,
+// QKV 70.0 -> 56.5, W1 82.2 -> 73.8 (256-row tiles 76.0 -> 69.1); per step: 512 streams 17.8 -> 16.5-16.9 ms synchronous, 128 streams
+// 4.81 -> 4.49 pipelined, 64 streams (7 row chunks) 2.49 -> 2.44; 32 streams (4 row chunks) 1.52 / 1.54: up to 4 row chunks the old order
+// stays (profiles/r4_tile_order.md).  The order never changes a result (engine option "tile_bands", gemm_variant_identity.py).
+__device__ __forceinline__ void tile_of(int id, int n_groups, int m_chunks, int bands, int &mc, int &ng, int &split) {      // bands = GemmParams::tile_bands
+    const int per = n_groups * m_chunks;
+    split = id / per;
+    const int in = id - split * per;
+    if (bands == 2 || (bands == 0 && m_chunks <= 4)) { mc = in % m_chunks; ng = in / m_chunks; return; }
+    const int w = (n_groups & 7) == 0 ? 8 : (n_groups & 3) == 0 ? 4 : (n_groups & 1) == 0 ? 2 : 1;
+    const int band = in / (w * m_chunks), ib = in - band * (w * m_chunks);
+    mc = ib / w;
+    ng = band * w + ib % w;
+}
+
 // ------------------------------------------------------------------------------------
 constexpr int G2_SLOT = 32768;
 
@@ -177,9 +198,8 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
         const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
     }
-    const int mc = id % m_chunks;
-    const int rest = id / m_chunks;
-    const int ng = rest % n_groups, split = rest / n_groups;
+    int mc, ng, split;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ng4 = wave & 3, mh = wave >> 2;
@@ -276,7 +296,8 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
         const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
     }
-    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    int mc, ng, split;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
     const int KT = p.K >> 5, kc_total = KT >> 1;
@@ -357,7 +378,8 @@ __global__ __launch_bounds__(512) void k_gemm_t64(GemmParams p, int n_groups, in
         const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
     }
-    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    int mc, ng, split;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ng2 = wave & 1, mq = wave >> 1, q = lane >> 4, r = lane & 15;
     const int KT = p.K >> 5, kc_total = KT >> 1;
@@ -455,7 +477,8 @@ __global__ __launch_bounds__(1024) void k_gemm_roles(GemmParams p, int n_groups,
         const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
     }
-    const int mc = id % m_chunks, rest = id / m_chunks, ng = rest % n_groups, split = rest / n_groups;
+    int mc, ng, split;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
     const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const bool loader = wave16 >= 8;
     const int wave = wave16 & 7;
@@ -789,7 +812,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
         const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
     }
-    const int mc = id % m_chunks, ng = id / m_chunks;
+    int mc, ng, split_unused;
+    tile_of(id, n_groups, m_chunks, p.tile_bands == 2 ? 2 : 1, mc, ng, split_unused);          // bands of column groups whatever the row count (tile_of() above)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nq = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
     const int KT = p.K >> 5, m0 = mc * BM;
@@ -949,8 +973,13 @@ static bool gemm_coresident(const GemmParams &p) {
     constexpr int min_m = 769;
     if (p.coresident >= 2) return p.coresident == 2;          // engine option "gemm_cores" (A/B runs, the bit-identity test)
     // more than one wave of tiles (M >= 1 792): workgroups of ONE launch start as earlier ones finish, so the two on a CU are out of
-    // phase by themselves -- synchronous steps gain as well (128 streams x R = 13: 6.51 -> 5.95 ms, 512 streams 19.9 -> 18.6 ms)
-    return p.M >= 1792 || (p.coresident == 1 && p.M >= min_m);
+    // phase by themselves -- synchronous steps gain as well (128 streams x R = 13: 6.51 -> 5.95 ms, 512 streams 19.9 -> 18.6 ms).
+    // Only with more tiles than CUs: a launch that puts at most one workgroup on a CU has nothing to pair and keeps the deep rings
+    // (cold operands, us per launch, deep / shallow: 1 792 rows pw1 224 tiles 12.6 / 16.7, W2 112 tiles 28.3 / 32.4; 3 584 rows W2 224 tiles
+    // 34.7 / 45.1, Wo 12.0 / 14.8 -- profiles/r4_tile_order.md)
+    if (p.coresident == 1 && p.M >= min_m) return true;
+    const long tiles = (long)(p.N / (gemm_use_t64(p.M, p.N, p.epi) ? 64 : 128)) * ((p.M + TM - 1) / TM) * (p.splits < 1 ? 1 : p.splits);
+    return p.M >= 1792 && tiles > g_num_cus;
 }
 
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {

@@ -125,6 +125,9 @@ struct GemmParams {
     int no_wide;
     // 256 = of the wide tiles only the 256-row form (engine option "wide_tiles" = 256: A/B against the 224-row form); 0 = the launcher's rule
     int wide_rows;
+    // tile order of the LDS-tiled bf16 kernels (tile_of(), kernels_gemm.hip): 0 = bands of column groups above 4 row chunks, 1 = always,
+    // 2 = never (the row chunk fastest; engine option "tile_bands" = 0: the order of rounds 1-3)
+    int tile_bands;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------

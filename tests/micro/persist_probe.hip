@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
                 memset(&g, 0, sizeof(g));
                 g.A = A; g.W = W; g.M = M; g.N = s.N; g.K = s.K; g.lda = s.K; g.splits = 1; g.epi = s.epi;
                 g.out_f32 = outf; g.ldo = s.epi == EPI_GLU ? s.N / 2 : s.N; g.out_act = act; g.ldo_act = s.N; g.bias = bias;
-                g.no_persist = mode >= 1; g.coresident = mode == 2 ? 3 : 0; g.no_wide = mode < 3; g.wide_rows = mode == 4 ? 256 : 0;
+                g.no_persist = mode >= 1; g.coresident = mode == 2 ? 3 : 0; g.no_wide = mode != 3; g.wide_rows = 0; g.tile_bands = mode == 4 ? 2 : 0;
                 for (int i = 0; i < 3; i++) launch_gemm_bf16(g, st);
                 hipEvent_t a, b;
                 CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
@@ -55,7 +55,7 @@ int main(int argc, char **argv) {
                 us[mode] = 1e3 * ms / reps;
             }
             const double fl = 2.0 * M * s.N * s.K * 1e-6;
-            printf("%sM = %5d  %-34s persistent %7.2f us (%5.0f TFLOP/s) | per-tile, two per CU %7.2f us (%5.0f) | per-tile, deep rings %7.2f us (%5.0f) | wide tiles %7.2f us (%5.0f) | wide, 256 rows only %7.2f us (%5.0f)\n", cold ? "[cold] " : "", M, s.name,
+            printf("%sM = %5d  %-34s persistent %7.2f us (%5.0f TFLOP/s) | per-tile, two per CU %7.2f us (%5.0f) | per-tile, deep rings %7.2f us (%5.0f) | wide tiles %7.2f us (%5.0f) | per-tile, two per CU, row-fastest order %7.2f us (%5.0f)\n", cold ? "[cold] " : "", M, s.name,
                    us[0], fl / us[0], us[1], fl / us[1], us[2], fl / us[2], us[3], fl / us[3], us[4], fl / us[4]);
         }
     return 0;
