@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD" "SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_wide_$i -- $BIN cold 7168 > $OUT/pmc_wide_$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_wide_$i -- $BIN cold ${PROBE_M:-7168} > $OUT/pmc_wide_$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python3 - <<PY
