@@ -149,6 +149,7 @@ struct nasr_engine {
     // workspace set, descriptor blocks, joint.enc buffer, token landing zone, graphs (their kernel arguments point into
     // the slot).  E + 1 steps are in flight; slot of a step = its sequence number mod NSLOT.
     static const int MAXSEG = 4, LSLOT = MAXSEG + 1;     // lanes mode: E + 1 steps in flight, slot = sequence number mod LSLOT
+    int pipe_last_nseg = 0;          // pieces of the youngest step in flight (pipe_step drains before a step that is cut differently)
     static const int GP_C = 2, GP_Y = FUSED_GROUP, GP_S = GP_C * GP_Y;   // grouped mode ("pipeline" = 8): 2 chains x 4 problems per launch = 8 stages
     static const int NSLOT = GP_S + 3;                    // grouped mode: 8 steps in flight + the one being decoded + the one being collected + one spare
     struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; };

@@ -306,7 +306,19 @@ int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t 
                      int32_t *const *tokens_out, const int32_t *tokens_cap, int32_t *n_tokens) {
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
     if (ensure_pipe(e, (int)(e->pipe_seq % nasr_engine::LSLOT))) return -1;     // also picks the lanes
-    const int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, e->max_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
+    int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, e->max_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
+    // From 3 584 rows a step's GEMMs fill the chip several times over by themselves, and every further lane is another GEMM's working set
+    // in the same L2s: two pieces are faster than four (ms per step at 2 / 3 / 4 pieces, R = 13: 512 streams 15.29 / 15.60 / 15.97, 384 streams
+    // 11.72 / 12.05 / 12.46, 256 streams 8.02 / 8.01 / 8.11; below that more pieces win: 192 streams 6.38 / 6.14 / 6.22, 128 streams 4.55 / 4.33 /
+    // 4.31 -- profiles/r4_tile_order.md).  "pipeline" = E stays the upper bound; a step's tokens come back the same number of calls later
+    // whatever the piece count (the slot rotation, not the pieces, sets that).
+    if ((long)B * T * G >= 3584) nseg = std::min(nseg, 2);
+    // steps in flight order their layers through the lanes (piece k of every step on lane k): a step cut differently from the ones before it
+    // must not overtake them -- complete those first (a call population that crosses 3 584 rows, or an option change; never the steady state)
+    if (e->pipe_last_nseg != nseg) {
+        if (e->pipe_last_nseg && pipe_drain(e)) return -1;
+        e->pipe_last_nseg = nseg;
+    }
     const int64_t seq = e->pipe_seq;
     const int p = (int)(seq % nasr_engine::LSLOT);
     if (ensure_pipe(e, p)) return -1;
