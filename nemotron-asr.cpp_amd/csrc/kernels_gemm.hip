@@ -1004,7 +1004,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         // least 5 / 8 full, or three rounds and more (persist_probe, cold operands, us per launch against the per-tile pair: 7 168 rows W1 448
         // tiles 78 / 83, pw1 224 tiles 38 / 45, QKV 336 tiles 69 / 70: a wash, left alone; 15 360 rows N = 1024 240 tiles 109 / 160).  The
         // 256 x 128 form measured worse than the per-tile kernels with cold operands (W2 at 7 168 rows 92 / 77) and is not used.
-        if (!p.no_wide && p.splits == 1 && p.M >= 1792 && (p.K & 31) == 0 && p.N % 256 == 0) {
+        if (!p.no_wide && p.splits == 1 && p.M >= (p.coresident == 1 ? 1344 : 1792) && (p.K & 31) == 0 && p.N % 256 == 0) {
             // 256- or 224-row tiles: whichever needs fewer rounds x rows (7 168 rows: N = 4096 two full rounds of 224-row tiles instead of
             // 1.75 of 256-row ones, N = 2048 one round of 256 smaller tiles; 15 360 rows stay at 256).  Cold operands, us per launch, 256 / 224 rows:
             // W1 at 7 168 rows 78.8 / 74.9, pw1 38.4 / 35.4, W1 at 3 584 rows 43.8 / 41.0; synchronous steps 512 streams 18.08 -> 17.82 ms, 256
@@ -1018,6 +1018,16 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 if (!(tiles >= (long)g_num_cus * 7 / 8 && (last == 0 || last * 8 >= (long)g_num_cus * 5 || tiles >= (long)g_num_cus * 3))) continue;
                 const long cost = (tiles + g_num_cus - 1) / g_num_cus * bm;
                 if (!best_mt || cost < best_cost) { best_mt = mt; best_cost = cost; best_tiles = tiles; }
+            }
+            // Pipelined steps (other lanes' workgroups fill the CUs a launch leaves idle): 224-row tiles from 96 of them, where the rule above finds
+            // too few to fill the chip.  What a pipelined step is short of is operand delivery -- at 64 streams the LDS fills of a step's
+            // 128 x 128 tiles add up to 23 GB = 9.5 TB/s, between what the Infinity Cache (8.6) and an XCD's L2 (17-19) deliver -- and a
+            // 224 x 256 tile moves 0.54 of the bytes per flop.  ms per step, four lanes, without / with: 96 streams 3.37 / 3.33, 128 streams
+            // 4.30 / 4.19, 192 streams 6.22 / 6.02; from 64 tiles: 4.21 (128 streams), 3.35 (96); at 64 streams (64 / 48 / 32 tiles) 2.42 -> 2.54, W1's 64 tiles alone 2.415 -> 2.449: not taken.
+            // With it: 256 streams 8.00 -> 7.93, 384 streams 11.75 -> 11.43, 512 streams (every GEMM of the layer on these tiles) 15.31 -> 14.49.
+            if (!best_mt && p.coresident == 1 && p.wide_rows != 2) {
+                const long tiles = (long)(p.N / 256) * ((p.M + 223) / 224);
+                if (tiles >= 96) { best_mt = 7; best_tiles = tiles; }
             }
             if (p.wide_rows == 256 && best_mt) { best_mt = 8; best_tiles = (long)(p.N / 256) * ((p.M + 255) / 256); }      // engine option "wide_tiles" = 256: round 4's first form only
             if (best_mt == 8) {

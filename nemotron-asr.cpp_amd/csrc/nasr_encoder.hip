@@ -17,7 +17,7 @@ int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
     g.f32_fma_tile = e->opt_f32_mfma ? 0 : 1;
     g.no_persist = e->opt_persist_gemm ? 0 : 1;
     g.no_wide = e->opt_wide_tiles ? 0 : 1;
-    g.wide_rows = e->opt_wide_tiles == 256 ? 256 : 0;
+    g.wide_rows = e->opt_wide_tiles == 256 ? 256 : e->opt_wide_tiles == 3 ? 2 : 0;
     g.tile_bands = e->opt_tile_bands < 0 ? 0 : e->opt_tile_bands == 0 ? 2 : 1;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);

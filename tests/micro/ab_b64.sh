@@ -7,6 +7,7 @@ run() {
     local opts="" envs="NASR_AB=0"
     for kv in "$@"; do case "$kv" in opt:*) opts="$opts --engine-option ${kv#opt:}";; *) envs="$envs $kv";; esac; done
     for mode in "" "--sync-steps"; do
+        [ -n "$mode" ] && [ "${AB_SYNC:-1}" = 0 ] && continue          # AB_SYNC=0: pipelined steps only
         local line
         line=$(env $envs timeout -k 10 300 python3 bench.py $common $opts $mode 2>/dev/null | grep '^{' | tail -n 1)
         echo "$tag ${mode:-pipelined}: $(python3 -c "import json,sys; d=json.loads(sys.argv[1]); print(d['ms_per_step'], 'ms', d['value'], 'RTFx')" "$line")"
