@@ -307,12 +307,13 @@ int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t 
     const int T = streams[0]->T, R = streams[0]->R, shift = 8 * T;
     if (ensure_pipe(e, (int)(e->pipe_seq % nasr_engine::LSLOT))) return -1;     // also picks the lanes
     int nseg = std::max(1, std::min({e->opt_pipeline, e->n_lanes, e->max_lanes, (int)nasr_engine::MAXSEG, (int)e->hp.n_layers}));
-    // From 3 584 rows a step's GEMMs fill the chip several times over by themselves, and every further lane is another GEMM's working set
-    // in the same L2s: two pieces are faster than four (ms per step at 2 / 3 / 4 pieces, R = 13: 512 streams 15.29 / 15.60 / 15.97, 384 streams
-    // 11.72 / 12.05 / 12.46, 256 streams 8.02 / 8.01 / 8.11; below that more pieces win: 192 streams 6.38 / 6.14 / 6.22, 128 streams 4.55 / 4.33 /
-    // 4.31 -- profiles/r4_tile_order.md).  "pipeline" = E stays the upper bound; a step's tokens come back the same number of calls later
-    // whatever the piece count (the slot rotation, not the pieces, sets that).
-    if ((long)B * T * G >= 3584) nseg = std::min(nseg, 2);
+    // From 3 584 rows a step's GEMMs fill the chip by themselves, and every further lane is another GEMM's working set in the same L2s: fewer
+    // pieces are faster than four.  ms per step at 2 / 3 / 4 pieces, R = 13 (with the pipelined steps' 224-row tiles): 512 streams 14.57 / 14.32 /
+    // 14.61, 384 streams 11.51 / 10.95 / 11.06, 256 streams 7.99 / 7.93 / 7.97 (before those tiles two pieces were best: 15.29 / 15.60 / 15.97);
+    // below 3 584 rows four win (192 streams 6.38 / 6.14 / 6.22 before the tiles, 128 streams 4.55 / 4.33 / 4.31, 64 streams 2.95 / 2.57 / 2.40) --
+    // profiles/r4_tile_order.md.  "pipeline" = E stays the upper bound, engine option "large_step_pieces" (default 3) is this one; a step's
+    // tokens come back at most E calls later whatever the piece count.
+    if ((long)B * T * G >= 3584 && e->opt_large_step_pieces > 0) nseg = std::min(nseg, e->opt_large_step_pieces);
     // steps in flight order their layers through the lanes (piece k of every step on lane k): a step cut differently from the ones before it
     // must not overtake them -- complete those first (a call population that crosses 3 584 rows, or an option change; never the steady state)
     if (e->pipe_last_nseg != nseg) {

@@ -622,8 +622,8 @@ def test_lanes_option_gives_queues_back_and_keeps_results(W2):
 
 
 def test_steps_cut_into_different_piece_counts_keep_their_order():
-    """Round 4: from 3 584 rows per step the engine cuts a pipelined step into two pieces instead of four (every further lane is another
-    GEMM's working set in the same L2s: 512 streams 15.97 -> 15.29 ms).  Steps in flight order their layers through the lanes, so a step
+    """Round 4: from 3 584 rows per step the engine cuts a pipelined step into at most three pieces instead of four (every further lane is
+    another GEMM's working set in the same L2s; engine option "large_step_pieces", here 2 so that the two cuts differ as much as they can).  Steps in flight order their layers through the lanes, so a step
     that is cut differently from the ones before it has to wait for them: calls of 256 streams x R = 13 (3 584 rows, two pieces) alternate
     with calls of the first 64 of those streams (896 rows, four pieces), then the other 192 catch up -- tokens, encoder output and caches
     of every stream must be those of synchronous stepping, bit for bit.  (With the wait taken out the test still passes: the overtaking
@@ -639,6 +639,7 @@ def test_steps_cut_into_different_piece_counts_keep_their_order():
     for pipeline in (0, 4):
         eng = capi.Engine(W, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
         eng.set_option("pipeline", pipeline)
+        eng.set_option("large_step_pieces", 2)
         sts = [eng.stream(R) for _ in range(B)]
         pos = [0] * B
         toks = [[] for _ in range(B)]
