@@ -1,4 +1,4 @@
-"""Bit-identity of GEMM kernel variants: 16 / 64 / 128 / 256 / 512 streams x R = 13 (M = 224 ... 7 168) on a 3-layer bf16 engine, a few
+"""Bit-identity of GEMM kernel variants: 16 / 64 / 100 / 128 / 256 / 260 / 512 streams x R = 13 (M = 224 ... 7 168) on a 3-layer bf16 engine, a few
 steps; prints one digest per setting.  A setting is a space-separated list of engine options ("opt:persistent_gemm=0 opt:gemm_cores=1":
 nasr_engine_set_option before the first step) and / or environment variables ("VAR=value"); the first digest is the build's default.
     python gemm_variant_identity.py "opt:gemm_cores=1" "opt:gemm_cores=0" "opt:persistent_gemm=1"
@@ -22,7 +22,8 @@ def child():
     h = hashlib.sha256()
     n = synth.shift_samples(R)
     pool = [synth.make_pcm(300 + b, 6 * n / 16000 + 0.01)[:6 * n] for b in range(128)]
-    for B, pipeline in ((16, 0), (64, 0), (64, 4), (128, 0), (256, 0), (512, 0), (512, 4)):
+    # 100 streams pipelined (1 400 rows = 6.25 tiles of 224) and 260 streams synchronous (3 640 rows = 14.2 tiles of 256): ragged last tiles of k_gemm_wide
+    for B, pipeline in ((16, 0), (64, 0), (64, 4), (100, 4), (128, 0), (256, 0), (260, 0), (512, 0), (512, 4)):
         eng = capi.Engine(W, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
         for kv in os.environ.get("NASR_VARIANT_OPTS", "").split():
             k, v = kv.split("=", 1)
