@@ -22,6 +22,8 @@ def main():
     n_layers = int(sys.argv[4][1:]) if len(sys.argv) > 4 else (8 if pmode == 8 else 4)      # "L8", "L24"
     # SOAK_STREAMS="13x72,0x4": 72 streams of R = 13 and 4 of R = 0 (default: 0, 0, 0, 1, 13).  With ~58 of 72 R = 13 streams per call
     # the row count of a step crosses 768 both ways: deep-ring and co-resident GEMM kernels alternate between the steps in flight.
+    # "13x100": multi-chunk pushes (2-4 chunks of ~80 streams) cross 3 584 rows: steps cut into three and into four pieces alternate
+    # (round 4: pipe_step waits for the steps in flight before one that is cut differently), 224-row tiles come and go.
     spec = __import__("os").environ.get("SOAK_STREAMS")
     Rs = [0, 0, 0, 1, 13]
     if spec:
@@ -35,6 +37,10 @@ def main():
     for mode in (0, pmode):
         e = capi.Engine(W, n_layers=n_layers, dtype=capi.DTYPE_BF16, max_streams=B)
         e.set_option("pipeline", mode)
+        if mode:
+            for kv in __import__("os").environ.get("SOAK_OPTS", "").split():      # SOAK_OPTS="large_step_pieces=2 wide_tiles=3": options of the pipelined engine
+                k, v = kv.split("=")
+                e.set_option(k, int(v))
         engs.append(e)
     streams = [[e.stream(R) for R in Rs] for e in engs]
     pcm = [synth.make_pcm(500 + b, 900.0 if B <= 8 else 150.0) for b in range(B)]

@@ -550,7 +550,8 @@ def test_progress_does_not_drain_the_pipeline(W2):
     eng.close()
 
 
-@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1200", "7", "8"), ("1000", "3", "4", "L4", "SOAK_STREAMS=13x72,0x4")])
+@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1200", "7", "8"), ("1000", "3", "4", "L4", "SOAK_STREAMS=13x72,0x4"),
+                                  ("300", "11", "4", "L4", "SOAK_STREAMS=13x100", "SOAK_OPTS=large_step_pieces=2")])
 def test_pipelined_engine_soak(args):
     """tests/micro/soak_pipeline.py, short form: random push sizes (partial chunks, several chunks, ragged groups), random subsets of
     five streams of three lookaheads, resets, finalize / collect in between -- a pipelined engine emits exactly the tokens of a
@@ -558,7 +559,9 @@ def test_pipelined_engine_soak(args):
     exposed the lane inconsistency of the round-2 cuts at calls 475-499 (a stream alternating between one-to-four-row steps and larger
     ones while both are in flight; enqueue_encoder: snap8) -- with four lanes, and with the grouped pipeline (mode 8).  Last case: 72
     streams of R = 13 (+ 4 of R = 0), ~58 of them per call: the rows of a step cross 768 both ways, so steps on the deep-ring GEMM
-    kernels and steps on the co-resident ones are in flight together."""
+    kernels and steps on the co-resident ones are in flight together.  Round 4: 100 streams of R = 13, ~80 per call, pushes of 1-4 chunks: the
+    rows of a step cross 3 584 both ways, so steps cut into two pieces (engine option "large_step_pieces" = 2) and into four, on 224-row tiles
+    and on 128-row ones, follow each other."""
     import subprocess
     import sys
     from pathlib import Path
