@@ -1008,11 +1008,10 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             // 256- or 224-row tiles: whichever needs fewer rounds x rows (7 168 rows: N = 4096 two full rounds of 224-row tiles instead of
             // 1.75 of 256-row ones, N = 2048 one round of 256 smaller tiles; 15 360 rows stay at 256).  Cold operands, us per launch, 256 / 224 rows:
             // W1 at 7 168 rows 78.8 / 74.9, pw1 38.4 / 35.4, W1 at 3 584 rows 43.8 / 41.0; synchronous steps 512 streams 18.08 -> 17.82 ms, 256
-            // streams 9.56 -> 9.42.  Pipelined steps LOSE 0.5-0.8 % (16.22 -> 16.35, 8.41 -> 8.45: the CUs a partial round leaves idle run
-            // another lane's kernels, full rounds leave none), so they keep the 256-row form (profiles/r4_wide_tiles.md).
+            // streams 9.56 -> 9.42; pipelined steps (three pieces) 384 streams 10.95 -> 10.82, 512 streams 14.32 = (profiles/r4_wide_tiles.md).
             int best_mt = 0;
             long best_cost = 0, best_tiles = 0;
-            for (int mt = 8; mt >= (p.coresident == 1 ? 8 : 7); mt--) {
+            for (int mt = 8; mt >= 7; mt--) {
                 const int bm = 32 * mt, mw = (p.M + bm - 1) / bm;
                 const long tiles = (long)(p.N / 256) * mw, last = tiles % g_num_cus;
                 if (!(tiles >= (long)g_num_cus * 7 / 8 && (last == 0 || last * 8 >= (long)g_num_cus * 5 || tiles >= (long)g_num_cus * 3))) continue;
