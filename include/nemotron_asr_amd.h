@@ -212,6 +212,7 @@ enum {
  * large-M GEMM kernels of which two share a CU), "persistent_gemm" (1: GEMMs with several 128 x 128 tiles per CU on the persistent tile loop; default 0),
  * "wide_tiles" (default 1: 256- / 224-row tiles from 1 792 rows where their rounds fill the chip, in pipelined steps from 1 344 rows and 96 tiles;
  * 256: the 256-row form only; 3: without the pipelined steps' 96-tile rule; 0: off), 
+ * "t64_tiles" (default 64, process-wide: the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles; round 3: 127),
  * "tile_bands" (-1 = the rule: above 4 row chunks the tiles of a launch are handed to the XCDs in bands of column groups, so that the panels an XCD reads stay in its L2;
  * 0 / 1 = never / always), "f32_mfma" (0: f32 GEMMs above
  * four rows on the FMA tile kernel instead of the f32 MFMA), "decode_graph_iterations" (>= 1, default 12: decode iterations a

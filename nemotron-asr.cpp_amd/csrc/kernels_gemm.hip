@@ -943,10 +943,16 @@ void init_gemm_kernel_attributes() {
 // tiles wherever the 128 x 128 tiling had <= 128 workgroups against the split-K form only: 16 streams x R = 13 (32-64 tiles)
 // 1.22 vs 1.32 ms per step, 32 streams (64-128 tiles) 1.82 vs 1.77, 64 streams (pw1: 112 tiles -> 224) 2.66 vs 2.65 -- although
 // alone the 112-tile launch takes 13.3 us and the vendor library's MT128x64 kernel 10.6 (tests/prof_gemm_shapes.sh).
+// Round 4: for the split-K GEMMs only up to 64 tiles of 128 x 128 (M <= 1 024).  Above that two K-halves of 128 x 128 tiles fill the chip by themselves
+// (72-120 tiles x 2 <= 256 workgroups) where the half-width form makes 288-480 workgroups of a shape that moves 1.5 x the operand bytes per flop: 112 streams
+// x R = 13 (104 tiles) synchronous 5.92 -> 5.30 ms, pipelined 3.82 -> 3.77; 128 streams (112 tiles) pipelined 4.21 -> 4.14, synchronous 5.52 -> 5.69
+// (profiles/r4_tile_order.md).  Engine option "t64_tiles" (process-wide: the choice is made in two places that must agree).
+static int g_t64_part_tiles = 64;
+void gemm_set_t64_part_tiles(int tiles) { g_t64_part_tiles = tiles; }
 bool gemm_use_t64(int M, int N, int epi) {
     if (M <= gemm_skinny_max_m()) return false;
     const int tiles = (N / 128) * ((M + 127) / 128);
-    if (epi == EPI_PART_F32) return N == 1024 && tiles < 128;
+    if (epi == EPI_PART_F32) return N == 1024 && tiles <= g_t64_part_tiles;
     return tiles <= 64;
 }
 int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 128; }

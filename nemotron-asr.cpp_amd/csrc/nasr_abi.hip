@@ -9,6 +9,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     else if (!strcmp(key, "graph_cache")) { if (value < 1) return fail("graph_cache must be >= 1"); e->opt_graph_cache = value; }
     else if (!strcmp(key, "multichunk")) e->opt_multichunk = value != 0;
     else if (!strcmp(key, "large_step_pieces")) { if (value < 0 || value > nasr_engine::MAXSEG) return fail("large_step_pieces must be 0 .. %d", (int)nasr_engine::MAXSEG); e->opt_large_step_pieces = value; }
+    else if (!strcmp(key, "t64_tiles")) { if (value < 0) return fail("t64_tiles must be >= 0"); gemm_set_t64_part_tiles(value); }      // process-wide; before the first step
     else if (!strcmp(key, "tile_bands")) e->opt_tile_bands = value;
     else if (!strcmp(key, "wide_tiles")) e->opt_wide_tiles = value;              // like "fused": set before the first step
     else if (!strcmp(key, "persistent_gemm")) e->opt_persist_gemm = value != 0;      // like "fused": set before the first step

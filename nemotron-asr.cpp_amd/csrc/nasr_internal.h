@@ -135,7 +135,8 @@ struct GemmParams {
 void init_gemm_kernel_attributes();    // one-time hipFuncSetAttribute calls (never inside a stream capture)
 void init_fused_kernel_attributes();
 int gemm_skinny_max_m();     // largest M served by the weight-streaming kernel
-int gemm_tile_n(int M, int N, int epi);   // output-tile width the large-M kernel will use (128, or 64 for the N = 1024 split-K GEMMs)
+int gemm_tile_n(int M, int N, int epi);
+void gemm_set_t64_part_tiles(int tiles);      // engine option "t64_tiles"   // output-tile width the large-M kernel will use (128, or 64 for the N = 1024 split-K GEMMs)
 void launch_gemm_bf16(const GemmParams &p, hipStream_t st);
 void launch_gemm_f32(const GemmParams &p, hipStream_t st);
 void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st);
