@@ -77,13 +77,30 @@ def store_weights(d: Path, W: dict):
     shutil.rmtree(tmp, ignore_errors=True)
     shutil.rmtree(d, ignore_errors=True)
     tmp.mkdir(parents=True)
-    index = []
-    for i, (name, v) in enumerate(W.items()):
-        arr = v[1] if isinstance(v, tuple) else v
-        np.save(tmp / f"{i}.npy", np.ascontiguousarray(arr))
-        index.append([name, int(v[0]), list(v[2])] if isinstance(v, tuple) else [name, None, None])
-    (tmp / "index.json").write_text(json.dumps(index))
-    tmp.rename(d)
+    try:
+        index = []
+        for i, (name, v) in enumerate(W.items()):
+            arr = v[1] if isinstance(v, tuple) else v
+            np.save(tmp / f"{i}.npy", np.ascontiguousarray(arr))
+            index.append([name, int(v[0]), list(v[2])] if isinstance(v, tuple) else [name, None, None])
+        (tmp / "index.json").write_text(json.dumps(index))
+        tmp.rename(d)
+    except BaseException:
+        shutil.rmtree(tmp, ignore_errors=True)      # RAM-backed files: never leave half a set behind
+        raise
+
+
+def remove_stale_shm(max_age_s=1800.0):
+    """/dev/shm/nasr_bench_* left by a run that crashed or was killed (2.4-5 GB of RAM each; round-4 advisor): anything older
+    than half an hour goes before this run parks its own"""
+    import shutil
+    now = time.time()
+    for d in Path("/dev/shm").glob("nasr_bench_*"):
+        try:
+            if now - d.stat().st_mtime > max_age_s:
+                shutil.rmtree(d, ignore_errors=True)
+        except OSError:
+            pass
 
 
 def load_weights(d: Path) -> dict:
@@ -185,7 +202,7 @@ def pmc_traffic(kernel_symbol_part, tag):
     (profiles/r4_pmc_traffic_<tag>.json, written by tests/prof_r4.sh: FETCH_SIZE x 2 + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside this process; null when no
     summary for the configuration / kernel is committed."""
-    f = next((c for c in (ROOT / "profiles" / f"r4_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r3_pmc_traffic_{tag}.json") if c.exists()), None)
+    f = next((c for c in (ROOT / "profiles" / f"r5_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r4_pmc_traffic_{tag}.json") if c.exists()), None)
     if f is None:
         return None
     try:
@@ -198,6 +215,25 @@ def pmc_traffic(kernel_symbol_part, tag):
             tot += rec["hbm_bytes_per_launch_corrected"] * rec.get("launches_FETCH_SIZE", 1)
             n += rec.get("launches_FETCH_SIZE", 1)
     return round(tot / n) if n else None
+
+
+def timed_regime_block(tag, depth, ms_per_step, sr):
+    """The regime `value` is timed in (E lanes: pieces of consecutive steps side by side), with its own kernel-level evidence: the
+    rocprofv3 --kernel-trace of the same command, reduced by tests/prof_r5.sh to profiles/r5_<tag>_pipelined_trace.json (sum of kernel
+    durations per step over all lanes, the wall time those kernels cover, how many run at a time).  The whole-step fraction is what the
+    headline stands for; the `roofline` block is the dominant kernel ALONE on the chip (synchronous regime)."""
+    if not depth:
+        return None
+    out = dict(regime=f"pipelined, {depth} lanes", ms_per_step=ms_per_step, hbm_frac=sr["hbm_frac"], mfma_frac=sr["mfma_frac"])
+    f = ROOT / "profiles" / f"r5_{tag}_pipelined_trace.json"
+    if f.exists():
+        try:
+            t = json.loads(f.read_text())
+            out.update(kernel_ms_per_step=t["kernel_ms_per_step"], busy_ms_per_step=t["busy_ms_per_step"], overlap=t["overlap"],
+                       profiled_ms_per_step=t["ms_per_step"], dominant=t["dominant"], source=f"profiles/{f.name}")
+        except (ValueError, KeyError):
+            pass
+    return out
 
 
 _SYMBOL = {"k_fused_ln_gemm": ("k_fused_skinny<0,",), "k_fused_plain_gemm": ("k_fused_skinny<1,",), "k_fused_attn_gemm": ("k_fused_skinny<2,",),
@@ -349,7 +385,9 @@ def profile_pass(run, n_steps, label, pmc_tag, restore_pipeline, bound=None):
     common = dict(kernel=dom["name"], avg_launch_us=round(avg_s * 1e6, 3), avg_launch_us_event_brackets=round(avg_ev_us, 3),
                   launches_per_step=per_step, share_of_step=round(share, 4), alg_bytes_per_launch=round(nbytes),
                   alg_flops_per_launch=round(flops), traffic=traffic, workload=label,
-                  regime=f"kernel alone on the chip: synchronous graph-replayed steps, {round(step_s * 1e3, 4)} ms per step")
+                  regime="synchronous", step_ms=round(step_s * 1e3, 4),
+                  regime_note="kernel alone on the chip: synchronous graph-replayed steps (one launch chain; launches_per_step x avg_launch_us fits inside "
+                              "step_ms, NOT inside the pipelined ms_per_step -- that regime is the `timed_regime` block)")
     if mfma_bound:
         roof = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_PEAK_TFLOPS, 4),
                     peak_measured=MFMA_MEASURED_TFLOPS, frac_of_measured=round(tf / MFMA_MEASURED_TFLOPS, 4),
@@ -403,9 +441,60 @@ def reference_cli_baseline(pcm, R):
                 sample=f"{pcm.size / 16000:.1f} s of the headline stream through {exe} --cpu (real checkpoint {gguf}: other weights than the GPU run)")
 
 
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    return dict(nproc=os.cpu_count(), affinity=aff, cpu_model=model)
+
+
+def cpu_baseline_sample(ob, om, synth, p, R, n_step, cpu_seconds, passes=3):
+    """The oracle (the CPU restatement of the reference's path; stands in for src/transcribe_stream.cpp:260-267's own RTF line, ggml
+    being absent) on `passes` consecutive stretches of stream 0, each timed on its own: `value` is the MEDIAN pass, `runs` all of
+    them, `best` the fastest.  Threads are pinned (OMP_PROC_BIND=close, OMP_PLACES=cores: set in main() before any OpenMP runtime
+    loads) and the host is named in the entry -- round 4's figure moved 2 x between boxes with neither stated.
+    -> (entry, oracle stream, its tokens so far, steps processed after the two warm-up pushes)"""
+    ost = ob.OracleStream(om, R)
+    ost.enable_decision_log()
+    n_total = max(2 * passes, min(int(cpu_seconds * synth.SAMPLE_RATE / n_step), p.size // n_step - 2))
+    n_pass = max(1, n_total // passes)
+    ref_tokens = ost.process(p[:2 * n_step])            # warm-up: fills the first chunk
+    c0 = ost.total_chunks
+    times, k = [], 2
+    for _ in range(passes):
+        tc = time.perf_counter()
+        for kk in range(k, k + n_pass):
+            ref_tokens += ost.process(p[kk * n_step:(kk + 1) * n_step])
+        times.append(time.perf_counter() - tc)
+        k += n_pass
+    audio_pass = n_pass * n_step / synth.SAMPLE_RATE
+    vals = sorted(audio_pass / t for t in times)
+    med = statistics.median(vals)
+    entry = dict(value=round(med, 3), unit="audio-s/s", cores=ob.lib().orc_num_threads(), kind="port",
+                 runs=[round(audio_pass / t, 3) for t in times], best=round(vals[-1], 3), spread=round((vals[-1] - vals[0]) / med, 3),
+                 sample=f"{passes} x {audio_pass:.1f} s of stream 0 ({ost.total_chunks - c0} chunks, {sum(times):.1f} s of CPU work), oracle/nasr_oracle.c f32 + OpenMP",
+                 omp=dict(proc_bind=os.environ.get("OMP_PROC_BIND"), places=os.environ.get("OMP_PLACES"), wait_policy=os.environ.get("OMP_WAIT_POLICY")),
+                 host=host_info())
+    return entry, ost, ref_tokens, passes * n_pass
+
+
 def main():
     args = parse()
     ENGINE_OPTIONS[:] = args.engine_option
+    # the CPU baseline's threads: one per core, neighbours close (before torch / the oracle load an OpenMP runtime, which reads these once)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -476,6 +565,8 @@ def main():
     t0 = time.time()
     speech = args.checkpoint == "speech" and args.layers == 24          # the fit belongs to the 24-layer encoder
     node_rank0 = int(os.environ.get("LOCAL_RANK", "0")) == 0
+    if node_rank0:
+        remove_stale_shm()
 
     def shared(tag, make):
         """N > 1: the node's first rank builds the tensors once and parks them in /dev/shm, the others map them read-only
@@ -484,12 +575,14 @@ def main():
             return make()
         d = Path("/dev/shm") / f"nasr_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}"
         if node_rank0:
+            SHM_DIRS.append(d)                  # the atexit hook removes it if anything below fails
             store_weights(d, make())
         dist.barrier()
         out = load_weights(d)
         dist.barrier()
-        if node_rank0:
-            SHM_DIRS.append(d)                  # removed at exit (files stay mapped in the ranks that still use them)
+        if node_rank0:                          # every rank has mapped the files: unlink them now (the mappings stay valid), so that a rank
+            import shutil                       # that crashes or is killed later leaves nothing behind in RAM
+            shutil.rmtree(d, ignore_errors=True)
         return out
 
     W = shared(f"f32_{args.layers}_{int(speech)}", lambda: synth.make_weights(n_layers=args.layers, margins="speech" if speech else "random"))
@@ -520,6 +613,7 @@ def main():
         return barrier
 
     barrier = barrier_for(run)
+    pcm0, n_step0 = run.pcm_host[0], run.n_step      # stream 0's audio (the CPU baseline's sample at N > 1, after `run` is closed)
     for _ in range(args.warmup):
         run.step()
     run.drain()                                # pipelined steps: the last warm-up step's tokens are not the timed region's
@@ -703,20 +797,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
         om = ob.OracleModel(Wcpu, args.layers)
-        ost = ob.OracleStream(om, R)
-        ost.enable_decision_log()
         n_step = run.n_step
         p = run.pcm_host[0]
-        n_cpu_steps = max(2, min(int(args.cpu_seconds * synth.SAMPLE_RATE / n_step), p.size // n_step - 2))
-        ref_tokens = ost.process(p[:2 * n_step])            # warm-up: fills the first chunk
-        c0 = ost.total_chunks
-        tc = time.perf_counter()
-        for k in range(2, 2 + n_cpu_steps):
-            ref_tokens += ost.process(p[k * n_step:(k + 1) * n_step])
-        tcpu = time.perf_counter() - tc
-        cpu = dict(value=round(n_cpu_steps * n_step / synth.SAMPLE_RATE / tcpu, 3), unit="audio-s/s",
-                   cores=ob.lib().orc_num_threads(), kind="port",
-                   sample=f"{n_cpu_steps * n_step / synth.SAMPLE_RATE:.1f} s of stream 0 ({ost.total_chunks - c0} chunks, {tcpu:.1f} s), oracle/nasr_oracle.c f32 + OpenMP")
+        cpu, ost, ref_tokens, n_cpu_steps = cpu_baseline_sample(ob, om, synth, p, R, n_step, args.cpu_seconds)
         # engine tokens of stream 0 (warm-up + timed + host-PCM + profile steps, one continuous stream) vs the F32 oracle on the
         # same audio, cut at the frames both have decoded
         ref_frames, ref_log = ost.token_frames(), ost.decision_log()
@@ -885,13 +968,23 @@ def main():
             configs["b512_R13_q8_0"] = b
             brun.close()
 
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        # N > 1: the same baseline, after the last timed region (the other ranks are already in the closing barrier), on this rank's share
+        # of the host: threads = cores / world (set before the oracle library loads), so that a SCALE line is self-contained
+        os.environ.setdefault("NASR_ORACLE_THREADS", str(max(1, min(16, host_info()["affinity"] // world))))
+        from oracle import binding as ob
+        om = ob.OracleModel(W, args.layers)
+        cpu = cpu_baseline_sample(ob, om, synth, pcm0, R, n_step0, min(args.cpu_seconds, 30.0))[0]
+        cpu["sample"] += f"; rank 0 of {world}, threads = cores / {world}"
+        del om
+
     if rank == 0:
         workload = (f"nemotron-speech-streaming-0.6B ({args.layers} layers) {args.dtype}"
                     + (f" from {args.weights.upper()} tensors" if args.weights != "f32" else "") + f", batch={B} stream(s)/GPU, "
                     f"{80 * T} ms lookahead (R={R}), {world}xMI355X"
                     + (f", {args.chunks_per_step} chunks pushed per step" if args.chunks_per_step > 1 else "")
                     + (" [BASELINE.json configs[1]]" if headline_is_default else ""))
-        roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step", "frac_of_measured")
+        roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step", "frac_of_measured", "regime", "step_ms")
         sr = step_roofline(args.layers, B * args.chunks_per_step, R, step_s, {"f32": 2.0, "f16": 2.0, "q8_0": 34.0 / 32.0, "q4_0": 18.0 / 32.0}[args.weights])
         out = {
             "metric": "RTFx (audio-sec/sec), nemotron-0.6B streaming forward path",
@@ -923,6 +1016,7 @@ def main():
             "host_pcm_ms_per_step": host_pcm["ms_per_step"] if host_pcm else None,
             "pipeline8_ms_per_step": grouped_ms,
             "step_roofline": {"hbm_frac": sr["hbm_frac"], "mfma_frac": sr["mfma_frac"], "gbs": sr["gbs"]},
+            "timed_regime": timed_regime_block(f"b{B}_R{R}", depth, head["ms_per_step"], sr),
             "buffered_audio": buffered,
             "diarization": diar,
             "cpu_baseline_reference_cli": cpu_ref,
@@ -944,10 +1038,16 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _cleanup_shm():
+    import shutil
     for d in SHM_DIRS:
-        import shutil
         shutil.rmtree(d, ignore_errors=True)
+        shutil.rmtree(d.with_name(d.name + ".tmp"), ignore_errors=True)
 
 
 if __name__ == "__main__":
+    import atexit
+    atexit.register(_cleanup_shm)          # also on sys.exit / an exception; a SIGKILL leaves at most what remove_stale_shm() sweeps next time
     main()

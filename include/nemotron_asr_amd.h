@@ -120,7 +120,8 @@ void nasr_engine_destroy(nasr_engine *e);
  * 9 zero mel frames :73-74, cache_valid_len = 0 :81), nemo_stream_reset (:1307-1311),
  * nemo_stream_free (:1313-1317), nemo_stream_set_language (:735-749). ------------------ */
 int nasr_stream_create(nasr_engine *e, int right_context, int prompt_index, nasr_stream **out);
-/* reset == a fresh stream (every cache zeroed) */
+/* reset == a fresh stream: one launch clears the conv caches, decoder state, mel / audio buffers; the K/V rows go out of
+ * sight behind cache_valid_len = 0 (results bit-identical to a new engine's: tests/test_gpu_parity.py) */
 int nasr_stream_reset(nasr_stream *s);
 /* nemo_stream_reset AS CODED in the reference (src/nemo-stream.cpp:95-115, :31-34, :1307-1311): transcript, decoder state,
  * mel buffer (9 zero frames), cache_valid_len and the counters are reset, but the conv cache and the K/V rows are left as
@@ -212,12 +213,13 @@ enum {
  * large-M GEMM kernels of which two share a CU), "persistent_gemm" (1: GEMMs with several 128 x 128 tiles per CU on the persistent tile loop; default 0),
  * "wide_tiles" (default 1: 256- / 224-row tiles from 1 792 rows where their rounds fill the chip, in pipelined steps from 1 344 rows and 96 tiles;
  * 256: the 256-row form only; 3: without the pipelined steps' 96-tile rule; 0: off), 
- * "t64_tiles" (default 64, process-wide: the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles; round 3: 127),
+ * "t64_tiles" (default 64, per engine: the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles; round 3: 127),
  * "tile_bands" (-1 = the rule: above 4 row chunks the tiles of a launch are handed to the XCDs in bands of column groups, so that the panels an XCD reads stay in its L2;
  * 0 / 1 = never / always), "f32_mfma" (0: f32 GEMMs above
  * four rows on the FMA tile kernel instead of the f32 MFMA), "decode_graph_iterations" (>= 1, default 12: decode iterations a
  * pipelined step's decode graph carries before the eager fallback), "decode_lane" (0: the decode graphs run behind the last encoder
- * piece instead of on a stream of their own). */
+ * piece instead of on a stream of their own; read when the lanes are picked, so it is REJECTED after the first pipelined step or
+ * nasr_engine_lend_stream). */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 /* diagnostics: "graph_execs" (hipGraphExec objects alive), "graph_shapes" (distinct cached step shapes), "graph_evictions",
  * "graph_replays" (calls served by a hipGraph, pipelined ones included), "eager_steps" (calls that were not graph-eligible: ragged
@@ -227,8 +229,13 @@ int nasr_engine_set_option(nasr_engine *e, const char *key, int value);
 int nasr_engine_get_counter(const nasr_engine *e, const char *name, int64_t *value);
 /* enable recording of NASR_TAP_MEL / SUBSAMPLED / LAYER_OUT (costs extra copies) */
 int nasr_engine_set_debug(nasr_engine *e, int enable);
-/* returns the number of floats written (<= cap) or <0 */
+/* returns the number of floats written (<= cap) or <0.  NASR_TAP_K_CACHE / V_CACHE return the LOGICAL cache: rows that are not
+ * cached yet (the first 70 - cache_valid_len) read as the zeros the reference's tensors start with (src/nemo-stream.cpp:320-325). */
 int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, float *out, int64_t cap);
+/* test hook: overwrites every row of the stream's K/V rings (all layers) with +-value.  A stream start / reset does not clear the
+ * rings -- rows behind cache_valid_len are masked with -1e9 and weigh exactly 0, as in the reference's own reset
+ * (src/nemo-stream.cpp:95-115, :1037-1043) -- and this is how the tests prove that stale rows never reach a result. */
+int nasr_stream_debug_fill_kv(nasr_stream *s, float value);
 
 /* ---- measurement: per-kernel-class HIP-event timing on the engine's own
  * stream.  Replaces the std::chrono timers of src/nemo-stream.h:236-244. ---------------- */

@@ -28,7 +28,7 @@ EXPORTS = [
     "nasr_stream_get_stats", "nasr_stream_get_progress", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_engine_lend_stream", "nasr_device_alloc", "nasr_device_free",
-    "nasr_device_upload", "nasr_engine_synchronize", "nasr_engine_get_counter",
+    "nasr_device_upload", "nasr_engine_synchronize", "nasr_engine_get_counter", "nasr_stream_debug_fill_kv",
     "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_set_stream", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel",
 ]
 
@@ -76,6 +76,7 @@ def lib():
             getattr(L, f"nasr_stream_{n}").argtypes = [vp]
         L.nasr_stream_set_prompt.argtypes = [vp, C.c_int]
         L.nasr_stream_reset_ex.argtypes = [vp, C.c_int]
+        L.nasr_stream_debug_fill_kv.argtypes = [vp, C.c_float]
         L.nasr_stream_get_stats.argtypes = [vp, C.POINTER(StreamStats)]
         L.nasr_stream_get_progress.argtypes = [vp, C.POINTER(StreamStats)]
         L.nasr_diar_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(WeightDesc), C.c_int, C.c_int, C.c_int]
@@ -147,6 +148,10 @@ class Stream:
 
     def set_prompt(self, prompt_index: int):
         _chk(lib().nasr_stream_set_prompt(self.h, prompt_index))
+
+    def debug_fill_kv(self, value: float):
+        """test hook: every K/V ring row of this stream's slot := +-value (stale rows must never reach a result)"""
+        _chk(lib().nasr_stream_debug_fill_kv(self.h, float(value)))
 
     def destroy(self):
         if self.h:

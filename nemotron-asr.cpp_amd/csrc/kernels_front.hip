@@ -113,6 +113,45 @@ void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring
     hipLaunchKernelGGL(k_mel_zero, dim3(max_frames, B), dim3(NMEL), 0, st, desc, mel_ring);
 }
 
+// ---- stream start / reset in ONE launch (src/nemo-stream.cpp:36-93 ::init, :95-115 ::reset) ----------------------------------
+// Rounds 1-4 issued 2 hipMemsetAsync per layer + 5 on the engine's stream for every stream that started (53 fills, 32 MB zeroed, in
+// front of the next step of every live stream).  What a fresh stream needs is much less: the conv caches (64 KB per layer), the decoder
+// state, the 9 literal-zero mel frames the first chunk reads, the 256 zero samples the audio buffer is pre-seeded with, last_sample
+// and the decoder control block.  The K/V rings are NOT touched: cache_valid_len = 0 hides every cached row behind the -1e9 mask
+// (weight exactly 0, :1037-1043 -- the reference's own reset relies on it, :95-115), the pool is zeroed once at nasr_engine_create and only
+// ever holds finite values the engine wrote itself (tests/test_gpu_parity.py::test_stale_kv_rows_never_reach_a_result).
+// blocks [0, n_layers): conv cache of that layer (skipped when the reference's reset semantics are asked for); block n_layers: the rest.
+__global__ __launch_bounds__(256) void k_stream_reset(StreamResetParams p) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((int)blockIdx.x < p.n_layers) {
+        if (p.keep_reference_state) return;
+        float4 *cc = (float4 *)(p.cc_pools[blockIdx.x] + (size_t)p.slot * p.cc_slot_floats);
+        for (int i = threadIdx.x; i < p.cc_slot_floats / 4; i += 256) cc[i] = z4;
+        return;
+    }
+    const size_t slot = (size_t)p.slot;
+    for (int i = threadIdx.x; i < 4 * HID / 4; i += 256) {
+        ((float4 *)(p.dec_h + slot * 4 * HID))[i] = z4;
+        ((float4 *)(p.dec_c + slot * 4 * HID))[i] = z4;
+    }
+    for (int i = threadIdx.x; i < PRE_CACHE * NMEL / 4; i += 256) ((float4 *)(p.mel_ring + slot * MEL_RING * NMEL))[i] = z4;   // mel_start = 0
+    if (!p.keep_reference_state) {
+        for (int i = threadIdx.x; i < NFFT / 2 / 4; i += 256) ((float4 *)(p.abuf + slot * 2 * ABUF_CAP))[i] = z4;              // parity 0, src/preprocessor.cpp:220-221
+        if (threadIdx.x == 0) p.last_sample[slot] = 0.0f;
+    }
+    if (threadIdx.x == 0) {
+        DecCtrl c;
+        c.t = 0; c.n_frames = 0; c.symbols = 0; c.prev_token = BLANK;      // src/nemo-stream.cpp:55-56
+        c.cur = 0; c.n_tok = 0; c.active = 0; c.iterations = 0; c.row = 0;
+        c.dirty = 1;                                                       // no LSTM candidate computed yet
+        c.frame0 = 0; c.frame_next = 0;
+        p.ctrl[slot] = c;
+    }
+}
+void launch_stream_reset(const StreamResetParams &p, hipStream_t st) {
+    hipLaunchKernelGGL(k_stream_reset, dim3(p.n_layers + 1), dim3(256), 0, st, p);
+}
+
 // ---- conv0 (3x3 stride-2, 1 -> 256 channels, + ReLU) fused into the first depthwise 3x3 stride-2 conv ----
 // (src/nemo-ggml.cpp:969-978, pads (2 before, 1 after) on both axes :905-913, :936-943).  conv0's output
 // [H1][65][256] f32 is 9x larger than its input and was the largest intermediate of the step (260 MB at 64

@@ -946,16 +946,16 @@ void init_gemm_kernel_attributes() {
 // Round 4: for the split-K GEMMs only up to 64 tiles of 128 x 128 (M <= 1 024).  Above that two K-halves of 128 x 128 tiles fill the chip by themselves
 // (72-120 tiles x 2 <= 256 workgroups) where the half-width form makes 288-480 workgroups of a shape that moves 1.5 x the operand bytes per flop: 112 streams
 // x R = 13 (104 tiles) synchronous 5.92 -> 5.30 ms, pipelined 3.82 -> 3.77; 128 streams (112 tiles) pipelined 4.21 -> 4.14, synchronous 5.52 -> 5.69
-// (profiles/r4_tile_order.md).  Engine option "t64_tiles" (process-wide: the choice is made in two places that must agree).
-static int g_t64_part_tiles = 64;
-void gemm_set_t64_part_tiles(int tiles) { g_t64_part_tiles = tiles; }
-bool gemm_use_t64(int M, int N, int epi) {
+// (profiles/r4_tile_order.md).  Engine option "t64_tiles" (the choice is made in two places that must agree: both read GemmParams::t64_tiles_p1).
+// t64_p1 = GemmParams::t64_tiles_p1 (the engine's option + 1; 0 = the default of 64): carried per GEMM so that several engines in one
+// process cannot change each other's choice between the two places that must agree (round-4 advisor: it was a process-wide global).
+bool gemm_use_t64(int M, int N, int epi, int t64_p1) {
     if (M <= gemm_skinny_max_m()) return false;
     const int tiles = (N / 128) * ((M + 127) / 128);
-    if (epi == EPI_PART_F32) return N == 1024 && tiles <= g_t64_part_tiles;
+    if (epi == EPI_PART_F32) return N == 1024 && tiles <= (t64_p1 > 0 ? t64_p1 - 1 : 64);
     return tiles <= 64;
 }
-int gemm_tile_n(int M, int N, int epi) { return gemm_use_t64(M, N, epi) ? 64 : 128; }
+int gemm_tile_n(int M, int N, int epi, int t64_p1) { return gemm_use_t64(M, N, epi, t64_p1) ? 64 : 128; }
 
 // Largest M served by the weight-streaming ("skinny") kernel; above it the LDS-tiled kernels take over.  Round 1 had 128 (chosen
 // on synchronous steps).  Re-measured in round 2 (ms per step, <= 32 / <= 64 / <= 128 rows skinny):
@@ -984,7 +984,7 @@ static bool gemm_coresident(const GemmParams &p) {
     // (cold operands, us per launch, deep / shallow: 1 792 rows pw1 224 tiles 12.6 / 16.7, W2 112 tiles 28.3 / 32.4; 3 584 rows W2 224 tiles
     // 34.7 / 45.1, Wo 12.0 / 14.8 -- profiles/r4_tile_order.md)
     if (p.coresident == 1 && p.M >= min_m) return true;
-    const long tiles = (long)(p.N / (gemm_use_t64(p.M, p.N, p.epi) ? 64 : 128)) * ((p.M + TM - 1) / TM) * (p.splits < 1 ? 1 : p.splits);
+    const long tiles = (long)(p.N / (gemm_use_t64(p.M, p.N, p.epi, p.t64_tiles_p1) ? 64 : 128)) * ((p.M + TM - 1) / TM) * (p.splits < 1 ? 1 : p.splits);
     return p.M >= 1792 && tiles > g_num_cus;
 }
 
@@ -998,7 +998,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_skinny<4>, grid, dim3(256), 0, st, p);
     } else {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
-        if (gemm_use_t64(p.M, p.N, p.epi)) {       // half-width tiles: the caller chose splits for N / 64 column groups (gemm_tile_n)
+        if (gemm_use_t64(p.M, p.N, p.epi, p.t64_tiles_p1)) {       // half-width tiles: the caller chose splits for N / 64 column groups (gemm_tile_n)
             n_groups = p.N / 64;
             if (gemm_coresident(p))      // 3 slots = 72 KiB: two workgroups per CU
                 hipLaunchKernelGGL(k_gemm_t64<3>, dim3(n_groups * m_chunks * p.splits), dim3(512), 3 * T64_SLOT, st, p, n_groups, m_chunks);

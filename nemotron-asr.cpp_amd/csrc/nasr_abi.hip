@@ -9,18 +9,16 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     else if (!strcmp(key, "graph_cache")) { if (value < 1) return fail("graph_cache must be >= 1"); e->opt_graph_cache = value; }
     else if (!strcmp(key, "multichunk")) e->opt_multichunk = value != 0;
     else if (!strcmp(key, "large_step_pieces")) { if (value < 0 || value > nasr_engine::MAXSEG) return fail("large_step_pieces must be 0 .. %d", (int)nasr_engine::MAXSEG); e->opt_large_step_pieces = value; }
-    else if (!strcmp(key, "t64_tiles")) { if (value < 0) return fail("t64_tiles must be >= 0"); gemm_set_t64_part_tiles(value); }      // process-wide; before the first step
+    else if (!strcmp(key, "t64_tiles")) { if (value < 0) return fail("t64_tiles must be >= 0"); e->opt_t64_tiles = value; }      // like "fused": set before the first step
     else if (!strcmp(key, "tile_bands")) e->opt_tile_bands = value;
     else if (!strcmp(key, "wide_tiles")) e->opt_wide_tiles = value;              // like "fused": set before the first step
     else if (!strcmp(key, "persistent_gemm")) e->opt_persist_gemm = value != 0;      // like "fused": set before the first step
     else if (!strcmp(key, "gemm_cores")) { if (value < -1 || value > 1) return fail("gemm_cores must be -1, 0 or 1"); e->opt_gemm_cores = value; }
     else if (!strcmp(key, "decode_graph_iterations")) { if (value < 1) return fail("decode_graph_iterations must be >= 1"); e->opt_decode_graph_iters = value; }
     else if (!strcmp(key, "decode_lane")) {
-        ApiGuard api_guard;
-        HIPCHK(hipSetDevice(e->device));
-        if (pipe_drain(e)) return -1;
+        // read by pick_lanes() only, and the lanes are picked once: later the option would be a silent no-op (round-4 advisor)
+        if (e->pipe_ready) return fail("decode_lane must be set before the first pipelined step (the lanes are already picked)");
         e->opt_decode_lane = value != 0;
-        release_lanes(e);                       // the lanes are picked again on the next pipelined step
     }
     else if (!strcmp(key, "f32_mfma")) e->opt_f32_mfma = value != 0;      // 0: f32 GEMMs above four rows on the FMA tile kernel (round 3's path); like "fused", set before the first step
     else if (!strcmp(key, "pipeline")) {
@@ -549,6 +547,10 @@ extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, flo
         HIPCHK(hipMemcpy(raw.data(), (char *)e->kv_pool[index] + (slot * 2 + v) * KVC * D * e->esz, raw.size(), hipMemcpyDeviceToHost));
         for (int j = 0; j < LCTX; j++) {   // logical order: ring[(kv_head + j) % KVC]
             const int ring = (s->kv_head + j) % KVC;
+            if (j < LCTX - s->valid_len) {     // not cached yet: the reference's tensor holds its initial zeros there (src/nemo-stream.cpp:320-325); here the
+                for (int d = 0; d < D; d++) out[(size_t)j * D + d] = 0.0f;      // ring may hold an earlier stream's rows, which no kernel ever weighs (the mask)
+                continue;
+            }
             for (int d = 0; d < D; d++) {
                 if (e->bf16) {
                     uint32_t u = (uint32_t)((const uint16_t *)raw.data())[(size_t)ring * D + d] << 16;
@@ -576,6 +578,26 @@ extern "C" int64_t nasr_stream_get_tap(nasr_stream *s, int which, int index, flo
     }
     }
     return fail("unknown tap %d", which);
+}
+
+// test hook: every K/V ring row of the stream's slot, in every layer, := value (see the header)
+extern "C" int nasr_stream_debug_fill_kv(nasr_stream *s, float value) {
+    ApiGuard api_guard;
+    if (!s) return fail("null stream");
+    nasr_engine *e = s->e;
+    HIPCHK(hipSetDevice(e->device));
+    if (pipe_drain(e)) return -1;
+    const size_t n = (size_t)2 * KVC * D;
+    std::vector<char> host(n * e->esz);
+    for (size_t i = 0; i < n; i++) {
+        const float v = (i & 1) ? -value : value;
+        if (e->bf16) { uint32_t u; memcpy(&u, &v, 4); ((uint16_t *)host.data())[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+        else ((float *)host.data())[i] = v;
+    }
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (int l = 0; l < e->hp.n_layers; l++)
+        HIPCHK(hipMemcpy((char *)e->kv_pool[l] + (size_t)s->slot * n * e->esz, host.data(), host.size(), hipMemcpyHostToDevice));
+    return 0;
 }
 
 extern "C" int nasr_engine_profile(nasr_engine *e, int enable) {

@@ -19,6 +19,7 @@ int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
     g.no_wide = e->opt_wide_tiles ? 0 : 1;
     g.wide_rows = e->opt_wide_tiles == 256 ? 256 : e->opt_wide_tiles == 3 ? 2 : 0;
     g.tile_bands = e->opt_tile_bands < 0 ? 0 : e->opt_tile_bands == 0 ? 2 : 1;
+    g.t64_tiles_p1 = e->opt_t64_tiles + 1;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);
     return 0;
@@ -28,7 +29,7 @@ int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
 int pick_splits(const nasr_engine *e, int M, int N, int K) {
     if (!e->bf16) return 1;
     const bool skinny = M <= gemm_skinny_max_m();
-    int tasks = skinny ? (N / 16) * ((M + 63) / 64) : (N / gemm_tile_n(M, N, EPI_PART_F32)) * ((M + 127) / 128);
+    int tasks = skinny ? (N / 16) * ((M + 63) / 64) : (N / gemm_tile_n(M, N, EPI_PART_F32, e->opt_t64_tiles + 1)) * ((M + 127) / 128);
     // partial traffic grows with the split factor, and with pipelined steps the CUs a launch leaves idle run another chain's
     // kernels: four splits only up to 40 tiles (three lanes, R = 13: 12 / 16 streams = 32 tiles 1.15 / 1.23 ms with 4 splits
     // against 1.23 / 1.30 with 2; 24 streams = 48 tiles 1.53 vs 1.50; 32 streams = 64 tiles 1.82 vs 1.68; 64 streams = 112 tiles:

@@ -488,6 +488,13 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
         rc |= dalloc(e, &kp, S * 2 * KVC * D * e->esz);
         e->kv_pool[l] = kp;
         rc |= dalloc(e, &e->cc_pool[l], S * 2 * ks1 * D);
+        // the K/V rings are zeroed HERE and never again: a stream that starts on a used slot finds the previous stream's rows,
+        // all finite, all behind the validity mask (stream_zero_state)
+        if (!rc && hipMemsetAsync(kp, 0, S * 2 * KVC * D * e->esz, e->st) != hipSuccess) rc = fail("hipMemsetAsync (K/V pool) failed");
+    }
+    if (!rc) {
+        rc |= dalloc(e, &e->cc_ptrs_dev, Lr);
+        if (!rc && hipMemcpy(e->cc_ptrs_dev, e->cc_pool.data(), Lr * sizeof(float *), hipMemcpyHostToDevice) != hipSuccess) rc = fail("hipMemcpy (conv-cache table) failed");
     }
     rc |= dalloc(e, &e->dec_h, S * 4 * HID);
     rc |= dalloc(e, &e->dec_c, S * 4 * HID);
@@ -650,26 +657,16 @@ void engine_destroy_impl(nasr_engine *e) {
 // -1e9 and weight exactly 0) and the preprocessor's carry (un-framed samples, last_sample) survive.
 int stream_zero_state(nasr_stream *s, bool keep_reference_state) {
     nasr_engine *e = s->e;
-    const size_t slot = (size_t)s->slot, ks1 = (size_t)e->hp.kernel_size - 1;
-    if (!keep_reference_state) {
-        for (int l = 0; l < e->hp.n_layers; l++) {
-            HIPCHK(hipMemsetAsync((char *)e->kv_pool[l] + slot * 2 * KVC * D * e->esz, 0, (size_t)2 * KVC * D * e->esz, e->st));
-            HIPCHK(hipMemsetAsync(e->cc_pool[l] + slot * 2 * ks1 * D, 0, 2 * ks1 * D * 4, e->st));
-        }
-        HIPCHK(hipMemsetAsync(e->abuf + slot * 2 * ABUF_CAP, 0, (size_t)2 * ABUF_CAP * 4, e->st));
-        HIPCHK(hipMemsetAsync(e->last_sample + slot, 0, 4, e->st));
-    }
-    HIPCHK(hipMemsetAsync(e->dec_h + slot * 4 * HID, 0, 4 * HID * 4, e->st));
-    HIPCHK(hipMemsetAsync(e->dec_c + slot * 4 * HID, 0, 4 * HID * 4, e->st));
-    HIPCHK(hipMemsetAsync(e->mel_ring + slot * MEL_RING * NMEL, 0, (size_t)MEL_RING * NMEL * 4, e->st));
-    DecCtrl c;
-    memset(&c, 0, sizeof(c));
-    c.prev_token = BLANK;                      // src/nemo-stream.cpp:55-56
-    c.dirty = 1;                               // no LSTM candidate computed yet
-    std::vector<DecCtrl> cv(1, c);
-    const DecCtrl *dsrc;
-    if (stage_desc(e, cv, &dsrc)) return -1;
-    HIPCHK(hipMemcpyAsync(e->ctrl + slot, dsrc, sizeof(DecCtrl), hipMemcpyDeviceToDevice, e->st));
+    // ONE launch (k_stream_reset, kernels_front.hip); the K/V rings are left alone: zeroed once at nasr_engine_create, hidden by
+    // cache_valid_len = 0 afterwards (rounds 1-4: 53 fills of 32 MB per stream start on the engine's stream)
+    StreamResetParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.cc_pools = e->cc_ptrs_dev; rp.n_layers = e->hp.n_layers; rp.slot = s->slot;
+    rp.cc_slot_floats = 2 * (e->hp.kernel_size - 1) * D;
+    rp.keep_reference_state = keep_reference_state ? 1 : 0;
+    rp.abuf = e->abuf; rp.last_sample = e->last_sample; rp.mel_ring = e->mel_ring; rp.dec_h = e->dec_h; rp.dec_c = e->dec_c; rp.ctrl = e->ctrl;
+    launch_stream_reset(rp, e->st);
+    HIPCHK(hipGetLastError());
     if (!keep_reference_state) {
         s->abuf_cnt = NFFT / 2;                // 256 zero samples pre-seeded, src/preprocessor.cpp:220-221
         s->abuf_par = 0;

@@ -120,6 +120,7 @@ struct nasr_engine {
     float *abuf, *last_sample, *mel_ring;
     std::vector<void *> kv_pool;     // per layer [slot][2][KVC][1024] act dtype
     std::vector<float *> cc_pool;    // per layer [slot][2][ks-1][1024]
+    float **cc_ptrs_dev = nullptr;   // device copy of cc_pool (k_stream_reset walks the layers in one launch)
     float *dec_h, *dec_c;
     DecCtrl *ctrl;
     int *tok_ring;
@@ -138,6 +139,7 @@ struct nasr_engine {
     bool opt_decode_lane = true;       // the decode graphs get a lane of their own when a queue is free (option "decode_lane")
     int opt_gemm_cores = -1;           // -1: the engine's rule; 0 / 1: never / always the GEMM kernels of which two share a CU (option "gemm_cores")
     int opt_large_step_pieces = 3;   // option "large_step_pieces": most pieces of a pipelined step of 3 584 rows and more (0 = as many as "pipeline" says)
+    int opt_t64_tiles = 64;          // option "t64_tiles": the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles (per engine, carried in GemmParams)
     int opt_tile_bands = -1;         // option "tile_bands": -1 = the rule (bands of column groups above 4 row chunks), 0 = never, 1 = always (same bits)
     int opt_wide_tiles = 1;          // option "wide_tiles": 256- / 224-row GEMM tiles from 1 792 rows where they fill the chip (k_gemm_wide; same bits); 256 = the 256-row form only, 0 = off
     bool opt_persist_gemm = false;   // option "persistent_gemm" = 1: GEMMs with >= 1.75 tiles of 128 x 128 per CU on the persistent tile loop (k_gemm_persist; same bits).  Off by default: alone on the chip with cache-resident operands it is 14-37 % faster at 7 168 rows, inside the engine (weights cold from HBM) 1 % -- profiles/r4_persistent_gemm.md

@@ -129,14 +129,15 @@ struct GemmParams {
     // tile order of the LDS-tiled bf16 kernels (tile_of(), kernels_gemm.hip): 0 = bands of column groups above 4 row chunks, 1 = always,
     // 2 = never (the row chunk fastest; engine option "tile_bands" = 0: the order of rounds 1-3)
     int tile_bands;
+    // engine option "t64_tiles" + 1 (0 = the default, 64): the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles
+    int t64_tiles_p1;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
 void init_gemm_kernel_attributes();    // one-time hipFuncSetAttribute calls (never inside a stream capture)
 void init_fused_kernel_attributes();
 int gemm_skinny_max_m();     // largest M served by the weight-streaming kernel
-int gemm_tile_n(int M, int N, int epi);
-void gemm_set_t64_part_tiles(int tiles);      // engine option "t64_tiles"   // output-tile width the large-M kernel will use (128, or 64 for the N = 1024 split-K GEMMs)
+int gemm_tile_n(int M, int N, int epi, int t64_tiles_p1);      // output-tile width the large-M kernel will use (128, or 64 for the N = 1024 split-K GEMMs); t64_tiles_p1 as in GemmParams
 void launch_gemm_bf16(const GemmParams &p, hipStream_t st);
 void launch_gemm_f32(const GemmParams &p, hipStream_t st);
 void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st);
@@ -156,6 +157,15 @@ struct MelParams {
 void launch_mel(const MelParams &p, int max_n, hipStream_t st);
 void launch_mel_put(const float *staged, const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
 void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
+struct StreamResetParams {      // one launch per stream start / reset (kernels_front.hip: k_stream_reset)
+    float *const *cc_pools;     // device array [n_layers] of the layers' conv-cache pools
+    int n_layers, slot;
+    int cc_slot_floats;         // 2 * (ks - 1) * 1024
+    int keep_reference_state;   // NASR_RESET_REFERENCE: conv caches, audio-buffer carry and last_sample survive
+    float *abuf, *last_sample, *mel_ring, *dec_h, *dec_c;
+    DecCtrl *ctrl;
+};
+void launch_stream_reset(const StreamResetParams &p, hipStream_t st);
 
 void launch_sub_conv0_dw(const RowDesc *rows, int B, int chunk_mel, const float *mel_ring, const float *w0t, const float *b0,
                          const float *w2t, const float *b2, void *out, int out_bf16, int H1, int W1, hipStream_t st);

@@ -83,7 +83,15 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
-    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE... | chunks T SAMPLES...\n", argv[0]); return 2; }
+    if (argc >= 4 && !strcmp(argv[1], "jsonint")) {     // jsonint DEFAULT JSON...: what the server's right_context would be after json_int (host logic test)
+        for (int i = 3; i < argc; i++) {
+            int v = atoi(argv[2]);
+            const bool found = nasr_proto::json_int(argv[i], "right_context", v);
+            printf("%d %d\n", found ? 1 : 0, v);
+        }
+        return 0;
+    }
+    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE... | chunks T SAMPLES... | jsonint DEFAULT JSON...\n", argv[0]); return 2; }
     int rc = 0;
     for (int i = 2; i < argc; i++) rc |= !strcmp(argv[1], "gguf") ? run_gguf(argv[i]) : run_frames(argv[i]);
     return rc;

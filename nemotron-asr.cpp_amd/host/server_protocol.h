@@ -41,7 +41,17 @@ inline bool json_int(const std::string &j, const char *key, int &out) {
     if (p == std::string::npos) return false;
     p = j.find(':', p + k.size());
     if (p == std::string::npos) return false;
-    out = atoi(j.c_str() + p + 1);
+    // like the reference's json_get_int (src/nemo-server.cpp:172-188): blanks, an optional '-', at least one digit -- anything else
+    // (null, a string, a bare word) leaves `out` alone and returns false, so the server keeps its default; the value is clamped
+    // instead of overflowing (round-4 advisor: atoi returned 0 for "13" / null and overrode --right-context)
+    const char *c = j.c_str() + p + 1;
+    while (*c == ' ' || *c == '\t') c++;
+    bool neg = false;
+    if (*c == '-') { neg = true; c++; }
+    if (*c < '0' || *c > '9') return false;
+    long long v = 0;
+    for (; *c >= '0' && *c <= '9'; c++) { v = v * 10 + (*c - '0'); if (v > 2147483647LL) v = 2147483647LL; }
+    out = (int)(neg ? -v : v);
     return true;
 }
 

@@ -126,6 +126,17 @@ def test_mutated_wire_frames(harness, tmp_path):
     assert len(out) == len(files) and all(line.startswith("ok: ") for line in out), [line for line in out if not line.startswith("ok: ")][:3]
 
 
+def test_json_int_keeps_the_default_on_non_numbers(harness):
+    """The reference's json_get_int (src/nemo-server.cpp:172-188) returns false on anything that is not a number and the server keeps its
+    --right-context default; round 4's atoi form returned 0 for null / "13" / a bare word and silently overrode it (advisor)."""
+    cases = ['{"right_context":13}', '{"right_context": 6 }', '{"right_context":\t1}', '{"right_context":-7}', '{"right_context":null}',
+             '{"right_context":"13"}', '{"right_context":abc}', '{"right_context":}', '{"lang":"en"}', '{"right_context": 99999999999999999999}',
+             '{"right_context":-99999999999999999999}', '{"right_context":']
+    out = subprocess.run([str(harness), "jsonint", "13"] + cases, capture_output=True, text=True, check=True).stdout.split("\n")
+    got = [tuple(int(x) for x in line.split()) for line in out if line]
+    assert got == [(1, 13), (1, 6), (1, 1), (1, -7), (0, 13), (0, 13), (0, 13), (0, 13), (0, 13), (1, 2147483647), (1, -2147483647), (0, 13)]
+
+
 def test_oracle_streaming_session_under_asan_and_ubsan(tmp_path):
     """The oracle (the checker of every parity test) itself under ASan + UBSan: a two-layer model, ragged pushes at R = 0 and R = 13,
     the bf16-emulating mode, the decision log, reset in the reference's mode, the tail flush, the
