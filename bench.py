@@ -137,6 +137,7 @@ def parse(argv=None):
     ap.add_argument("--checkpoint", default="speech", choices=["speech", "random"],
                     help="speech: joint fitted to the phone inventory of the synthetic speech audio (wide top-2 margins, token-exact "
                          "at reduced precision); random: the near-tie stress checkpoint (N(0, s^2) logits)")
+    ap.add_argument("--no-grouped", action="store_true", help="skip the pipeline = 8 (grouped launches) leg of the headline workload")
     ap.add_argument("--no-b512", action="store_true", help="skip the 512-streams-on-one-GPU entry")
     ap.add_argument("--no-f32-engine", action="store_true", help="skip the f32-engine entry (the configuration that is exact in every bit of its tokens)")
     ap.add_argument("--no-host-pcm", action="store_true", help="skip the host-PCM (H2D inside the timed region) figure")
@@ -229,8 +230,8 @@ def timed_regime_block(tag, depth, ms_per_step, sr):
     if f.exists():
         try:
             t = json.loads(f.read_text())
-            out.update(kernel_ms_per_step=t["kernel_ms_per_step"], busy_ms_per_step=t["busy_ms_per_step"], overlap=t["overlap"],
-                       profiled_ms_per_step=t["ms_per_step"], dominant=t["dominant"], source=f"profiles/{f.name}")
+            out.update(kernel_ms_per_step=t["kernel_ms_per_step"], avg_kernels_in_flight=t.get("avg_kernels_in_flight"), in_flight_share=t.get("in_flight_share"),
+                       stamped_ms_per_step=t["ms_per_step"], dominant=t["dominant"], source=f"profiles/{f.name}")
         except (ValueError, KeyError):
             pass
     return out
@@ -642,7 +643,7 @@ def main():
 
     # the grouped pipeline (option pipeline = 8: 8 steps in flight, four steps per launch) on the same run, for the record
     grouped_ms = None
-    if depth == 4 and B * T * args.chunks_per_step <= 2 and args.dtype == "bf16" and args.layers % 8 == 0:
+    if depth == 4 and B * T * args.chunks_per_step <= 2 and args.dtype == "bf16" and args.layers % 8 == 0 and not args.no_grouped:
         run.eng.set_option("pipeline", 8)
         for _ in range(12):
             run.step()

@@ -75,6 +75,30 @@ def main(path):
     for r in rows:
         byk[r["k"] % 8].append((r["end"] - r["start"]) / 100)
     print("duration by kernel of the layer (us):", ", ".join(f"{NAMES[k]} {sum(v) / len(v):.2f}" for k, v in sorted(byk.items())))
+    if len(sys.argv) > 2:
+        # round 5: the same numbers as JSON (bench.py's `timed_regime` block reads profiles/r5_<tag>_pipelined_trace.json).  rocprofv3 cannot give
+        # them: its queue interception serialises the lanes (profiles/r5_b1_R0_pipelined_kernel_stats.md: 4.0 ms per step under the profiler)
+        import json
+        n_launch = len({(r["ps"], r["k"]) for r in rows})
+        per_step = max(r["k"] for r in rows) + 1                     # fused launches of one step (8 x layers)
+        avg_us = sum(durs) / len(durs)
+        busy = sum(v for k, v in occ.items() if k >= 1)
+        clipped = sum(min(r["end"], hi) - max(r["start"], lo) for r in rows if r["end"] > lo)
+        ms_per_step = float(sys.argv[3]) if len(sys.argv) > 3 else None
+        j = dict(source="in-kernel s_memrealtime stamps of the diagnostic build (make -C nemotron-asr.cpp_amd/csrc stamps; tests/micro/stamps_timeline.py): first / last "
+                        "workgroup of every fused-layer launch of the last five steps; front end and decode launches are not stamped",
+                 steps_in_file=round(n_launch / per_step, 2), launches_per_step=per_step, ms_per_step=ms_per_step,
+                 kernel_ms_per_step=round(per_step * avg_us / 1e3, 4),
+                 busy_ms_per_step=round(per_step * avg_us / 1e3 * busy / max(1, clipped), 4),
+                 overlap=round(clipped / max(1, busy), 3),          # over the stamped window, which ends with the drain of the pipeline (fewer lanes busy)
+                 avg_kernels_in_flight=round(per_step * avg_us / 1e3 / ms_per_step, 3) if ms_per_step else None,      # sum of kernel time per step / ms_per_step: the steady-state figure
+                 in_flight_share={str(k): round(v / tot, 4) for k, v in sorted(occ.items())},
+                 dominant=dict(kernel="k_fused_skinny<LN> (ln+W1, ln+QKV, ln+pw1, ln+W1': 4 of a layer's 8 launches)",
+                               calls_per_step=per_step // 2, avg_us=round(sum(sum(byk[k]) for k in (0, 2, 4, 6)) / max(1, sum(len(byk[k]) for k in (0, 2, 4, 6))), 3)),
+                 kernel_us=dict(p10=pct(durs, .1), p50=pct(durs, .5), p90=pct(durs, .9)), gap_us=dict(p10=pct(gaps, .1), p50=pct(gaps, .5), p90=pct(gaps, .9)),
+                 by_kernel_us={NAMES[k]: round(sum(v) / len(v), 3) for k, v in sorted(byk.items())})
+        json.dump(j, open(sys.argv[2], "w"), indent=1)
+        print("json ->", sys.argv[2])
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 # usage: tests/prof_r5.sh <tag> [bench args...]      (on the GPU box, through gpurun)
 # Kernel-level evidence for ONE bench configuration in the regime it is TIMED in (pipelined steps unless PROF_MODE=--sync-steps):
 #   1. rocprofv3 --kernel-trace --stats   -> gpurun_out/r5_<tag>_kernel_stats.{csv,md}   (per-kernel calls / average / total)
-#                                            gpurun_out/r5_<tag>_trace.json: from the dispatch time stamps of the trace, over the timed steps:
+#                                            gpurun_out/r5_<tag>_rocprof_trace.json: from the dispatch time stamps of the trace, over the timed steps:
 #                                            sum of kernel durations per step (all lanes), wall time covered by at least one kernel per step
 #                                            ("busy"), overlap = sum / busy, time share with 1 / 2 / 3 / 4+ kernels in flight, the dominant kernel
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only; MI355X_MICROARCH.md, HBM: bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB)
@@ -12,7 +12,7 @@
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 STEPS=${PROF_STEPS:-24}
-ARGS="--no-cpu-baseline --no-profile-pass --no-buffered --no-extra-configs --no-host-pcm --no-b512 --no-f32-engine --regions 1 ${PROF_MODE-} --steps $STEPS --warmup 3 $*"
+ARGS="--no-grouped --no-cpu-baseline --no-profile-pass --no-buffered --no-extra-configs --no-host-pcm --no-b512 --no-f32-engine --regions 1 ${PROF_MODE-} --steps $STEPS --warmup 3 $*"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/prof_$TAG.log 2>&1
 echo "stats pass rc=$? segv=$(grep -c SIGSEGV $OUT/prof_$TAG.log) $(grep -o '"ms_per_step": [0-9.]*' $OUT/prof_$TAG.log | head -1)"
@@ -22,7 +22,7 @@ for C in ${PROF_COUNTERS-FETCH_SIZE WRITE_SIZE}; do      # PROF_COUNTERS="" skip
 done
 python3 - <<PY
 import csv, glob, json, collections, re
-out = "$OUT"; tag = "$TAG"; steps = int("$STEPS")
+out = "$OUT"; tag = "$TAG"; steps = int('$STEPS')
 log = open(f"{out}/prof_{tag}.log", errors="replace").read()
 m = re.search(r'"ms_per_step": ([0-9.]+)', log)
 ms_per_step = float(m.group(1)) if m else None
@@ -47,7 +47,7 @@ if ft:
         except (KeyError, ValueError):
             pass
     ev.sort()
-    # one k_preemph launch per step: the timed region = the last `steps` of them
+    # one k_preemph launch per step: the timed region = the last STEPS of them
     pre = [a for a, b, n in ev if "k_preemph" in n]
     if len(pre) > steps:
         t0 = pre[len(pre) - steps]
@@ -74,7 +74,7 @@ if ft:
                                ms_per_step=round(dom[1][1] / 1e6 / steps, 4)),
                  kernels_per_step={n[:80]: dict(calls=round(v[0] / steps, 2), avg_us=round(v[1] / v[0] / 1e3, 3), ms=round(v[1] / 1e6 / steps, 4))
                                    for n, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:16]})
-        json.dump(j, open(f"{out}/r5_{tag}_trace.json", "w"), indent=1)
+        json.dump(j, open(f"{out}/r5_{tag}_rocprof_trace.json", "w"), indent=1)
         print("trace:", {k: j[k] for k in ("ms_per_step", "window_ms_per_step", "kernel_ms_per_step", "busy_ms_per_step", "overlap", "in_flight_share")})
         print("dominant:", j["dominant"])
     else:
