@@ -217,7 +217,11 @@ enum {
  * "tile_bands" (-1 = the rule: above 4 row chunks the tiles of a launch are handed to the XCDs in bands of column groups, so that the panels an XCD reads stay in its L2;
  * 0 / 1 = never / always), "f32_mfma" (0: f32 GEMMs above
  * four rows on the FMA tile kernel instead of the f32 MFMA), "decode_graph_iterations" (>= 1, default 12: decode iterations a
- * pipelined step's decode graph carries before the eager fallback), "decode_lane" (0: the decode graphs run behind the last encoder
+ * pipelined step's decode graph carries before the eager fallback), "resid_epilogue" (0: every residual GEMM writes split-K partial
+ * slabs and k_post adds them, as in rounds 1-4; default 1: the GEMM adds to the residual stream in its epilogue where one workgroup owns a tile's
+ * whole K sum -- same bits), "ablate" (MEASUREMENT ONLY -- results
+ * are invalid: bit mask of launches left out of a step: 1 residual + LayerNorm, 2 attention, 4 depthwise conv, 8 decode iterations, 16 front end, 32 encoder
+ * GEMMs; what each costs a pipelined step: profiles/r5_ablation.md), "decode_lane" (0: the decode graphs run behind the last encoder
  * piece instead of on a stream of their own; read when the lanes are picked, so it is REJECTED after the first pipelined step or
  * nasr_engine_lend_stream). */
 int nasr_engine_set_option(nasr_engine *e, const char *key, int value);

@@ -23,6 +23,7 @@
 #include "nasr_internal.h"
 #include "nasr_epilogue.h"
 #include "nasr_wave.h"
+#include "nasr_post.h"
 
 namespace nasr {
 
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmParams p) {
 }
 
 constexpr int TM = 128;
+constexpr int TM_ROWS = 128;          // rows of a row chunk whose publication a chained launch counts (= TM)
 
 __device__ __forceinline__ int panel_off(int row, int chunk) {  // byte offset in a [128][64] bf16 panel
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -283,6 +285,50 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2(GemmParams p, int n_groups,
 // Panel rows are 64 B here, so four rows share a 256-byte bank line: 16-byte column c of row r lives at column c ^ ((-(r >> 2)) & 3)
 // (conflict-free for the four 16-lane groups a ds_read_b128 is served in: MI355X_MICROARCH.md, LDS).
 // ------------------------------------------------------------------------------------
+// ---- chained launches (ChainParams, nasr_internal.h): head workgroups = the k_post that produces this launch's A rows ----------------------
+template <int NT>
+__device__ __forceinline__ void chain_head_phase(const ChainParams &c, float *sh) {          // sh: NT / 256 x 8 floats of LDS
+    constexpr int SIDE = NT / 256;                                                            // rows that go through the barriers side by side
+    const int side = threadIdx.x >> 8, t256 = threadIdx.x & 255;
+    const int row0 = (int)blockIdx.x * c.head_rows;
+    for (int it = 0; it < c.head_rows; it += SIDE) {
+        const int m = row0 + it + side;
+        post_row(c.post, m < c.post.M ? m : c.post.M - 1, t256, sh + side * 8, m < c.post.M && it + side < c.head_rows);
+    }
+    // publish: the rows went out write-through (store_wt_*); every storing wave waits for its stores, the barrier collects the waves, then ONE
+    // agent-scope add for the workgroup (MI355X_MICROARCH.md, inter-workgroup visibility: the signalling lane comes after EVERY wave's wait)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int rows = c.post.M - row0 < c.head_rows ? c.post.M - row0 : c.head_rows;
+        if (rows > 0) __hip_atomic_fetch_add(c.flags + row0 / TM_ROWS, (unsigned)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// tile workgroup of row chunk mc (chunk_rows rows per chunk, n_wait tile workgroups share the chunk): returns once the chunk's rows are published
+__device__ __forceinline__ void chain_wait(const ChainParams &c, int mc, int chunk_rows, int n_wait) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {
+        if (threadIdx.x == 0) {
+            const int left = c.post.M - mc * chunk_rows;
+            const unsigned want = (unsigned)(left < chunk_rows ? left : chunk_rows);
+            unsigned spins = 0;
+            while (__hip_atomic_load(c.flags + mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {      // ONE relaxed poller per workgroup
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 21)) { __hip_atomic_store(c.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // never hang the GPU
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // buffer_inv sc1: this CU's L1 forgets what it held of the rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... completed before the barrier lets the other waves load
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {          // the last tile workgroup of the chunk to get here re-arms both counters for the next launch that uses them
+        const unsigned passed = __hip_atomic_fetch_add(c.flags + 64 + mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (passed + 1 == (unsigned)n_wait) {
+            __hip_atomic_store(c.flags + mc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.flags + 64 + mc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 constexpr int K32_SLOT = 16384;
 __device__ __forceinline__ int panel32_off(int row, int col) { return row * 64 + ((col ^ ((0 - (row >> 2)) & 3)) << 4); }
 template <int NS>
@@ -290,8 +336,10 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
     constexpr int P = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char ring[];
     if (p.prio & 1) __builtin_amdgcn_s_setprio(3);
-    const int nblk = gridDim.x;
-    int id = blockIdx.x;
+    const int n_head = p.chain.head_wgs;            // chained launch: the first workgroups are the k_post that produces this launch's A rows
+    if ((int)blockIdx.x < n_head) { chain_head_phase<512>(p.chain, (float *)ring); return; }
+    const int nblk = gridDim.x - n_head;
+    int id = blockIdx.x - n_head;                   // n_head is a multiple of 8: the round-robin over the XCDs stays in step
     {
         const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
@@ -323,9 +371,23 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (n_head) {
+        // chained: the weight halves of the first P slots go out at once (they depend on nothing), the activation halves once the head workgroups
+        // have published this row chunk; the prologue is then drained completely, so the loop's counted waits (which assume two DMA
+        // instructions per chunk in issue order) hold from its first iteration on
 #pragma unroll
-    for (int i = 0; i < P; i++)
-        if (i < nchunks) issue(t0 + i, i);
+        for (int i = 0; i < P; i++)
+            if (i < nchunks) glds16(wpd + (size_t)(t0 + i) * 64, ring_base + i * K32_SLOT + 8192 + wave * 1024);
+        chain_wait(p.chain, mc, TM, n_groups * p.splits);
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if (i < nchunks) glds16(asrc + (size_t)(t0 + i) * 64, ring_base + i * K32_SLOT + wave * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if (i < nchunks) issue(t0 + i, i);
+    }
     int slot = 0;
     for (int i = 0; i < nchunks; i++) {
         const int left = nchunks - 1 - i;                                          // chunks allowed to stay in flight: min(left, P - 1)
@@ -452,6 +514,115 @@ __global__ __launch_bounds__(512) void k_gemm_t64(GemmParams p, int n_groups, in
         if (m >= p.M) continue;
         if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + ((size_t)split * p.M + m) * p.ldo + n0, v);
         else epi_quad<true>(p, split, m, n0, v.x, v.y, v.z, v.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Round 5: the two K-halves of a 128 x 64 tile in ONE workgroup (16 waves: waves 0-7 = k_gemm_t64's eight waves on the first half of K,
+// waves 8-15 the same on the second half, each half with its own 3-slot ring: 2 x 72 KiB = what two co-resident k_gemm_t64<3> workgroups hold).
+// Rounds 1-4 wrote the two halves out as f32 partial slabs (2 x 3.67 MB per GEMM at 896 rows, write-through) and k_post read them back with the
+// residual: 16.5 MB per k_post launch, 97 launches per step; leaving k_post out of a pipelined 64-stream step saved 0.41 of its 2.48 ms
+// (profiles/r5_ablation.md).  Here the halves meet in LDS, and the epilogue adds scale x (p0 + p1) to the residual stream in place
+// (EPI_RESID_F32: the order and the fmaf of k_post -- o = t[0] + t[1]; x = fmaf(scale, o, x) -- so x keeps its bits): no partial slab leaves the
+// CU, k_post is left with the LayerNorm.  Each half performs k_gemm_t64's MFMAs in k_gemm_t64's order (split = half of 2): p0 and p1 are
+// the slabs' values.  The residual tile (32 KiB) is requested at kernel entry, long before it is needed.
+// ------------------------------------------------------------------------------------
+constexpr int T64W_NS = 3, T64W_HALF = T64W_NS * T64_SLOT;          // 73 728 B per K-half
+__global__ __launch_bounds__(1024) void k_gemm_t64w(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int NS = T64W_NS, P = NS - 1;
+    extern __shared__ __attribute__((aligned(16))) char ring_all[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    int mc, ng, split_unused;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split_unused);
+    const int wave16 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = wave16 >> 3, wave = wave16 & 7;
+    char *ring = ring_all + half * T64W_HALF;
+    const int ng2 = wave & 1, mq = wave >> 1, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int c0 = (int)((long)kc_total * half / 2), c1 = (int)((long)kc_total * (half + 1) / 2);     // k_gemm_t64's slice `half` of 2
+    const int nchunks = c1 - c0, m0 = mc * TM, ntile0 = ng * 4;
+    // the residual tile: two float4 per thread (row e >> 4, columns 4 (e & 15) of the 128 x 64 tile, e = tid and tid + 1024)
+    float4 xin[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int e = threadIdx.x + i * 1024, m = m0 + (e >> 4);
+        xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.epi == EPI_RESID_F32 && m < p.M) xin[i] = *(const float4 *)(p.resid + (size_t)m * p.ldo + ng * 64 + (e & 15) * 4);
+    }
+    const uint4 *wpd = (const uint4 *)p.W + ((size_t)(ntile0 + (wave >> 1)) * KT + (wave & 1)) * 64 + lane;
+    const int prow = lane >> 3, pc = lane & 7;
+    const char *asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int row = wave * 16 + i * 8 + prow;
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc[i] = a_row_ptr(p, m, 2) + ((pc ^ ((row >> 1) & 7)) << 4);
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kc, int slot) {
+        const unsigned sb = ring_base + slot * T64_SLOT;
+#pragma unroll
+        for (int i = 0; i < 2; i++) glds16(asrc[i] + (size_t)kc * 128, sb + (wave * 16 + i * 8) * 128);
+        glds16(wpd + (size_t)(2 * kc) * 64, sb + 16384 + wave * 1024);
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P; i++)
+        if (i < nchunks) issue(c0 + i, i);
+    for (int i = 0; i < nchunks; i++) {                 // both halves run the same number of chunks (the launcher checks K % 128 == 0): the barriers pair up
+        const int rem = nchunks - 1 - i < P - 1 ? nchunks - 1 - i : P - 1;
+        if (rem >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");             // 3 DMA instructions per wave per chunk; the residual loads are older still
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char *sp = ring + (i % NS) * T64_SLOT;
+        const char *wl = sp + 16384 + ng2 * 4096 + lane * 16;
+        uint4 w[2][2];
+        w[0][0] = *(const uint4 *)(wl);
+        w[0][1] = *(const uint4 *)(wl + 1024);
+        w[1][0] = *(const uint4 *)(wl + 2048);
+        w[1][1] = *(const uint4 *)(wl + 3072);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                const uint4 bv = *(const uint4 *)(sp + panel_off((mq * 2 + mt) * 16 + r, k2 * 4 + q));
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[0][k2]), bf, acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[1][k2]), bf, acc[1][mt], 0, 0, 0);
+            }
+        }
+        if (i + P < nchunks) issue(c0 + i + P, (i + P) % NS);
+    }
+    __syncthreads();                           // every wave is done with its ring
+    float *stage = (float *)ring;              // this half's f32 tile [128][68]
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+            *(float4 *)(stage + ((mq * 2 + mt) * 16 + r) * T64_STG_LD + (ng2 * 2 + j) * 16 + q * 4) =
+                make_float4(acc[j][mt][0], acc[j][mt][1], acc[j][mt][2], acc[j][mt][3]);
+    __syncthreads();
+    const float *s0 = (const float *)ring_all, *s1 = (const float *)(ring_all + T64W_HALF);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int e = threadIdx.x + i * 1024, row = e >> 4, c4 = (e & 15) * 4, m = m0 + row, n0 = ng * 64 + c4;
+        if (m >= p.M) continue;
+        const float4 a = *(const float4 *)(s0 + row * T64_STG_LD + c4), b = *(const float4 *)(s1 + row * T64_STG_LD + c4);
+        const float4 o = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);             // k_post: o = t[0] + t[1]
+        if (p.epi == EPI_RESID_F32)
+            store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, make_float4(__builtin_fmaf(p.resid_scale, o.x, xin[i].x), __builtin_fmaf(p.resid_scale, o.y, xin[i].y),
+                                                                       __builtin_fmaf(p.resid_scale, o.z, xin[i].z), __builtin_fmaf(p.resid_scale, o.w, xin[i].w)));
+        else epi_quad<true>(p, 0, m, n0, o.x, o.y, o.z, o.w);
     }
 }
 
@@ -922,6 +1093,7 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_roles<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_t64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_t64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T64_SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_t64w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T64W_HALF);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_PART_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_SILU_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
@@ -956,6 +1128,20 @@ bool gemm_use_t64(int M, int N, int epi, int t64_p1) {
     return tiles <= 64;
 }
 int gemm_tile_n(int M, int N, int epi, int t64_p1) { return gemm_use_t64(M, N, epi, t64_p1) ? 64 : 128; }
+// EPI_RESID_F32 needs the complete K sum in one workgroup: the welded two-slice 128 x 64 form where pick_splits chose two slices of
+// half-width tiles (256 < M <= 1 024 at the default "t64_tiles"), or any launch without split-K
+static bool gemm_welded(int M, int N, int K, int splits, int t64_p1) {
+    return splits == 2 && (K & 127) == 0 && gemm_use_t64(M, N, EPI_PART_F32, t64_p1);
+}
+// a GEMM whose A rows come out of a k_post can carry that k_post as its head phase (ChainParams) when it runs on the 128 x 128 tiles of
+// k_gemm_tiled2_k32: more than 32 rows, no split-K, N a multiple of 128, at most 64 row chunks (the counters)
+bool gemm_chain_ok(int M, int N, int K, int splits) {
+    return M > gemm_skinny_max_m() && splits == 1 && N % 128 == 0 && (K & 63) == 0 && (M + TM - 1) / TM <= 64;
+}
+bool gemm_resid_foldable(int M, int N, int K, int splits, int t64_p1) {
+    if (M <= gemm_skinny_max_m()) return false;
+    return splits == 1 || gemm_welded(M, N, K, splits, t64_p1);
+}
 
 // Largest M served by the weight-streaming ("skinny") kernel; above it the LDS-tiled kernels take over.  Round 1 had 128 (chosen
 // on synchronous steps).  Re-measured in round 2 (ms per step, <= 32 / <= 64 / <= 128 rows skinny):
@@ -998,6 +1184,16 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         else hipLaunchKernelGGL(k_gemm_skinny<4>, grid, dim3(256), 0, st, p);
     } else {
         int n_groups = p.N / 128, m_chunks = (p.M + TM - 1) / TM;
+        if (p.chain.head_wgs > 0) {                        // chained launch (the caller asked gemm_chain_ok()): k_gemm_tiled2_k32 is the kernel that carries a head phase
+            hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, dim3(p.chain.head_wgs + n_groups * m_chunks * p.splits), dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            return;
+        }
+        if (p.epi == EPI_RESID_F32 && p.splits == 2) {      // the caller asked gemm_resid_foldable(): both K slices in one 16-wave workgroup
+            GemmParams w = p;
+            w.splits = 1;                                  // tile_of(): one workgroup per tile
+            hipLaunchKernelGGL(k_gemm_t64w, dim3((p.N / 64) * m_chunks), dim3(1024), 2 * T64W_HALF, st, w, p.N / 64, m_chunks);
+            return;
+        }
         if (gemm_use_t64(p.M, p.N, p.epi, p.t64_tiles_p1)) {       // half-width tiles: the caller chose splits for N / 64 column groups (gemm_tile_n)
             n_groups = p.N / 64;
             if (gemm_coresident(p))      // 3 slots = 72 KiB: two workgroups per CU

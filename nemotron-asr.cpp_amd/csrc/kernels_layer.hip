@@ -6,71 +6,14 @@
 //   k_dwconv    cached causal depthwise conv + LayerNorm + SiLU + conv-cache update (:336-412, :671-674)
 #include "nasr_internal.h"
 #include "nasr_wave.h"
+#include "nasr_post.h"
 
 namespace nasr {
-
-// sum over a 256-thread block; every thread gets the result.  `sh` = 4 floats of LDS that the PREVIOUS block_sum of
-// this workgroup did not use (callers alternate between two 4-float halves, so one barrier per sum is enough: a wave
-// can only be one barrier ahead, and by then every wave has read the half that is being rewritten).
-__device__ __forceinline__ float block_sum(float v, float *sh) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-// LayerNorm of the 4 elements each thread holds (1024 = 256 x 4), biased variance, eps 1e-5; the affine
-// parameters are passed in so that the caller can load them before the reductions; sh = 8 floats of LDS
-__device__ __forceinline__ float4 ln4(float4 v, float4 ww, float4 bb, float *sh) {
-    float mean = block_sum((v.x + v.y) + (v.z + v.w), sh) * (1.0f / D);
-    float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-    float var = block_sum((dx * dx + dy * dy) + (dz * dz + dw * dw), sh + 4) * (1.0f / D);
-    float inv = 1.0f / sqrtf(var + 1e-5f);
-    return make_float4(dx * inv * ww.x + bb.x, dy * inv * ww.y + bb.y, dz * inv * ww.z + bb.z, dw * inv * ww.w + bb.w);
-}
-__device__ __forceinline__ float4 ln4(float4 v, const float *w, const float *b, int c4, float *sh) {
-    return ln4(v, *(const float4 *)(w + c4), *(const float4 *)(b + c4), sh);
-}
-
-__device__ __forceinline__ void store_act4(void *base, size_t off, float4 v, int bf16) {      // write-through (nasr_wave.h)
-    if (bf16) {
-        uint2 r;
-        r.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-        r.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-        store_wt_u2((bf16_t *)base + off, r);
-    } else {
-        store_wt_f4((float *)base + off, v);
-    }
-}
 
 // ---- post: one workgroup per row ------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_post(PostParams p) {
     __shared__ float sh[8];
-    const int m = blockIdx.x, c4 = threadIdx.x * 4;
-    // every load of the kernel is independent of the arithmetic: issue them all first
-    float4 v = *(const float4 *)(p.x + (size_t)m * D + c4);
-    float4 t[8];
-#pragma unroll
-    for (int s = 0; s < 8; s++)
-        if (s < p.splits) t[s] = *(const float4 *)(p.part + ((size_t)s * p.M + m) * D + c4);
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 w1 = z4, b1 = z4, w2 = z4, b2 = z4;
-    if (p.ln_out) { w1 = *(const float4 *)(p.ln1_w + c4); b1 = *(const float4 *)(p.ln1_b + c4); }
-    if (p.ln2_w) { w2 = *(const float4 *)(p.ln2_w + c4); b2 = *(const float4 *)(p.ln2_b + c4); }
-    if (p.splits > 0) {
-        float4 o = t[0];
-#pragma unroll
-        for (int s = 1; s < 8; s++)
-            if (s < p.splits) { o.x += t[s].x; o.y += t[s].y; o.z += t[s].z; o.w += t[s].w; }
-        v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
-    }
-    if (p.ln_out) v = ln4(v, w1, b1, sh);
-    if (p.splits > 0 || p.ln_out) store_wt_f4(p.x + (size_t)m * D + c4, v);
-    if (p.copy_out) *(float4 *)(p.copy_out + (size_t)m * D + c4) = v;
-    if (p.ln2_w) {
-        float4 a = ln4(v, w2, b2, sh);
-        store_act4(p.a_out, (size_t)m * D + c4, a, p.act_bf16);
-    }
+    post_row(p, blockIdx.x, threadIdx.x, sh, true);          // nasr_post.h: the same body runs in the head phase of a chained GEMM launch
 }
 void launch_post(const PostParams &p, hipStream_t st) {
     hipLaunchKernelGGL(k_post, dim3(p.M), dim3(256), 0, st, p);
@@ -254,6 +197,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     // V^T image: row d = 256 B = 16 chunks of 8 keys; chunk (j >> 3) sits at ((j >> 3) ^ d ^ (d >> 4)) & 15.  The 16 lanes
     // that hold the 16 d-groups of one key write 16 different chunks (d & 15 alone takes two values there: 16-way
     // conflicts, SQ_LDS_BANK_CONFLICT 85 % of the LDS cycles of this kernel before)
+    if (!(p.ablate & 1))
 #pragma unroll
     for (int it = 0; it < 6; it++) {
         const int e = threadIdx.x + it * 256, c = e & 15, j = e >> 4;
@@ -468,7 +412,7 @@ __global__ __launch_bounds__(256) void k_dwconv(ConvParams p) {
             else { acc.x += z.x * w.x; acc.y += z.y * w.y; acc.z += z.z * w.z; acc.w += z.w * w.w; }
         }
     }
-    float4 n = ln4(acc, lw, lb, sh);                                               // :671-673
+    float4 n = ln4(acc, lw, lb, sh, threadIdx.x);                                               // :671-673
     n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));          // SiLU :674
     n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
     store_act4(p.c_out, ((size_t)b * T + i) * D + c4, n, p.act_bf16);
@@ -481,7 +425,83 @@ __global__ __launch_bounds__(256) void k_dwconv(ConvParams p) {
         }
     }
 }
+// ---- the same, one workgroup per STREAM (round 5; kernel size 9, up to 14 frames per stream) ------------------------------------------
+// k_dwconv's grid is (streams, frames): every GLU row is fetched by nine workgroups and the conv cache by eight, 7 168 workgroups of one
+// load round trip + two barriers at 512 streams x R = 13 (30 us per launch for 78 MB of algorithmic bytes; with attention 2.3 ms of a
+// 14.6 ms pipelined step, profiles/r5_ablation.md).  Here a workgroup keeps the stream's whole window -- 8 cached rows + T new ones, its 4
+// channels per thread -- in registers: every row is read ONCE, the T outputs are formed in k_dwconv's order, their T LayerNorms share two
+// barriers (per row the sums are k_dwconv's: wave_sum, then (w0 + w1) + (w2 + w3)), and the new cache is the window's last 8 rows.
+// Same bits as k_dwconv (engine option "dwconv_stream" = 0; tests/micro/gemm_variant_identity.py).
+__global__ __launch_bounds__(256) void k_dwconv_stream(ConvParams p) {
+    __shared__ float sh[2][TMAX][4];
+    const int b = blockIdx.x, T = p.T;
+    const int c4 = threadIdx.x * 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RowDesc rd = p.rows[b];
+    const float *cc_in = p.cc_pool + (size_t)rd.slot * p.cc_slot_stride + (size_t)rd.cc_par * 8 * D;
+    float *cc_out = p.cc_pool + (size_t)rd.slot * p.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * 8 * D;
+    const float *g = p.glu + (size_t)b * T * D;
+    float4 z[8 + TMAX], w[9];
+#pragma unroll
+    for (int r = 0; r < 8; r++) z[r] = *(const float4 *)(cc_in + (size_t)r * D + c4);
+#pragma unroll
+    for (int i = 0; i < TMAX; i++) z[8 + i] = i < T ? *(const float4 *)(g + (size_t)i * D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = *(const float4 *)(p.dw + (size_t)k * D + c4);
+    const float4 lw = *(const float4 *)(p.ln_w + c4), lb = *(const float4 *)(p.ln_b + c4);
+    float4 acc[TMAX];
+    float s[TMAX];
+#pragma unroll
+    for (int i = 0; i < TMAX; i++) {
+        float4 a = make_float4(z[i].x * w[0].x, z[i].y * w[0].y, z[i].z * w[0].z, z[i].w * w[0].w);
+#pragma unroll
+        for (int k = 1; k < 9; k++) { a.x += z[i + k].x * w[k].x; a.y += z[i + k].y * w[k].y; a.z += z[i + k].z * w[k].z; a.w += z[i + k].w * w[k].w; }
+        acc[i] = a;
+        s[i] = wave_sum((a.x + a.y) + (a.z + a.w));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) sh[0][i][wave] = s[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TMAX; i++) {
+        const float mean = ((sh[0][i][0] + sh[0][i][1]) + (sh[0][i][2] + sh[0][i][3])) * (1.0f / D);
+        acc[i].x -= mean; acc[i].y -= mean; acc[i].z -= mean; acc[i].w -= mean;
+        s[i] = wave_sum((acc[i].x * acc[i].x + acc[i].y * acc[i].y) + (acc[i].z * acc[i].z + acc[i].w * acc[i].w));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) sh[1][i][wave] = s[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TMAX; i++) {
+        if (i < T) {
+            const float var = ((sh[1][i][0] + sh[1][i][1]) + (sh[1][i][2] + sh[1][i][3])) * (1.0f / D);
+            const float inv = 1.0f / sqrtf(var + 1e-5f);
+            float4 n = make_float4(acc[i].x * inv * lw.x + lb.x, acc[i].y * inv * lw.y + lb.y, acc[i].z * inv * lw.z + lb.z, acc[i].w * inv * lw.w + lb.w);
+            n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));          // SiLU :674
+            n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
+            store_act4(p.c_out, ((size_t)b * T + i) * D + c4, n, p.act_bf16);
+        }
+    }
+    // new conv cache = the window's last 8 rows (:396-408), written to the other buffer
+#pragma unroll
+    for (int r2 = 0; r2 < 8; r2++) {
+        float4 v = z[r2];                          // T = 0 never happens; the row is z[T + r2]
+#pragma unroll
+        for (int i = 1; i <= TMAX; i++)
+            if (i == T) v = z[i + r2];
+        *(float4 *)(cc_out + (size_t)r2 * D + c4) = v;
+    }
+}
 void launch_dwconv(const ConvParams &p, hipStream_t st) {
+    // from 256 streams: below that too few workgroups (64 streams: 64 of 256 CUs busy, a synchronous step 4.05 -> 4.24 ms); 512 streams x R = 13: 30.3 -> 26.2 us
+    // per launch, a pipelined step 14.46 -> 14.18 ms
+    if (p.stream_form && p.ks == 9 && p.T >= 4 && p.T <= TMAX && p.B >= 256) {
+        hipLaunchKernelGGL(k_dwconv_stream, dim3(p.B), dim3(256), 0, st, p);
+        return;
+    }
     hipLaunchKernelGGL(k_dwconv, dim3(p.B, p.T), dim3(256), 0, st, p);
 }
 

@@ -20,6 +20,10 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         if (e->pipe_ready) return fail("decode_lane must be set before the first pipelined step (the lanes are already picked)");
         e->opt_decode_lane = value != 0;
     }
+    else if (!strcmp(key, "dwconv_stream")) e->opt_dwconv_stream = value != 0;      // like "fused": set before the first step
+    else if (!strcmp(key, "chain")) { if (value < 0 || value > 2) return fail("chain must be 0, 1 or 2"); e->opt_chain = value; }      // like "fused": set before the first step
+    else if (!strcmp(key, "resid_epilogue")) { if (value < 0 || value > 2) return fail("resid_epilogue must be 0, 1 or 2"); e->opt_resid_epilogue = value; }      // like "fused": set before the first step
+    else if (!strcmp(key, "ablate")) e->opt_ablate = value;          // measurement only (see the header); before the first step
     else if (!strcmp(key, "f32_mfma")) e->opt_f32_mfma = value != 0;      // 0: f32 GEMMs above four rows on the FMA tile kernel (round 3's path); like "fused", set before the first step
     else if (!strcmp(key, "pipeline")) {
         ApiGuard api_guard;
@@ -142,6 +146,7 @@ int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, const int
         if (d.n_frames > 0) s->abuf_par ^= 1;
         s->mel_count += d.n_frames;
     }
+    if (*gh_active < 0) return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
     if (*gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
         DecParams dp;
         make_dec_params(e, (const RowDesc *)(e->g_desc + L.rows), B, T * G, dp);

@@ -20,6 +20,7 @@ int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
     g.wide_rows = e->opt_wide_tiles == 256 ? 256 : e->opt_wide_tiles == 3 ? 2 : 0;
     g.tile_bands = e->opt_tile_bands < 0 ? 0 : e->opt_tile_bands == 0 ? 2 : 1;
     g.t64_tiles_p1 = e->opt_t64_tiles + 1;
+    if (e->opt_ablate & 32) return 0;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);
     return 0;
@@ -214,7 +215,7 @@ int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, c
     };
     // ---- a-2 subsampling ------------------------------------------------------------------
     const int H1 = chunk_mel / 2 + 1, W1 = 65, H2 = H1 / 2 + 1, W2 = 33, H3 = H2 / 2 + 1, W3 = 17;
-    if (front) {
+    if (front && !(e->opt_ablate & 16)) {
     {
         ProfScope ps(e, "k_sub_conv0_dw", (double)Bs * (chunk_mel * NMEL * 4 + H2 * W2 * SUBC * (act ? 2 : 4)), 2.0 * Bs * H2 * W2 * SUBC * 90);
         launch_sub_conv0_dw(vrows, Bs, chunk_mel, e->mel_ring, e->w0t, e->b0, e->w2t, e->b2, e->sub_b, act, H1, W1, st);
@@ -280,34 +281,74 @@ int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, c
         if (run_layers_fused(e, rows, B, T, G, snap8(seg, bound8(seg)), snap8(seg + 1, bound8(seg + 1)))) return -1;
     } else {
     // ---- 24 cached conformer layers -----------------------------------------------------------
+        // Round 5, chained launches: a k_post that is due is held back (`pend`) and rides as the HEAD PHASE of the GEMM that reads its rows
+        // (GemmParams::chain; W1, QKV, pw1 -- same arithmetic, same bits, one launch and one dependent boundary fewer); if the next launch is
+        // not such a GEMM, or the piece ends, it is launched on its own as before.
+        const bool chain = e->bf16 && !e->debug && !e->prof.on && e->opt_chain && (e->opt_chain == 2 || e->gemm_coresident) && M >= 769 && M < 1344;
+        PostParams pend;
+        bool has_pend = false;
+        double pend_bytes = 0;
+        auto flush_post = [&]() {
+            if (!has_pend) return;
+            has_pend = false;
+            if (e->opt_ablate & 1) return;
+            ProfScope ps(e, "k_post", pend_bytes);
+            launch_post(pend, st);
+        };
+        auto post = [&](const PostParams &q, double bytes) {
+            pend = q; pend_bytes = bytes; has_pend = true;
+            if (!chain) flush_post();
+        };
+        auto gemm_a = [&](GemmParams &gp, const char *tag) {          // a GEMM whose A operand is e->a, the rows of the k_post before it
+            if (has_pend && !(e->opt_ablate & 1) && gemm_chain_ok(gp.M, gp.N, gp.K, gp.splits)) {
+                gp.chain.post = pend;
+                gp.chain.head_rows = 4;
+                gp.chain.head_wgs = (((M + 3) / 4) + 7) & ~7;          // a multiple of 8: the tiles behind keep their XCDs
+                gp.chain.flags = e->chain_flags;
+                gp.chain.error = (unsigned *)(e->n_active + 3);
+                has_pend = false;
+            } else flush_post();
+            run_gemm(e, gp, false, tag);
+        };
         if (front) {
             PostParams pp;
             memset(&pp, 0, sizeof(pp));
             pp.x = e->x; pp.M = M; pp.ln2_w = e->L[0].ln_ff1_w; pp.ln2_b = e->L[0].ln_ff1_b; pp.a_out = e->a; pp.act_bf16 = act;
-            { ProfScope ps(e, "k_post", (double)M * D * (4 + e->esz)); launch_post(pp, st); }
+            post(pp, (double)M * D * (4 + e->esz));
         }
 
         const int nL = e->hp.n_layers, ks = e->hp.kernel_size;
         for (int l = l0; l < l1; l++) {
             LayerW &L = e->L[l];
+            // a residual GEMM (N = 1024): x += scale * A.W^T.  Round 5: where one workgroup owns the complete K sum of a tile (no split-K, or the
+            // welded two-slice form k_gemm_t64w) the GEMM adds to x in its own epilogue and the k_post behind it is left with the LayerNorm
+            // (returns 0 splits for it); otherwise split-K partial slabs + k_post as in rounds 1-4.  Same bits either way.
+            auto resid_gemm = [&](const void *A, int lda, void *w, int K, float scale, const char *tag) -> int {
+                GemmParams a;
+                memset(&a, 0, sizeof(a));
+                a.A = A; a.W = w; a.M = M; a.N = D; a.K = K; a.lda = lda; a.splits = pick_splits(e, M, D, K);
+                // without split-K the fold costs nothing (same kernel, no slab): always; the welded two-slice kernel is two co-resident workgroups in one --
+                // what pipelined steps run anyway, 12 % slower than k_gemm_t64<4> on 224 CUs when the step is alone on the chip: pipelined steps only
+                const bool fold = e->bf16 && e->opt_resid_epilogue && (a.splits == 1 || e->opt_resid_epilogue == 2 || e->gemm_coresident) && gemm_resid_foldable(M, D, K, a.splits, e->opt_t64_tiles + 1);
+                if (fold) { a.epi = EPI_RESID_F32; a.out_f32 = e->x; a.resid = e->x; a.resid_scale = scale; a.ldo = D; }
+                else { a.epi = EPI_PART_F32; a.out_f32 = e->part; a.ldo = D; }
+                run_gemm(e, a, false, tag);
+                return fold ? 0 : a.splits;
+            };
             auto ffn = [&](void *w1, void *w2, const float *nln_w, const float *nln_b, bool last) {
                 GemmParams a;
                 memset(&a, 0, sizeof(a));
                 a.A = e->a; a.W = w1; a.M = M; a.N = FF; a.K = D; a.lda = D; a.splits = 1;
                 a.epi = EPI_SILU_ACT; a.out_act = e->hbuf; a.ldo_act = FF;
-                run_gemm(e, a, false, "ffn_w1");
-                memset(&a, 0, sizeof(a));
-                a.A = e->hbuf; a.W = w2; a.M = M; a.N = D; a.K = FF; a.lda = FF; a.splits = pick_splits(e, M, D, FF);
-                a.epi = EPI_PART_F32; a.out_f32 = e->part; a.ldo = D;
-                run_gemm(e, a, false, "ffn_w2");
+                gemm_a(a, "ffn_w1");
+                a.splits = resid_gemm(e->hbuf, FF, w2, FF, 0.5f, "ffn_w2");
                 PostParams q;
                 memset(&q, 0, sizeof(q));
                 q.x = e->x; q.M = M; q.part = e->part; q.splits = a.splits; q.scale = 0.5f;   // :633-634
                 q.a_out = e->a; q.act_bf16 = act;
                 if (last) { q.ln_out = 1; q.ln1_w = L.ln_out_w; q.ln1_b = L.ln_out_b; }       // :687
                 q.ln2_w = nln_w; q.ln2_b = nln_b;
-                ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * a.splits + e->esz));
-                launch_post(q, st);
+                post(q, (double)M * D * (8 + 4 * a.splits + e->esz));
             };
             // 1. FFN1 (:631-634) -> a = LN_att(x)
             ffn(L.ff1_w1, L.ff1_w2, L.ln_att_w, L.ln_att_b, false);
@@ -316,60 +357,53 @@ int enqueue_encoder(nasr_engine *e, const RowDesc *rows, const RowDesc *vrows, c
             g.A = e->a; g.W = L.wqkv; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.splits = 1;
             g.epi = EPI_QKV; g.q_out = e->q; g.kv_pool = e->kv_pool[l]; g.kv_slot_stride = (int64_t)2 * KVC * D;
             g.rows = rows; g.T = TS;
-            run_gemm(e, g, false, "qkv");
+            gemm_a(g, "qkv");
             {
                 AttnParams ap;
                 memset(&ap, 0, sizeof(ap));
                 ap.q = e->q; ap.kv_pool = e->kv_pool[l]; ap.kv_slot_stride = (int64_t)2 * KVC * D; ap.act_bf16 = act;
                 ap.posproj = L.posproj[T]; ap.bias_u = L.bias_u; ap.bias_v = L.bias_v; ap.rows = rows; ap.B = B; ap.T = T; ap.TS = TS;
-                ap.ctx_out = e->ctx;
+                ap.ctx_out = e->ctx; ap.ablate = (e->opt_ablate >> 6) & 3;
                 const int KV = LCTX + T;
                 ProfScope ps(e, "k_attention", (double)B * (2.0 * KV + KV + T - 1) * D * e->esz, 2.0 * B * T * KV * D * 3);
-                launch_attention(ap, st);
+                if (!(e->opt_ablate & 2)) launch_attention(ap, st);
             }
-            memset(&g, 0, sizeof(g));
-            g.A = e->ctx; g.W = L.wo; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
-            g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
-            run_gemm(e, g, false, "attn_out");
+            g.splits = resid_gemm(e->ctx, D, L.wo, D, 1.0f, "attn_out");
             {
                 PostParams q;
                 memset(&q, 0, sizeof(q));
                 q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
                 q.ln2_w = L.ln_conv_w; q.ln2_b = L.ln_conv_b; q.a_out = e->a; q.act_bf16 = act;
-                ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
-                launch_post(q, st);
+                post(q, (double)M * D * (8 + 4 * g.splits + e->esz));
             }
             // 3. conv module (:646-679)
             memset(&g, 0, sizeof(g));
             g.A = e->a; g.W = L.pw1; g.M = M; g.N = 2 * D; g.K = D; g.lda = D; g.splits = 1;
             g.epi = EPI_GLU; g.out_f32 = e->glu; g.ldo = D;
-            run_gemm(e, g, false, "pw1");
+            gemm_a(g, "pw1");
             {
                 ConvParams cp;
                 memset(&cp, 0, sizeof(cp));
                 cp.glu = e->glu; cp.cc_pool = e->cc_pool[l]; cp.cc_slot_stride = (int64_t)2 * (ks - 1) * D;
                 cp.dw = L.dw; cp.ln_w = L.cln_w; cp.ln_b = L.cln_b; cp.rows = rows; cp.B = B; cp.T = TS; cp.ks = ks;
-                cp.c_out = e->cbuf; cp.act_bf16 = act;
+                cp.c_out = e->cbuf; cp.act_bf16 = act; cp.stream_form = e->opt_dwconv_stream ? 1 : 0;
                 ProfScope ps(e, "k_dwconv", (double)M * D * (4 + e->esz) + (double)B * 2 * (ks - 1) * D * 4, 2.0 * M * D * ks);
-                launch_dwconv(cp, st);
+                if (!(e->opt_ablate & 4)) launch_dwconv(cp, st);
             }
-            memset(&g, 0, sizeof(g));
-            g.A = e->cbuf; g.W = L.pw2; g.M = M; g.N = D; g.K = D; g.lda = D; g.splits = pick_splits(e, M, D, D);
-            g.epi = EPI_PART_F32; g.out_f32 = e->part; g.ldo = D;
-            run_gemm(e, g, false, "pw2");
+            g.splits = resid_gemm(e->cbuf, D, L.pw2, D, 1.0f, "pw2");
             {
                 PostParams q;
                 memset(&q, 0, sizeof(q));
                 q.x = e->x; q.M = M; q.part = e->part; q.splits = g.splits; q.scale = 1.0f;
                 q.ln2_w = L.ln_ff2_w; q.ln2_b = L.ln_ff2_b; q.a_out = e->a; q.act_bf16 = act;
-                ProfScope ps(e, "k_post", (double)M * D * (8 + 4 * g.splits + e->esz));
-                launch_post(q, st);
+                post(q, (double)M * D * (8 + 4 * g.splits + e->esz));
             }
             // 4. FFN2 (:682-685) + norm_out (:687); then the next layer's first LayerNorm
             const bool has_next = l + 1 < nL;
             ffn(L.ff2_w1, L.ff2_w2, has_next ? e->L[l + 1].ln_ff1_w : nullptr, has_next ? e->L[l + 1].ln_ff1_b : nullptr, true);
-            if (e->debug && tap_copy(e->tap_layers, (size_t)nL * TMAX * D, (size_t)l * TMAX * D)) return -1;
+            if (e->debug) { flush_post(); if (tap_copy(e->tap_layers, (size_t)nL * TMAX * D, (size_t)l * TMAX * D)) return -1; }
         }
+        flush_post();          // the piece ends: the last k_post has no GEMM of this piece behind it
     }
     if (!tail) return 0;
     // ---- a-11 prompt fusion (multilingual only, src/nemo-ggml.cpp:1087-1105) ---------------------
@@ -488,7 +522,7 @@ int validate_batch(nasr_engine *e, nasr_stream *const *streams, int B) {
 __global__ void k_collect(const int *slots, const int *tok_read, int B, const DecCtrl *ctrl, const int *tok_ring, int *out, int stride,
                           const int *n_active) {
     const int b = blockIdx.x;
-    if (b == 0 && threadIdx.x == 0 && n_active) out[(size_t)B * (1 + stride)] = *n_active;   // rides along in the same D2H copy
+    if (b == 0 && threadIdx.x == 0 && n_active) out[(size_t)B * (1 + stride)] = n_active[3] ? -1 : *n_active;   // rides along in the same D2H copy; -1: a chained GEMM launch gave up waiting (ChainParams::error = n_active + 3)
     const int slot = slots[b];
     const int n_tok = ctrl[slot].n_tok, rd = tok_read[b];
     const int n_new = n_tok - rd;

@@ -435,12 +435,21 @@ int alloc_ws(nasr_engine *e, nasr_engine::WS &w) {
     // stored).  Rows per encoder frame are largest for multi-chunk steps at R = 0: H2 = 2T + 3 = 5 per frame.
     rc |= dalloc(e, &w.sub_a, M * 5 * 33 * SUBC);
     { char *p; rc |= dalloc(e, &p, (M * 5 * 33 * SUBC) * 4); w.sub_b = p; }
+    rc |= dalloc(e, &w.chain_flags, 128);
+    if (!rc) hipMemsetAsync(w.chain_flags, 0, 128 * sizeof(unsigned), e->st);      // self re-arming afterwards (chain_wait, kernels_gemm.hip)
+    if (!rc) {       // a workspace set starts from zeros (nothing reads it before it is written; an ablated measurement run does)
+        hipMemsetAsync(w.x, 0, M * D * 4, e->st); hipMemsetAsync(w.x2, 0, M * D * 4, e->st); hipMemsetAsync(w.part, 0, 8 * M * D * 4, e->st);
+        hipMemsetAsync(w.q, 0, M * D * 4, e->st); hipMemsetAsync(w.glu, 0, M * D * 4, e->st);
+        hipMemsetAsync(w.a, 0, M * D * e->esz, e->st); hipMemsetAsync(w.hbuf, 0, M * FF * e->esz, e->st);
+        hipMemsetAsync(w.ctx, 0, M * D * e->esz, e->st); hipMemsetAsync(w.cbuf, 0, M * D * e->esz, e->st);
+        hipMemsetAsync(w.sub_a, 0, M * 5 * 33 * SUBC * 4, e->st); hipMemsetAsync(w.sub_b, 0, M * 5 * 33 * SUBC * 4, e->st);
+    }
     return rc;
 }
 // the enqueue functions address the workspace through the engine's own fields: point them at a set
 void use_ws(nasr_engine *e, const nasr_engine::WS &w) {
     e->x = w.x; e->x2 = w.x2; e->part = w.part; e->q = w.q; e->glu = w.glu; e->sub_a = w.sub_a; e->hfuse = w.hfuse;
-    e->a = w.a; e->hbuf = w.hbuf; e->ctx = w.ctx; e->cbuf = w.cbuf; e->sub_b = w.sub_b;
+    e->a = w.a; e->hbuf = w.hbuf; e->ctx = w.ctx; e->cbuf = w.cbuf; e->sub_b = w.sub_b; e->chain_flags = w.chain_flags;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -507,6 +516,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     rc |= dalloc(e, &e->predg, S * JNT);
     rc |= dalloc(e, &e->key, M);
     rc |= dalloc(e, &e->n_active, 4);
+    if (!rc) hipMemsetAsync(e->n_active, 0, 4 * sizeof(int), e->st);      // [3] = ChainParams::error
     rc |= dalloc(e, &e->dlist, S);
     rc |= dalloc(e, &e->rowmap, M);
     rc |= dalloc(e, &e->tok_frame, S * TOK_CAP);

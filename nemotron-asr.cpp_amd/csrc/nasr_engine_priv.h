@@ -143,6 +143,13 @@ struct nasr_engine {
     int opt_tile_bands = -1;         // option "tile_bands": -1 = the rule (bands of column groups above 4 row chunks), 0 = never, 1 = always (same bits)
     int opt_wide_tiles = 1;          // option "wide_tiles": 256- / 224-row GEMM tiles from 1 792 rows where they fill the chip (k_gemm_wide; same bits); 256 = the 256-row form only, 0 = off
     bool opt_persist_gemm = false;   // option "persistent_gemm" = 1: GEMMs with >= 1.75 tiles of 128 x 128 per CU on the persistent tile loop (k_gemm_persist; same bits).  Off by default: alone on the chip with cache-resident operands it is 14-37 % faster at 7 168 rows, inside the engine (weights cold from HBM) 1 % -- profiles/r4_persistent_gemm.md
+    bool opt_dwconv_stream = true;   // option "dwconv_stream": the depthwise conv with one workgroup per stream from 256 streams x 4 frames (k_dwconv_stream; same bits)
+    int opt_chain = 0;               // option "chain" (OFF: measured 23 % SLOWER, profiles/r5_chained_launches.md): 1 = in pipelined steps of 769 .. 1 343 rows the GEMM that reads a k_post's
+                                     // rows carries that k_post as its head phase (GemmParams::chain: one launch fewer per LayerNorm, same bits); 2 = in synchronous steps too
+    int opt_resid_epilogue = 1;       // option "resid_epilogue": residual GEMMs add to the residual stream in their own epilogue where one workgroup owns a tile's whole K sum
+                                     // (k_gemm_t64w / launches without split-K): 1 = in pipelined steps (default), 2 = always, 0 = partial slabs + k_post everywhere (rounds 1-4); same bits
+    int opt_ablate = 0;              // option "ablate" (MEASUREMENT ONLY, results are invalid): bit mask of launches left out of the unfused step -- 1 k_post, 2 attention,
+                                     // 4 depthwise conv, 8 decode iterations, 16 front end (mel + subsampling), 32 every encoder GEMM: what each costs a pipelined step (profiles/r5_ablation.md)
     bool opt_f32_mfma = true;        // f32 GEMMs above four rows on v_mfma_f32_32x32x2_f32 (bit-identical to the FMA tile kernel)
     char *gh = nullptr;                                                               // pinned host block
     int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active
@@ -155,7 +162,7 @@ struct nasr_engine {
     int pipe_last_nseg = 0;          // pieces of the youngest step in flight (pipe_step drains before a step that is cut differently)
     static const int GP_C = 2, GP_Y = FUSED_GROUP, GP_S = GP_C * GP_Y;   // grouped mode ("pipeline" = 8): 2 chains x 4 problems per launch = 8 stages
     static const int NSLOT = GP_S + 3;                    // grouped mode: 8 steps in flight + the one being decoded + the one being collected + one spare
-    struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; };
+    struct WS { float *x, *x2, *part, *q, *glu, *sub_a, *hfuse; void *a, *hbuf, *ctx, *cbuf, *sub_b; unsigned *chain_flags; };
     WS ws[NSLOT];                    // ws[0] = the set the synchronous paths use (mirrored in x, x2, ... below)
     int opt_pipeline = 0;            // 0: synchronous steps; E >= 1: the encoder in E pieces + the decode, each piece one step behind the previous
     hipStream_t lane[MAXSEG] = {nullptr, nullptr, nullptr, nullptr};   // lane[k]: encoder piece k (lane[0] = st)
@@ -197,6 +204,7 @@ struct nasr_engine {
     size_t desc_bytes = 0, col_bytes = 0;
     int64_t pipe_steps = 0;
     void *a, *hbuf, *ctx, *cbuf, *sub_b;             // (with x, x2, part, q, glu, sub_a, hfuse: the CURRENT workspace set, see use_ws)
+    unsigned *chain_flags = nullptr;                 // ... and its row-chunk counters of chained launches (a set's launches never overlap: one array per set)
     float *predg;                    // [slot][640] cached joint.pred output of the LSTM candidate
     unsigned long long *key;
     int *n_active;                   // [3] = n_active, n_dirty, n_rows

@@ -64,6 +64,11 @@ __device__ __forceinline__ void epi_quad(const GemmParams &p, int split, int m, 
         const float4 b = *(const float4 *)(p.bias + n0);
         *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) = make_float4(v0 + b.x, v1 + b.y, v2 + b.z, v3 + b.w);
     } break;
+    case EPI_RESID_F32: {
+        const float4 x = *(const float4 *)(p.resid + (size_t)m * p.ldo + n0);
+        *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) = make_float4(__builtin_fmaf(p.resid_scale, v0, x.x), __builtin_fmaf(p.resid_scale, v1, x.y),
+                                                                        __builtin_fmaf(p.resid_scale, v2, x.z), __builtin_fmaf(p.resid_scale, v3, x.w));
+    } break;
     case EPI_BIAS_RELU_F32: {
         const float4 b = *(const float4 *)(p.bias + n0);
         *(float4 *)(p.out_f32 + (size_t)m * p.ldo + n0) =

@@ -89,6 +89,34 @@ enum Epi {
     EPI_BIAS_RELU_ACT,  // out_act[m][n] = relu(acc + bias[n])
     EPI_BIAS_RELU_F32,  // out_f32[m][n] = relu(acc + bias[n])
     EPI_BIAS_ACT,       // out_act[m][n] = acc + bias[n]
+    EPI_RESID_F32,      // out_f32[m][n] = fmaf(resid_scale, acc, resid[m][n])   (round 5: the residual add in the producing GEMM; acc = the complete K sum)
+};
+
+struct PostParams {       // x += scale * sum_s part[s]; then LayerNorm(s)
+    float *x; int M;
+    const float *part; int splits; float scale;   // splits = 0: no residual update
+    const float *ln1_w, *ln1_b;   // if ln_out: x = LN1(x) written back first
+    int ln_out;
+    const float *ln2_w, *ln2_b;   // a = LN2(x) (null: no act output)
+    void *a_out; int act_bf16;
+    float *copy_out;              // optional f32 copy of the final x (taps / encoder out)
+};
+// Round 5: a CHAINED launch.  The residual + LayerNorm that produces a GEMM's A rows used to be its own launch (k_post) between the GEMM that
+// wrote the residual and the GEMM that reads the normalised rows: 97 launches per 24-layer step whose removal saved 0.41 of a pipelined
+// 64-stream step's 2.48 ms (profiles/r5_ablation.md) although their own duration is 5 us -- what they cost is a place in the dependent chain
+// (a boundary on either side, a round trip of loads, two reductions).  In a chained launch the first `head_wgs` workgroups of the grid ARE
+// that k_post (nasr_post.h: the same body, `head_rows` rows each, in row order), and the tile workgroups behind them start by streaming
+// their WEIGHT panels into the LDS ring, then wait until the rows of their own row chunk are published (one counter per row chunk, agent
+// scope; MI355X_MICROARCH.md, inter-workgroup visibility: write-through stores + vmcnt(0) + barrier + one atomic add per head workgroup;
+// one relaxed poll + buffer_inv sc1 + barrier on the tile side), then fill the activation half of the ring.  Head workgroups never wait and
+// have the lowest block ids, so every wait is on a workgroup that is already running or queued ahead; a poll that does not end within
+// ~50 ms sets `chain.error` and gives up (the launch then finishes with wrong numbers and the engine reports it) rather than hang the GPU.
+struct ChainParams {
+    PostParams post;          // rows [0, post.M) = the GEMM's A rows
+    int head_wgs;             // 0: an ordinary launch
+    int head_rows;            // rows per head workgroup (a divisor of 128: a head workgroup's rows lie in one row chunk)
+    unsigned *flags;          // [2][32]: rows published per row chunk / tile workgroups of the chunk that have passed the wait (the last one resets both)
+    unsigned *error;          // set to 1 by a tile workgroup that gave up waiting
 };
 
 struct GemmParams {
@@ -104,6 +132,8 @@ struct GemmParams {
     float *out_f32;  int ldo;     // f32 output / partials ([split][M][ldo])
     void  *out_act;  int ldo_act; // act-dtype output
     const float *bias;
+    // EPI_RESID_F32: the residual stream the product is added to (may be out_f32 itself: every element is read and written by one thread)
+    const float *resid; float resid_scale;
     // EPI_QKV
     float *q_out;                 // [M][1024] f32
     void  *kv_pool;               // K/V rings of this layer: [slot][2][KVC][1024] act dtype
@@ -131,6 +161,7 @@ struct GemmParams {
     int tile_bands;
     // engine option "t64_tiles" + 1 (0 = the default, 64): the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles
     int t64_tiles_p1;
+    ChainParams chain;
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------
@@ -139,6 +170,10 @@ void init_fused_kernel_attributes();
 int gemm_skinny_max_m();     // largest M served by the weight-streaming kernel
 int gemm_tile_n(int M, int N, int epi, int t64_tiles_p1);      // output-tile width the large-M kernel will use (128, or 64 for the N = 1024 split-K GEMMs); t64_tiles_p1 as in GemmParams
 void launch_gemm_bf16(const GemmParams &p, hipStream_t st);
+// can a residual GEMM (N = 1024 ... D columns, `splits` K slices by pick_splits) add its product to the residual stream in its own epilogue
+// (EPI_RESID_F32)?  Yes where one workgroup owns the complete K sum of a tile: no split-K, or the two-slice 128 x 64 form (k_gemm_t64w)
+bool gemm_resid_foldable(int M, int N, int K, int splits, int t64_tiles_p1);
+bool gemm_chain_ok(int M, int N, int K, int splits);      // may this GEMM carry the k_post that produces its A rows as a head phase (GemmParams::chain)?
 void launch_gemm_f32(const GemmParams &p, hipStream_t st);
 void launch_pack_weight_bf16(const float *w_f32, bf16_t *packed, int N, int K, hipStream_t st);
 void launch_f32_to_bf16(const float *in, bf16_t *out, int64_t n, hipStream_t st);
@@ -172,15 +207,6 @@ void launch_sub_conv0_dw(const RowDesc *rows, int B, int chunk_mel, const float 
 void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, const float *bias, void *out,
                    int out_bf16, hipStream_t st);
 
-struct PostParams {       // x += scale * sum_s part[s]; then LayerNorm(s)
-    float *x; int M;
-    const float *part; int splits; float scale;   // splits = 0: no residual update
-    const float *ln1_w, *ln1_b;   // if ln_out: x = LN1(x) written back first
-    int ln_out;
-    const float *ln2_w, *ln2_b;   // a = LN2(x) (null: no act output)
-    void *a_out; int act_bf16;
-    float *copy_out;              // optional f32 copy of the final x (taps / encoder out)
-};
 void launch_post(const PostParams &p, hipStream_t st);
 
 struct AttnParams {
@@ -191,6 +217,7 @@ struct AttnParams {
     const RowDesc *rows; int B; int T;
     int TS;               // rows per stream in this launch = G*T when G chunks of a stream are batched (0: = T)
     void *ctx_out;        // [M][1024] act dtype
+    int ablate;           // measurement only (engine option "ablate" bits 64 / 128): k_attention_mfma without its V^T LDS writes / without its K and position loads
 };
 void launch_attention(const AttnParams &p, hipStream_t st);
 
@@ -201,6 +228,7 @@ struct ConvParams {
     const float *ln_w, *ln_b;
     const RowDesc *rows; int B; int T; int ks;
     void *c_out; int act_bf16;
+    int stream_form;      // 1: one workgroup per stream where the shape allows (k_dwconv_stream; engine option "dwconv_stream", same bits)
 };
 void launch_dwconv(const ConvParams &p, hipStream_t st);
 

@@ -199,7 +199,7 @@ int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, int nse
                     memset(&mp, 0, sizeof(mp));
                     mp.desc = g_pcm; mp.B = B; mp.max_frames = max_frames_per_push(T * G); mp.abuf = e->abuf; mp.last_sample = e->last_sample;
                     mp.mel_ring = e->mel_ring; mp.window = e->window; mp.fbT = e->fbT; mp.fb_band = e->fb_band; mp.cos_t = e->cos_t; mp.sin_t = e->sin_t;
-                    launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
+                    if (!(e->opt_ablate & 16)) launch_mel(mp, mp.max_frames * HOP + NFFT, e->st);
                 }
                 return enqueue_encoder(e, g_rows, G > 1 ? g_vrows : g_rows, nullptr, B, T, R, G, k, nseg) ? -1 : 0;
             })) return -1;
@@ -213,7 +213,7 @@ int build_pipe_graphs(nasr_engine *e, int p, int B, int T, int R, int G, int nse
             dp.encproj = P.encproj;
             launch_decode_begin(dp, cs);
             int it = 0;
-            for (int k = 0, n = pipe_blind_iterations(T * G, e->opt_decode_graph_iters); k < n; k++) launch_decode_iter(dp, it++, cs);
+            for (int k = 0, n = (e->opt_ablate & 8) ? 0 : pipe_blind_iterations(T * G, e->opt_decode_graph_iters); k < n; k++) launch_decode_iter(dp, it++, cs);
             hipLaunchKernelGGL(k_collect, dim3(B), dim3(64), 0, cs, P.g_dmeta, P.g_dmeta + B, B, e->ctrl, e->tok_ring, P.collect_dev, COLLECT_STRIDE, e->n_active);
             HIPCHK(hipMemcpyAsync(P.gh_collect, P.collect_dev, ((size_t)B * (1 + COLLECT_STRIDE) + 1) * sizeof(int), hipMemcpyDeviceToHost, cs));
             return 0;
@@ -266,7 +266,8 @@ int pipe_finish(nasr_engine *e, int p) {
     hipStream_t ds = dec_stream(e, P);
     { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.dec_done)); }
     int *gh_active = P.gh_collect + (size_t)B * (1 + COLLECT_STRIDE);      // k_collect appends n_active to its records
-    if (*gh_active != 0) {
+    if (*gh_active < 0) return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    if (*gh_active != 0 && !(e->opt_ablate & 8)) {
         const GraphDescLayout L = graph_desc_layout(B, P.G);
         DecParams dp;
         make_dec_params(e, (const RowDesc *)(P.g_desc + L.rows), B, TS, dp);
@@ -602,6 +603,7 @@ int gp_finish_decode(nasr_engine *e) {
     hipStream_t ds = e->lane[nasr_engine::GP_C - 1];
     { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.dec_done)); }
     int *gh_active = P.gh_collect + (size_t)nB * (1 + COLLECT_STRIDE);
+    if (*gh_active < 0) return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
     if (*gh_active != 0) {                                      // a burst beyond the graph's iteration budget: finish eagerly
         const GraphDescLayout L = graph_desc_layout(nB, P.G);
         DecParams dp;

@@ -583,15 +583,17 @@ def test_gemm_ring_variants_are_bit_identical():
     and storer waves, a tile parked beside the ring while the next one is multiplied) serves every GEMM with >= 1.75 tiles per CU -- the
     same digest with engine option "persistent_gemm" = 1 (off by default: it does not pay inside the engine, profiles/r4_persistent_gemm.md).
     And the same digest with the kernels and the tile order of round 3 ("wide_tiles" = 0, "tile_bands" = 0, "t64_tiles" = 127: no 256- / 224-row tiles, the row
-    chunk fastest, half-width tiles up to 127 tiles) and with the 256-row form only and column-group bands at every size ("wide_tiles" = 256, "tile_bands" = 1)."""
+    chunk fastest, half-width tiles up to 127 tiles) and with the 256-row form only and column-group bands at every size ("wide_tiles" = 256, "tile_bands" = 1).
+    Round 5: and with "resid_epilogue" = 0 -- split-K partial slabs + k_post everywhere, against the default where the residual GEMMs add to the residual
+    stream in their own epilogue (k_gemm_t64w: both K slices in one workgroup; launches without split-K)."""
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "opt:gemm_cores=1", "opt:gemm_cores=0", "opt:persistent_gemm=1",
-                        "opt:persistent_gemm=1 opt:gemm_cores=0", "opt:wide_tiles=0 opt:tile_bands=0 opt:t64_tiles=127", "opt:wide_tiles=256 opt:tile_bands=1"],
+                        "opt:persistent_gemm=1 opt:gemm_cores=0", "opt:wide_tiles=0 opt:tile_bands=0 opt:t64_tiles=127", "opt:wide_tiles=256 opt:tile_bands=1", "opt:resid_epilogue=0"],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert r.stdout.count("==") == 7 and "!=" not in r.stdout
+    assert r.stdout.count("==") == 8 and "!=" not in r.stdout
 
 
 def test_lanes_option_gives_queues_back_and_keeps_results(W2):
