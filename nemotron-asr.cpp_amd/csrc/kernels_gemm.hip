@@ -1051,6 +1051,17 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
     for (int qr = 0; qr < 4; qr++) {
         constexpr int HALF = BM / 2;
         const int part = qr & 1, rows0 = (qr >> 1) * HALF + part * 64, nrows = part ? HALF - 64 : 64;
+        // EPI_RESID_F32: the residual values this pass adds to are requested BEFORE the pass's two barriers and its staging, not inside the store
+        // loop (round 5: there the round trip sat in each of the four passes: 512 streams, k_gemm +2.5 us per launch with the fold, k_post -5.6)
+        float4 xq[8];
+        if (p.epi == EPI_RESID_F32) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int e = threadIdx.x + k * 512, row = e / (BN / 4), m = m0 + rows0 + row;
+                xq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < nrows * (BN / 4) && m < p.M) xq[k] = *(const float4 *)(p.resid + (size_t)m * p.ldo + ng * BN + (e - row * (BN / 4)) * 4);
+            }
+        }
         __syncthreads();                       // the ring (or the previous part) is no longer read
         if (mh == (qr >> 1)) {
 #pragma unroll
@@ -1063,12 +1074,18 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
                 }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < nrows * (BN / 4); e += 512) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {          // 64 rows x BN / 4 quads = 8 per thread at BN = 256
+            const int e = threadIdx.x + k * 512;
+            if (e >= nrows * (BN / 4)) break;
             const int row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4, m = m0 + rows0 + row, n0 = ng * BN + c4;
             if (m >= p.M) continue;
             const float4 v = *(const float4 *)(stage + row * C::STG_LD + c4);
             if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
             else if (p.epi == EPI_SILU_ACT) store_wt_u2((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0, pack4_bf16(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)));
+            else if (p.epi == EPI_RESID_F32)
+                store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, make_float4(__builtin_fmaf(p.resid_scale, v.x, xq[k].x), __builtin_fmaf(p.resid_scale, v.y, xq[k].y),
+                                                                           __builtin_fmaf(p.resid_scale, v.z, xq[k].z), __builtin_fmaf(p.resid_scale, v.w, xq[k].w)));
             else epi_quad<true>(p, 0, m, n0, v.x, v.y, v.z, v.w);
         }
     }

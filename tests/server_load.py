@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--warmup-seconds", type=float, default=0.0,
                     help="a first load of this many seconds per stream on the same server (graph captures, lane picking), not reported")
     ap.add_argument("--conns", type=int, default=8)
+    ap.add_argument("--devices", default="", help="passed to the server: one engine + worker per entry (\"0,0,0,0\": four engines on the one GPU of a test box), stream s on entry s mod count")
     args = ap.parse_args()
     wd = Path(args.workdir)
     wd.mkdir(parents=True, exist_ok=True)
@@ -296,7 +297,11 @@ def main():
     if not model.exists():
         write_model(model, args.layers)
     sock_path = str(wd / f"asr-{int(time.time() * 1000) % 100000}.sock")
-    proc = start_server(model, sock_path, args.streams, args.pipeline, extra=("--no-prewarm",) if args.no_prewarm else ("--prewarm", str(args.right_context)))
+    extra = ("--no-prewarm",) if args.no_prewarm else ("--prewarm", str(args.right_context))
+    n_dev = len(args.devices.split(",")) if args.devices else 1
+    if args.devices:
+        extra += ("--devices", args.devices)
+    proc = start_server(model, sock_path, -(-args.streams // n_dev) if args.devices else args.streams, args.pipeline, extra=extra)
     try:
         if args.warmup_seconds > 0:
             run_load(sock_path, args.streams, args.warmup_seconds, args.right_context, args.mode, n_conns=args.conns, client=args.client, workdir=args.workdir)
@@ -305,6 +310,9 @@ def main():
         srv, err = stop_server(proc)
     rep["server"] = srv
     rep["pipeline"] = args.pipeline
+    if args.devices:
+        rep["devices"] = args.devices
+        rep["server_stderr_tail"] = [ln for ln in err.splitlines() if "worker" in ln or "device" in ln][-12:]
     print(json.dumps(rep))
 
 
