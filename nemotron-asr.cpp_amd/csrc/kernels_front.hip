@@ -255,9 +255,51 @@ __global__ __launch_bounds__(256) void k_sub_dw(const float *in, int Hin, int Wi
     if (OUT_BF16) ((bf16_t *)out)[o] = f32_to_bf16(acc);
     else ((float *)out)[o] = acc;
 }
+// The same conv with one workgroup per OUTPUT ROW (round 5): k_sub_dw launches one 256-thread workgroup per output position -- 139 264 workgroups of nine
+// 4-byte loads per thread at 512 streams x R = 13, 355 us for 536 MB: bound by the dispatch of workgroups, not by HBM.  Here a lane holds four channels
+// (float4), a wave one output position, and the four waves walk the row's positions; per channel the products are added in k_sub_dw's order (kh, kw
+// ascending, taps outside the image skipped; no FMA contraction in this file): same bits.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void k_sub_dw_row(const float *in, int Hin, int Win, const float *wt /*[9][256]*/,
+                                                    const float *bias, void *out, int Hout, int Wout) {
+    const int t = blockIdx.x, b = blockIdx.y, wave = threadIdx.x >> 6, c4 = (threadIdx.x & 63) * 4;
+    float4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w[k] = *(const float4 *)(wt + k * SUBC + c4);
+    const float4 bs = *(const float4 *)(bias + c4);
+    for (int f = wave; f < Wout; f += 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int ih = 2 * t + kh - 2;
+            if (ih < 0 || ih >= Hin) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                const int iw = 2 * f + kw - 2;
+                if (iw < 0 || iw >= Win) continue;
+                const float4 x = *(const float4 *)(in + (((size_t)b * Hin + ih) * Win + iw) * SUBC + c4);
+                const float4 ww = w[kh * 3 + kw];
+                acc.x += ww.x * x.x; acc.y += ww.y * x.y; acc.z += ww.z * x.z; acc.w += ww.w * x.w;
+            }
+        }
+        acc.x += bs.x; acc.y += bs.y; acc.z += bs.z; acc.w += bs.w;
+        const size_t o = (((size_t)b * Hout + t) * Wout + f) * SUBC + c4;
+        if (OUT_BF16) {
+            uint2 r;
+            r.x = (uint32_t)f32_to_bf16(acc.x) | ((uint32_t)f32_to_bf16(acc.y) << 16);
+            r.y = (uint32_t)f32_to_bf16(acc.z) | ((uint32_t)f32_to_bf16(acc.w) << 16);
+            *(uint2 *)((bf16_t *)out + o) = r;
+        } else *(float4 *)((float *)out + o) = acc;
+    }
+}
 void launch_sub_dw(const float *in, int B, int Hin, int Win, const float *wt, const float *bias, void *out,
                    int out_bf16, hipStream_t st) {
     const int Hout = Hin / 2 + 1, Wout = Win / 2 + 1;
+    if ((long)Hout * B >= 512) {        // enough rows to fill the chip (16 streams x R = 13, 128 streams x R = 0)
+        if (out_bf16) hipLaunchKernelGGL(k_sub_dw_row<true>, dim3(Hout, B), dim3(256), 0, st, in, Hin, Win, wt, bias, out, Hout, Wout);
+        else hipLaunchKernelGGL(k_sub_dw_row<false>, dim3(Hout, B), dim3(256), 0, st, in, Hin, Win, wt, bias, out, Hout, Wout);
+        return;
+    }
     if (out_bf16) hipLaunchKernelGGL(k_sub_dw<true>, dim3(Hout * Wout, B), dim3(SUBC), 0, st, in, Hin, Win, wt, bias, out, Hout, Wout);
     else hipLaunchKernelGGL(k_sub_dw<false>, dim3(Hout * Wout, B), dim3(SUBC), 0, st, in, Hin, Win, wt, bias, out, Hout, Wout);
 }

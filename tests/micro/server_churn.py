@@ -52,7 +52,7 @@ def main():
     short = [sl.StreamState(100 + i, 0, 2.0 + (i * 0.31) % 1.0, delay=2.0 + arrival * i) for i in range(n_short)]
     out = {}
     for name, streams in (("live_only", [sl.StreamState(i, 0, total, delay=0.02 * i) for i in range(n_live)]), ("with_churn", live + short)):
-        proc = sl.start_server(model, sock, 128, 4, extra=("--prewarm", "0"))
+        proc = sl.start_server(model, sock, n_live + n_short + 8, 4, extra=("--prewarm", "0"))      # the Python client opens every session up front; the short ones start PUSHING at their delay
         try:
             rep = sl.run_load(sock, len(streams), 0.0, 0, "realtime", n_conns=8, client="python", streams=streams)
         finally:
