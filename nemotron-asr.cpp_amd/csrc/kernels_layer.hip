@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void k_post(PostParams p) {
     post_row(p, blockIdx.x, threadIdx.x, sh, true);          // nasr_post.h: the same body runs in the head phase of a chained GEMM launch
 }
 void launch_post(const PostParams &p, hipStream_t st) {
+    // (also measured SLOWER at 7 168 rows: a LayerNorm-only form with four rows per workgroup, all loads first, full occupancy: 16.2 against 14.3 us)
     // (round 5: two rows per workgroup with both rows' loads in flight before the first reduction measured SLOWER at 7 168 rows: 16.5 against 14.0 us)
     hipLaunchKernelGGL(k_post, dim3(p.M), dim3(256), 0, st, p);
 }
@@ -128,10 +129,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char qu_s[16 * 256], qv_s[16 * 256], w_s[16 * 256];
-    __shared__ __attribute__((aligned(16))) char vt_s[128 * 256];
+    // LDS (round 5): the V^T image (32 KiB) is needed in phase 3 only, the query images and the score tiles in phases 0-2 only: they share one region,
+    // the V rows wait in registers until the scores are done (one more barrier).  58 -> 36 KiB per workgroup: four workgroups per CU instead of two --
+    // the kernel is one load round trip, then three short compute phases; what hides a workgroup's round trip is the other workgroups of its CU
+    // (512 streams x R = 13: 77 us per launch at 2.9 TB/s before).
     constexpr int SKP = 100, SPP = 116;                    // row pitches (floats) of the score tiles: 96 / 112 + 4, so the 16 query rows of a float4 store spread over the banks
-    __shared__ __attribute__((aligned(16))) float sk[16 * SKP], sp[16 * SPP];
+    __shared__ __attribute__((aligned(16))) char lds[128 * 256 + 16 * 256];
+    char *const vt_s = lds;                                            // [128 d][256 B]                       phase 3
+    char *const qu_s = lds, *const qv_s = lds + 4096;                  // [16][256 B] each                     phases 0-1
+    float *const sk = (float *)(lds + 8192), *const sp = (float *)(lds + 8192 + 16 * SKP * 4);      // score tiles   phases 1-2 (ends at 22 016 < 32 768)
+    char *const w_s = lds + 128 * 256;                                 // softmax weights [16][256 B]          phases 2-3
     const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
     const int TS = p.TS > 0 ? p.TS : p.T;
     const int QB = T <= 2 ? 16 : T;                          // query rows per workgroup
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
             for (int ks = 0; ks < 4; ks++) av[n][ks] = *(const uint4 *)(arow + ks * 32 + q * 8);
         }
     }
-    // ---- phase 0: queries (+u, +v) -> bf16 LDS; V tile -> transposed LDS (zero padded to 96 keys) ----
+    // ---- phase 0: queries (+u, +v) -> bf16 LDS (the V rows stay in registers until the scores are done) ----
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int e = threadIdx.x + it * 256, i = e >> 7, d = e & 127;
@@ -194,21 +201,6 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         const int off = i * 256 + ((((d >> 3) ^ i) & 15) << 4) + (d & 7) * 2;
         *(bf16_t *)(qu_s + off) = f32_to_bf16(qq + p.bias_u[h * DH + d]);
         *(bf16_t *)(qv_s + off) = f32_to_bf16(qq + p.bias_v[h * DH + d]);
-    }
-    // V^T image: row d = 256 B = 16 chunks of 8 keys; chunk (j >> 3) sits at ((j >> 3) ^ d ^ (d >> 4)) & 15.  The 16 lanes
-    // that hold the 16 d-groups of one key write 16 different chunks (d & 15 alone takes two values there: 16-way
-    // conflicts, SQ_LDS_BANK_CONFLICT 85 % of the LDS cycles of this kernel before)
-    if (!(p.ablate & 1))
-#pragma unroll
-    for (int it = 0; it < 6; it++) {
-        const int e = threadIdx.x + it * 256, c = e & 15, j = e >> 4;
-        const uint32_t w4[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int d = c * 8 + u;
-            const bf16_t val = (bf16_t)((u & 1) ? (w4[u >> 1] >> 16) : (w4[u >> 1] & 0xffffu));
-            *(bf16_t *)(vt_s + d * 256 + ((((j >> 3) ^ d ^ (d >> 4)) & 15) << 4) + (j & 7) * 2) = val;
-        }
     }
     __syncthreads();
     // ---- phase 1: 6 key tiles + 7 relative-position tiles on the MFMA -------------------------------
@@ -250,6 +242,22 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         const int p0 = lane, p1 = lane + 64;
         *(bf16_t *)(w_s + i * 256 + ((((p0 >> 3) ^ i) & 15) << 4) + (p0 & 7) * 2) = f32_to_bf16(e0 * inv);
         *(bf16_t *)(w_s + i * 256 + ((((p1 >> 3) ^ i) & 15) << 4) + (p1 & 7) * 2) = f32_to_bf16(e1 * inv);
+    }
+    __syncthreads();                          // every read of the query images and the score tiles is done: their region becomes the V^T image
+    // V^T image: row d = 256 B = 16 chunks of 8 keys; chunk (j >> 3) sits at ((j >> 3) ^ d ^ (d >> 4)) & 15.  The 16 lanes
+    // that hold the 16 d-groups of one key write 16 different chunks (d & 15 alone takes two values there: 16-way
+    // conflicts, SQ_LDS_BANK_CONFLICT 85 % of the LDS cycles of this kernel before)
+    if (!(p.ablate & 1))
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int e = threadIdx.x + it * 256, c = e & 15, j = e >> 4;
+        const uint32_t w4[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int d = c * 8 + u;
+            const bf16_t val = (bf16_t)((u & 1) ? (w4[u >> 1] >> 16) : (w4[u >> 1] & 0xffffu));
+            *(bf16_t *)(vt_s + d * 256 + ((((j >> 3) ^ d ^ (d >> 4)) & 15) << 4) + (j & 7) * 2) = val;
+        }
     }
     __syncthreads();
     // ---- phase 3: O^T[d][i] = V^T . w^T, 8 d-tiles x 3 k-steps ---------------------------------------
