@@ -585,15 +585,17 @@ def test_gemm_ring_variants_are_bit_identical():
     And the same digest with the kernels and the tile order of round 3 ("wide_tiles" = 0, "tile_bands" = 0, "t64_tiles" = 127: no 256- / 224-row tiles, the row
     chunk fastest, half-width tiles up to 127 tiles) and with the 256-row form only and column-group bands at every size ("wide_tiles" = 256, "tile_bands" = 1).
     Round 5: and with "resid_epilogue" = 0 -- split-K partial slabs + k_post everywhere, against the default where the residual GEMMs add to the residual
-    stream in their own epilogue (k_gemm_t64w: both K slices in one workgroup; launches without split-K)."""
+    stream in their own epilogue (k_gemm_t64w: both K slices in one workgroup; launches without split-K) -- and with that fold in synchronous steps too
+    ("resid_epilogue" = 2) and the per-frame depthwise conv ("dwconv_stream" = 0), and with "chain" = 2: k_post as the head phase of the GEMM that reads its rows,
+    handed over through per-row-chunk flags inside one launch (measured slower and off by default, but a correct hand-off: same digest)."""
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "opt:gemm_cores=1", "opt:gemm_cores=0", "opt:persistent_gemm=1",
-                        "opt:persistent_gemm=1 opt:gemm_cores=0", "opt:wide_tiles=0 opt:tile_bands=0 opt:t64_tiles=127", "opt:wide_tiles=256 opt:tile_bands=1", "opt:resid_epilogue=0"],
-                       capture_output=True, text=True, timeout=1500)
+                        "opt:persistent_gemm=1 opt:gemm_cores=0", "opt:wide_tiles=0 opt:tile_bands=0 opt:t64_tiles=127", "opt:wide_tiles=256 opt:tile_bands=1", "opt:resid_epilogue=0", "opt:resid_epilogue=2 opt:dwconv_stream=0", "opt:chain=2"],
+                       capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert r.stdout.count("==") == 8 and "!=" not in r.stdout
+    assert r.stdout.count("==") == 10 and "!=" not in r.stdout
 
 
 def test_lanes_option_gives_queues_back_and_keeps_results(W2):

@@ -72,3 +72,25 @@ def test_server_with_mixed_lookaheads_and_sessions_that_come_and_go(tmp_path):
     assert rep["transcripts_correct"] == 12, (rep, [(st.R, st.text[:40]) for st in streams])
     assert srv["eager_outside_stream_end"] <= 2, srv
     assert rep["token_latency_ms"]["p99"] < 400.0, rep          # shapes are captured on the way: a first call of a new batch size costs ~20 ms
+
+
+def test_server_with_four_engines_spreads_the_streams(tmp_path):
+    """`--devices` = one engine + FIFO + worker thread per entry, stream s on entry s mod count (src/nemo-server.cpp has one model and one worker; the
+    N-GPU form of this server is what an 8-GPU node runs).  On the one GPU of a test box: `--devices 0,0,0,0`, 32 live streams (round 4 tested two
+    entries with a handful of streams): every transcript correct, every engine serves calls, and no engine is handed more than its share."""
+    model = sl.write_model(tmp_path / "speech-q8_0.gguf", 24, "q8_0")
+    sock = str(tmp_path / "asr-4dev.sock")
+    proc = sl.start_server(model, sock, 8, 4, extra=("--prewarm", "0", "--devices", "0,0,0,0"))
+    try:
+        rep = sl.run_load(sock, 32, 5.0, 0, "realtime", n_conns=4, client="native", workdir=str(tmp_path))
+    finally:
+        srv, err = sl.stop_server(proc)
+    assert not rep["errors"], rep
+    assert rep["transcripts_correct"] == 32, rep
+    hists = [ln for ln in err.splitlines() if ln.startswith("worker: B histogram")]
+    assert len(hists) == 4, err[-2000:]                      # four workers printed their own histogram
+    for ln in hists:
+        sizes = [int(tok.split(":")[0]) for tok in ln.split()[3:]]
+        calls = sum(int(tok.split(":")[1]) for tok in ln.split()[3:])
+        assert calls > 20 and max(sizes) <= 8, ln            # 32 streams mod 4: eight per engine, never more
+    assert rep["token_latency_ms"]["p99"] < 250.0, rep
