@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void k_melframes(MelParams p) {
         im[i2] = __fsub_rn(q1, ti);
         re[i1] = __fadd_rn(r1, tr);
         im[i1] = __fadd_rn(q1, ti);
-        __syncthreads();
+        // stages m <= 128: the 64 butterflies of a wave read and write only that wave's own 128 elements ([128 wave, +128)), and a wave's LDS
+        // operations execute in order -- no workgroup barrier needed (round 5: 9 -> 3 barriers per frame; same butterflies, same operands, same bits)
+        if (m >= 128) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
     }
     for (int k = threadIdx.x; k < NBINS; k += 256) {
         float mag = sqrtf(__fadd_rn(__fmul_rn(re[k], re[k]), __fmul_rn(im[k], im[k])));  // :201
@@ -344,7 +347,10 @@ __device__ __forceinline__ void diar_frame(const DiarMelParams &p, const Tp *x, 
         im[i2] = __fsub_rn(q1, ti);
         re[i1] = __fadd_rn(r1, tr);
         im[i1] = __fadd_rn(q1, ti);
-        __syncthreads();
+        // stages m <= 128: the 64 butterflies of a wave read and write only that wave's own 128 elements ([128 wave, +128)), and a wave's LDS
+        // operations execute in order -- no workgroup barrier needed (round 5: 9 -> 3 barriers per frame; same butterflies, same operands, same bits)
+        if (m >= 128) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
     }
     for (int k = threadIdx.x; k < NBINS; k += 256) pw[k] = __fadd_rn(__fmul_rn(re[k], re[k]), __fmul_rn(im[k], im[k]));
     __syncthreads();

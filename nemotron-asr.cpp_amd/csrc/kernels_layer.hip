@@ -434,33 +434,41 @@ __global__ __launch_bounds__(256) void k_dwconv(ConvParams p) {
         }
     }
 }
-// ---- the same, one workgroup per STREAM (round 5; kernel size 9, up to 14 frames per stream) ------------------------------------------
+// ---- the same, one workgroup per STREAM (or per half of its frames: below) (round 5; kernel size 9) ------------------------------------------
 // k_dwconv's grid is (streams, frames): every GLU row is fetched by nine workgroups and the conv cache by eight, 7 168 workgroups of one
 // load round trip + two barriers at 512 streams x R = 13 (30 us per launch for 78 MB of algorithmic bytes; with attention 2.3 ms of a
 // 14.6 ms pipelined step, profiles/r5_ablation.md).  Here a workgroup keeps the stream's whole window -- 8 cached rows + T new ones, its 4
 // channels per thread -- in registers: every row is read ONCE, the T outputs are formed in k_dwconv's order, their T LayerNorms share two
 // barriers (per row the sums are k_dwconv's: wave_sum, then (w0 + w1) + (w2 + w3)), and the new cache is the window's last 8 rows.
 // Same bits as k_dwconv (engine option "dwconv_stream" = 0; tests/micro/gemm_variant_identity.py).
+// NF frames per workgroup (7: a stream's 14 frames at 1.12 s lookahead are two workgroups, whose load and compute phases overlap on a CU -- four
+// fit -- where ONE workgroup per stream with all 22 rows in registers was a single round of 2 per CU: 26.2 us per launch at 512 streams).  The second
+// workgroup re-reads the 8 rows in front of its frames; the one that holds the stream's last frame writes the new cache.
+template <int NF>
 __global__ __launch_bounds__(256) void k_dwconv_stream(ConvParams p) {
-    __shared__ float sh[2][TMAX][4];
-    const int b = blockIdx.x, T = p.T;
+    __shared__ float sh[2][NF][4];
+    const int b = blockIdx.x, T = p.T, f0 = blockIdx.y * NF, nf = T - f0 < NF ? T - f0 : NF;
     const int c4 = threadIdx.x * 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RowDesc rd = p.rows[b];
     const float *cc_in = p.cc_pool + (size_t)rd.slot * p.cc_slot_stride + (size_t)rd.cc_par * 8 * D;
     float *cc_out = p.cc_pool + (size_t)rd.slot * p.cc_slot_stride + (size_t)(rd.cc_par ^ 1) * 8 * D;
     const float *g = p.glu + (size_t)b * T * D;
-    float4 z[8 + TMAX], w[9];
+    // local row j = row f0 + j of z = [conv cache (8 rows) ; GLU(new T rows)]
+    float4 z[8 + NF], w[9];
 #pragma unroll
-    for (int r = 0; r < 8; r++) z[r] = *(const float4 *)(cc_in + (size_t)r * D + c4);
-#pragma unroll
-    for (int i = 0; i < TMAX; i++) z[8 + i] = i < T ? *(const float4 *)(g + (size_t)i * D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 8 + NF; j++) {
+        const int r = f0 + j;
+        z[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 8) z[j] = *(const float4 *)(cc_in + (size_t)r * D + c4);
+        else if (r - 8 < T) z[j] = *(const float4 *)(g + (size_t)(r - 8) * D + c4);
+    }
 #pragma unroll
     for (int k = 0; k < 9; k++) w[k] = *(const float4 *)(p.dw + (size_t)k * D + c4);
     const float4 lw = *(const float4 *)(p.ln_w + c4), lb = *(const float4 *)(p.ln_b + c4);
-    float4 acc[TMAX];
-    float s[TMAX];
+    float4 acc[NF];
+    float s[NF];
 #pragma unroll
-    for (int i = 0; i < TMAX; i++) {
+    for (int i = 0; i < NF; i++) {
         float4 a = make_float4(z[i].x * w[0].x, z[i].y * w[0].y, z[i].z * w[0].z, z[i].w * w[0].w);
 #pragma unroll
         for (int k = 1; k < 9; k++) { a.x += z[i + k].x * w[k].x; a.y += z[i + k].y * w[k].y; a.z += z[i + k].z * w[k].z; a.w += z[i + k].w * w[k].w; }
@@ -469,46 +477,48 @@ __global__ __launch_bounds__(256) void k_dwconv_stream(ConvParams p) {
     }
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < TMAX; i++) sh[0][i][wave] = s[i];
+        for (int i = 0; i < NF; i++) sh[0][i][wave] = s[i];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TMAX; i++) {
+    for (int i = 0; i < NF; i++) {
         const float mean = ((sh[0][i][0] + sh[0][i][1]) + (sh[0][i][2] + sh[0][i][3])) * (1.0f / D);
         acc[i].x -= mean; acc[i].y -= mean; acc[i].z -= mean; acc[i].w -= mean;
         s[i] = wave_sum((acc[i].x * acc[i].x + acc[i].y * acc[i].y) + (acc[i].z * acc[i].z + acc[i].w * acc[i].w));
     }
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < TMAX; i++) sh[1][i][wave] = s[i];
+        for (int i = 0; i < NF; i++) sh[1][i][wave] = s[i];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TMAX; i++) {
-        if (i < T) {
+    for (int i = 0; i < NF; i++) {
+        if (i < nf) {
             const float var = ((sh[1][i][0] + sh[1][i][1]) + (sh[1][i][2] + sh[1][i][3])) * (1.0f / D);
             const float inv = 1.0f / sqrtf(var + 1e-5f);
             float4 n = make_float4(acc[i].x * inv * lw.x + lb.x, acc[i].y * inv * lw.y + lb.y, acc[i].z * inv * lw.z + lb.z, acc[i].w * inv * lw.w + lb.w);
             n.x = n.x / (1.0f + __expf(-n.x)); n.y = n.y / (1.0f + __expf(-n.y));          // SiLU :674
             n.z = n.z / (1.0f + __expf(-n.z)); n.w = n.w / (1.0f + __expf(-n.w));
-            store_act4(p.c_out, ((size_t)b * T + i) * D + c4, n, p.act_bf16);
+            store_act4(p.c_out, ((size_t)b * T + f0 + i) * D + c4, n, p.act_bf16);
         }
     }
-    // new conv cache = the window's last 8 rows (:396-408), written to the other buffer
+    // new conv cache = the last 8 rows of z (:396-408), written to the other buffer by the workgroup that holds the stream's last frame: local rows nf + r2
+    if (f0 + nf == T) {
 #pragma unroll
-    for (int r2 = 0; r2 < 8; r2++) {
-        float4 v = z[r2];                          // T = 0 never happens; the row is z[T + r2]
+        for (int r2 = 0; r2 < 8; r2++) {
+            float4 v = z[r2];
 #pragma unroll
-        for (int i = 1; i <= TMAX; i++)
-            if (i == T) v = z[i + r2];
-        *(float4 *)(cc_out + (size_t)r2 * D + c4) = v;
+            for (int i = 1; i <= NF; i++)
+                if (i == nf) v = z[i + r2];
+            *(float4 *)(cc_out + (size_t)r2 * D + c4) = v;
+        }
     }
 }
 void launch_dwconv(const ConvParams &p, hipStream_t st) {
     // from 256 streams: below that too few workgroups (64 streams: 64 of 256 CUs busy, a synchronous step 4.05 -> 4.24 ms); 512 streams x R = 13: 30.3 -> 26.2 us
     // per launch, a pipelined step 14.46 -> 14.18 ms
-    if (p.stream_form && p.ks == 9 && p.T >= 4 && p.T <= TMAX && p.B >= 256) {
-        hipLaunchKernelGGL(k_dwconv_stream, dim3(p.B), dim3(256), 0, st, p);
+    if (p.stream_form && p.ks == 9 && p.T >= 7 && p.T % 7 == 0 && p.B >= 256) {
+        hipLaunchKernelGGL(k_dwconv_stream<7>, dim3(p.B, p.T / 7), dim3(256), 0, st, p);
         return;
     }
     hipLaunchKernelGGL(k_dwconv, dim3(p.B, p.T), dim3(256), 0, st, p);
