@@ -285,3 +285,34 @@ def test_stale_kv_rows_never_reach_a_result(W2, dtype, R):
         assert np.array_equal(g[2], ref[2]), float(np.abs(g[2] - ref[2]).max())
         for a, b in zip(g[3], ref[3]):
             assert np.array_equal(a, b)
+
+
+def test_256_streams_R6_vs_oracle(W2):
+    """256 streams x R = 6 (T = 7, 1 792 rows): the shapes round 5's small kernels take besides 512 x R = 13 -- k_dwconv_stream<7> with ONE workgroup per
+    stream (it also writes the cache), k_sub_dw_row at another image height, split-K partial slabs + k_post at a size where the residual fold does not apply
+    (two K slices of 128 x 128 tiles).  Spot streams' encoder output of every step and their K / V / conv caches against the bf16-emulating oracle, pipelined."""
+    L, B, R, T = 2, 256, 6, 7
+    eng = capi.Engine(W2, n_layers=L, dtype=capi.DTYPE_BF16, max_streams=B)
+    eng.set_option("pipeline", 4)
+    om = ob.OracleModel(W2, L, emulate_bf16=True)
+    n = synth.shift_samples(R)
+    n_push = 5
+    pcms = [synth.make_pcm(1700 + (b % 61) * 7 + b // 61, n_push * n / 16000 + 0.01)[:n_push * n] for b in range(B)]
+    spots = (0, 85, 170, 255)
+    sts = [eng.stream(R) for _ in range(B)]
+    osts = {b: ob.OracleStream(om, R) for b in spots}
+    taps = {b: osts[b].enable_taps() for b in spots}
+    worst = 0.0
+    for k in range(n_push):
+        eng.step(sts, [p[k * n:(k + 1) * n] for p in pcms])
+        for b in spots:
+            c0 = osts[b].total_chunks
+            osts[b].process(pcms[b][k * n:(k + 1) * n])
+            if osts[b].total_chunks > c0:
+                got = sts[b].tap(capi.TAP_ENCODER_OUT).reshape(-1, 1024)[:T]
+                worst = max(worst, float(np.abs(got - taps[b][1][L - 1]).max()))
+    assert all(osts[b].total_chunks == n_push - 1 for b in spots)
+    assert worst < 3e-2, worst
+    kv = max(_spot_state_vs_oracle(sts[b], osts[b], L, T) for b in spots)
+    assert kv < 1.2e-1, kv
+    eng.close()
