@@ -22,6 +22,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
     }
     else if (!strcmp(key, "dwconv_stream")) e->opt_dwconv_stream = value != 0;      // like "fused": set before the first step
     else if (!strcmp(key, "chain")) { if (value < 0 || value > 2) return fail("chain must be 0, 1 or 2"); e->opt_chain = value; }      // like "fused": set before the first step
+    else if (!strcmp(key, "split_tasks")) e->opt_split_tasks = value;                // like "fused": set before the first step
     else if (!strcmp(key, "resid_epilogue")) { if (value < 0 || value > 2) return fail("resid_epilogue must be 0, 1 or 2"); e->opt_resid_epilogue = value; }      // like "fused": set before the first step
     else if (!strcmp(key, "ablate")) e->opt_ablate = value;          // measurement only (see the header); before the first step
     else if (!strcmp(key, "f32_mfma")) e->opt_f32_mfma = value != 0;      // 0: f32 GEMMs above four rows on the FMA tile kernel (round 3's path); like "fused", set before the first step

@@ -35,6 +35,10 @@ int pick_splits(const nasr_engine *e, int M, int N, int K) {
     // kernels: four splits only up to 40 tiles (three lanes, R = 13: 12 / 16 streams = 32 tiles 1.15 / 1.23 ms with 4 splits
     // against 1.23 / 1.30 with 2; 24 streams = 48 tiles 1.53 vs 1.50; 32 streams = 64 tiles 1.82 vs 1.68; 64 streams = 112 tiles:
     // 2 splits 2.76, 1 split 2.75, 4 splits 3.03)
+    // Round 5: one slice from 200 tiles of 128 x 128 (256 streams x R = 13: 224 tiles, 7.76 -> 7.48 ms per pipelined step): that many workgroups fill the chip
+    // by themselves, and a GEMM that owns its tiles' whole K sums adds to the residual stream in its own epilogue -- no partial slabs, k_post is the
+    // LayerNorm alone.  Counted in 128 x 128 tiles whatever the tile the launcher takes, so that every kernel variant sums in the same order.
+    if (!skinny && (N / 128) * ((M + 127) / 128) >= (e->opt_split_tasks > 0 ? e->opt_split_tasks : 200)) return 1;
     if (!skinny) return tasks <= 40 ? 4 : (tasks < 256 ? 2 : 1);
     constexpr int skinny_cap = 8;
     int s = 1;
