@@ -166,8 +166,54 @@ __device__ __forceinline__ void stage_acc(float *stage, int m_local, int n_local
 }
 // The two bulk outputs (split-K partials, SiLU activations: 7-15 MB per launch) are stored write-through (sc0 sc1): nothing
 // dirty is left in L2 for the end of the kernel to write back (gemm_probe: -0.4 ... -1.3 us per launch).
+// 16-byte stores for the 16-bit / paired outputs (round 5): with four columns per thread the SiLU rows, the K / V ring rows and the GLU pairs left as 8-byte
+// stores -- write-through 8-byte stores cost 2.7 x a 16-byte store per byte (MI355X_MICROARCH.md, stores of each flavour), and k_post's move to 16-byte
+// stores was most of what k_post_wave gained.  Eight columns per thread here: same values, half the store instructions, twice the bytes each.
+__device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
+    uint4 r;
+    r.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    r.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    r.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    r.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    return r;
+}
+// one item of eight consecutive columns n0 .. n0 + 7 of row m (n0 % 8 == 0) for the three epilogues with narrow elements; returns false for the others
+__device__ __forceinline__ bool epi_oct(const GemmParams &p, int m, int n0, const float (&v)[8]) {
+    if (p.epi == EPI_SILU_ACT) {
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = silu_f(v[i]);
+        store_u4((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0, pack8_bf16(s));
+        return true;
+    }
+    if (p.epi == EPI_GLU) {                    // (value, gate) pairs: four outputs
+        store_wt_f4(p.out_f32 + (size_t)m * p.ldo + (n0 >> 1), make_float4(v[0] * sigmoid_f(v[1]), v[2] * sigmoid_f(v[3]), v[4] * sigmoid_f(v[5]), v[6] * sigmoid_f(v[7])));
+        return true;
+    }
+    if (p.epi == EPI_QKV && n0 >= 1024) {      // K / V ring rows (the query columns stay f32: epi_quad)
+        const int which = n0 >> 10, col = n0 & 1023;
+        const int b = m / p.T, i = m - b * p.T;
+        const RowDesc rd = p.rows[b];
+        int ring = rd.kv_head + LCTX + i;
+        if (ring >= KVC) ring -= KVC;
+        const size_t off = (size_t)rd.slot * p.kv_slot_stride + ((size_t)(which - 1) * KVC + ring) * D + col;
+        *(uint4 *)((bf16_t *)p.kv_pool + off) = pack8_bf16(v);
+        return true;
+    }
+    return false;
+}
 template <int NTHREADS>
 __device__ __forceinline__ void staged_epilogue(const GemmParams &p, int split, int m0, int n_base, const float *stage) {
+    if (!p.narrow_stores && (p.epi == EPI_SILU_ACT || p.epi == EPI_GLU || p.epi == EPI_QKV)) {
+        for (int e = threadIdx.x; e < TM * 16; e += NTHREADS) {
+            const int row = e >> 4, c8 = (e & 15) * 8, m = m0 + row, n0 = n_base + c8;
+            if (m >= p.M) continue;
+            const float4 a = *(const float4 *)(stage + row * STG_LD + c8), b = *(const float4 *)(stage + row * STG_LD + c8 + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (!epi_oct(p, m, n0, v)) { epi_quad<true>(p, split, m, n0, a.x, a.y, a.z, a.w); epi_quad<true>(p, split, m, n0 + 4, b.x, b.y, b.z, b.w); }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < TM * 32; e += NTHREADS) {
         const int row = e >> 5, c4 = (e & 31) * 4, m = m0 + row, n0 = n_base + c4;
         const float4 v = *(const float4 *)(stage + row * STG_LD + c4);
@@ -972,7 +1018,7 @@ template <int BN, int MT> struct WideCfg {
     static constexpr int STG_LD = BN + 4;                     // floats per staged row
     static constexpr size_t LDS = (size_t)WD_NS * SLOT > (size_t)64 * (BN + 4) * 4 ? (size_t)WD_NS * SLOT : (size_t)64 * (BN + 4) * 4;
 };
-template <int BN, int MT>
+template <int BN, int MT, int PV = 0>
 __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, int m_chunks) {
     using C = WideCfg<BN, MT>;
     constexpr int P = WD_NS - 1, NT = C::NT, DMA = C::DMA, BM = C::BM;
@@ -1036,12 +1082,27 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
         uint4 wf[NT];
 #pragma unroll
         for (int j = 0; j < NT; j++) wf[j] = *(const uint4 *)(sp + BM * 64 + (nq * NT + j) * 1024 + lane * 16);
+        if constexpr (PV == 2) {          // probe: every fragment first, then the MFMAs as one prioritised cluster (the guide's phase form)
+            uint4 bvs[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
-            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+            for (int mt = 0; mt < MT; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, bvs[mt]), acc[j][mt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            if constexpr (PV == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
+            }
+            if constexpr (PV == 1) __builtin_amdgcn_s_setprio(0);
         }
         slot = slot + 1 == WD_NS ? 0 : slot + 1;
     }
@@ -1074,6 +1135,16 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
                 }
         }
         __syncthreads();
+        if (!p.narrow_stores && (p.epi == EPI_SILU_ACT || p.epi == EPI_GLU || p.epi == EPI_QKV)) {          // eight columns per thread: 16-byte stores (epi_oct)
+            for (int e = threadIdx.x; e < nrows * (BN / 8); e += 512) {
+                const int row = e / (BN / 8), c8 = (e - row * (BN / 8)) * 8, m = m0 + rows0 + row, n0 = ng * BN + c8;
+                if (m >= p.M) continue;
+                const float4 a = *(const float4 *)(stage + row * C::STG_LD + c8), b = *(const float4 *)(stage + row * C::STG_LD + c8 + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (!epi_oct(p, m, n0, v)) { epi_quad<true>(p, 0, m, n0, a.x, a.y, a.z, a.w); epi_quad<true>(p, 0, m, n0 + 4, b.x, b.y, b.z, b.w); }
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) {          // 64 rows x BN / 4 quads = 8 per thread at BN = 256
             const int e = threadIdx.x + k * 512;
@@ -1120,6 +1191,8 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 8>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
     hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
@@ -1253,7 +1326,9 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 return;
             }
             if (best_mt == 7) {
-                hipLaunchKernelGGL((k_gemm_wide<256, 7>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
+                if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_wide<256, 7, 1>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
+                else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_wide<256, 7, 2>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
+                else hipLaunchKernelGGL((k_gemm_wide<256, 7>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 return;
             }
         }

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void k_post(PostParams p) {
     post_row(p, blockIdx.x, threadIdx.x, sh, true);          // nasr_post.h: the same body runs in the head phase of a chained GEMM launch
 }
 void launch_post(const PostParams &p, hipStream_t st) {
-    // (also measured SLOWER at 7 168 rows: a LayerNorm-only form with four rows per workgroup, all loads first, full occupancy: 16.2 against 14.3 us)
+    // (also measured at 7 168 rows: a LayerNorm-only form with four rows per workgroup, all loads first, full occupancy: 16.2 against 14.3 us; one WAVE per
+    // row with 16-byte stores and no barrier: 13.51 against 13.58 ms per 512-stream step, 2.43 against 2.40 at 64 streams -- nothing: profiles/r5_configs2_launch_structure.md)
     // (round 5: two rows per workgroup with both rows' loads in flight before the first reduction measured SLOWER at 7 168 rows: 16.5 against 14.0 us)
     hipLaunchKernelGGL(k_post, dim3(p.M), dim3(256), 0, st, p);
 }
