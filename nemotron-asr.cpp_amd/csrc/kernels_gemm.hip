@@ -377,7 +377,7 @@ __device__ __forceinline__ void chain_wait(const ChainParams &c, int mc, int chu
 
 constexpr int K32_SLOT = 16384;
 __device__ __forceinline__ int panel32_off(int row, int col) { return row * 64 + ((col ^ ((0 - (row >> 2)) & 3)) << 4); }
-template <int NS>
+template <int NS, int PV = 0>
 __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_groups, int m_chunks) {
     constexpr int P = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -446,6 +446,23 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
         const char *sp = ring + slot * K32_SLOT;
         const char *wl = sp + 8192 + ng4 * 2048 + lane * 16;
         const uint4 w0 = *(const uint4 *)(wl), w1 = *(const uint4 *)(wl + 1024);
+        if constexpr (PV == 2) {          // probe: the DMA first, every fragment, then the eight MFMAs as one prioritised cluster
+            if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);
+            uint4 bvs[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, bvs[mt]), acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, bvs[mt]), acc[1][mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            continue;
+        }
+        if constexpr (PV == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
             const uint4 bv = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
@@ -453,6 +470,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
             acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), bf, acc[0][mt], 0, 0, 0);
             acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), bf, acc[1][mt], 0, 0, 0);
         }
+        if constexpr (PV == 1) __builtin_amdgcn_s_setprio(0);
         if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);     // the slot chunk i - 1 has just left
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
@@ -1183,6 +1201,8 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_t64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_t64w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T64W_HALF);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_PART_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_SILU_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
@@ -1348,7 +1368,9 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         }
         dim3 grid(n_groups * m_chunks * p.splits);
         if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU
-            hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 1>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 2>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            else hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             return;
         }
         constexpr int roles_min_chunks = 8;

@@ -20,6 +20,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         if (e->pipe_ready) return fail("decode_lane must be set before the first pipelined step (the lanes are already picked)");
         e->opt_decode_lane = value != 0;
     }
+    else if (!strcmp(key, "gemm_prio")) e->opt_gemm_prio = value;                    // probe: GemmParams::prio (measurement only)
     else if (!strcmp(key, "epilogue16")) e->opt_epilogue16 = value != 0;            // like "fused": set before the first step
     else if (!strcmp(key, "dwconv_stream")) e->opt_dwconv_stream = value != 0;      // like "fused": set before the first step
     else if (!strcmp(key, "chain")) { if (value < 0 || value > 2) return fail("chain must be 0, 1 or 2"); e->opt_chain = value; }      // like "fused": set before the first step

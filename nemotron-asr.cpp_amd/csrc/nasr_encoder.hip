@@ -21,6 +21,7 @@ int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
     g.tile_bands = e->opt_tile_bands < 0 ? 0 : e->opt_tile_bands == 0 ? 2 : 1;
     g.t64_tiles_p1 = e->opt_t64_tiles + 1;
     g.narrow_stores = e->opt_epilogue16 ? 0 : 1;
+    g.prio = e->opt_gemm_prio;
     if (e->opt_ablate & 32) return 0;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);
