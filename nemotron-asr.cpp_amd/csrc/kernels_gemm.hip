@@ -21,6 +21,7 @@
 //     same order per accumulator: which one runs never changes a bit of the result (tests/micro/gemm_variant_identity.py).
 // f32 path (parity mode): plain LDS-tiled FMA kernel, k ascending, deterministic.
 #include "nasr_internal.h"
+#include <type_traits>
 #include "nasr_epilogue.h"
 #include "nasr_wave.h"
 #include "nasr_post.h"
@@ -446,6 +447,25 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
         const char *sp = ring + slot * K32_SLOT;
         const char *wl = sp + 8192 + ng4 * 2048 + lane * 16;
         const uint4 w0 = *(const uint4 *)(wl), w1 = *(const uint4 *)(wl + 1024);
+        if constexpr (PV == 3) {          // probe: every fragment first, the two DMA instructions between the MFMA pairs
+            uint4 bvs[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
+            const bool more = i + P < nchunks;
+            const unsigned sb = ring_base + (slot == 0 ? NS - 1 : slot - 1) * K32_SLOT;
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, bvs[mt]), acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, bvs[mt]), acc[1][mt], 0, 0, 0);
+                if (mt < 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) { if (mt == 0) glds16(asrc + (size_t)(t0 + i + P) * 64, sb + wave * 1024); else glds16(wpd + (size_t)(t0 + i + P) * 64, sb + 8192 + wave * 1024); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            continue;
+        }
         if constexpr (PV == 2) {          // probe: the DMA first, every fragment, then the eight MFMAs as one prioritised cluster
             if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);
             uint4 bvs[4];
@@ -475,6 +495,103 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
     if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
+    __syncthreads();                           // every wave is done with the ring
+    float *stage = (float *)ring;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (ng4 * 2 + j) * 16 + q * 4, acc[j][mt]);
+    __syncthreads();
+    staged_epilogue<512>(p, split, m0, ng * 128, stage);
+}
+
+// k_gemm_tiled3 (round 5): k_gemm_tiled2_k32's tile, MFMAs and order with k_gemm_wide2's loop (below): the fragments of chunk i + 1 are read into a second
+// register set under chunk i's MFMAs, the two DMA instructions of chunk i + 5 go out between the MFMA pairs, five slots of 16 KiB (80 KiB: still two
+// workgroups per CU).  Needs an even number of chunks >= 6 per K slice; no chained head phase.
+constexpr int T3_NS = 5;
+__global__ __launch_bounds__(512) void k_gemm_tiled3(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int NS = T3_NS;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    int mc, ng, split;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ng4 = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int t0 = 2 * (int)((long)kc_total * split / p.splits), t1 = 2 * (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = t1 - t0, m0 = mc * TM;
+    const char *wpd = (const char *)((const uint4 *)p.W + (size_t)(ng * 8 + wave) * KT * 64 + lane) + (size_t)t0 * 1024;
+    const char *asrc;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        asrc = a_row_ptr(p, m, 2) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4) + (size_t)t0 * 64;
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 fw[2][2], fa[2][4];
+    const unsigned w_off = 8192 + ng4 * 2048 + lane * 16;
+    unsigned a_off[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) a_off[mt] = panel32_off((mh * 4 + mt) * 16 + r, q);
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+        glds16(asrc + (size_t)c * 64, ring_base + c * K32_SLOT + wave * 1024);
+        glds16(wpd + (size_t)c * 1024, ring_base + c * K32_SLOT + 8192 + wave * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    fw[0][0] = *(const uint4 *)(ring + w_off); fw[0][1] = *(const uint4 *)(ring + w_off + 1024);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) fa[0][mt] = *(const uint4 *)(ring + a_off[mt]);
+    int slot = 0;
+    auto body = [&](int i, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value, nxt = 1 - cur;
+        const bool has_next = i + 1 < nchunks;
+        const int nslot = slot + 1 == NS ? 0 : slot + 1;
+        if (has_next) {
+            const int left = nchunks - 2 - i;
+            if (left >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NS - 2)) : "memory");
+            else if (left == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // chunk i + 1 has landed; every wave holds chunk i in registers: its slot is free
+        }
+        const char *sp = ring + nslot * K32_SLOT;
+        const bool more = i + NS < nchunks;
+        const unsigned sb = ring_base + slot * K32_SLOT;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[cur][0]), __builtin_bit_cast(bf16x8, fa[cur][mt]), acc[0][mt], 0, 0, 0);
+            acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[cur][1]), __builtin_bit_cast(bf16x8, fa[cur][mt]), acc[1][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                if (mt == 0) { fw[nxt][0] = *(const uint4 *)(sp + w_off); fw[nxt][1] = *(const uint4 *)(sp + w_off + 1024); }
+                if (mt == 1) { fa[nxt][0] = *(const uint4 *)(sp + a_off[0]); fa[nxt][1] = *(const uint4 *)(sp + a_off[1]); }
+                if (mt == 2) { fa[nxt][2] = *(const uint4 *)(sp + a_off[2]); fa[nxt][3] = *(const uint4 *)(sp + a_off[3]); }
+            }
+            if (more) {
+                if (mt == 0) glds16(asrc + (size_t)(i + NS) * 64, sb + wave * 1024);
+                if (mt == 1) glds16(wpd + (size_t)(i + NS) * 1024, sb + 8192 + wave * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+    };
+    for (int i = 0; i < nchunks; i += 2) {
+        body(i, std::integral_constant<int, 0>{});
+        body(i + 1, std::integral_constant<int, 1>{});
+    }
     __syncthreads();                           // every wave is done with the ring
     float *stage = (float *)ring;
 #pragma unroll
@@ -1095,12 +1212,28 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
         else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
-        if (i + P < KT) issue(i + P, slot == 0 ? WD_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
+        if (PV != 3 && i + P < KT) issue(i + P, slot == 0 ? WD_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
         const char *sp = ring + slot * C::SLOT;
         uint4 wf[NT];
 #pragma unroll
         for (int j = 0; j < NT; j++) wf[j] = *(const uint4 *)(sp + BM * 64 + (nq * NT + j) * 1024 + lane * 16);
-        if constexpr (PV == 2) {          // probe: every fragment first, then the MFMAs as one prioritised cluster (the guide's phase form)
+        if constexpr (PV == 3) {          // probe: every fragment first, then the chunk's DMA instructions one by one BETWEEN the MFMA groups (their issue cost under the matrix pipe)
+            uint4 bvs[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
+            const bool more = i + P < KT;
+            const unsigned sb = ring_base + (slot == 0 ? WD_NS - 1 : slot - 1) * C::SLOT;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, bvs[mt]), acc[j][mt], 0, 0, 0);
+                if (mt < DMA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) glds16(src[mt] + (size_t)(i + P) * step[mt], sb + dst[mt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (PV == 2) {          // probe: every fragment first, then the MFMAs as one prioritised cluster (the guide's phase form)
             uint4 bvs[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
@@ -1180,6 +1313,196 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
     }
 }
 
+// Row-wise output of one wave's block parked in its own LDS region (stg[row][col], WE_LD floats per row): COLS = 64 columns, `rows` rows starting at
+// (m_base, n_base) of the GEMM.  16-bit outputs: eight columns per lane, eight rows per wave instruction (128-byte segments); f32 outputs: four columns
+// per lane, four rows per instruction (256-byte segments); the residual form requests eight instructions' worth of residual values ahead.
+constexpr int WE_LD = 68;
+template <int COLS>
+__device__ __forceinline__ void wave_epilogue_rows(const GemmParams &p, const float *stg, int rows, int m_base, int n_base, int lane) {
+    static_assert(COLS == 64, "lane maps below");
+    if (!p.narrow_stores && (p.epi == EPI_SILU_ACT || p.epi == EPI_GLU || p.epi == EPI_QKV)) {
+        const int lr = lane >> 3, c8 = (lane & 7) * 8;
+        for (int r0 = 0; r0 < rows; r0 += 8) {
+            const int row = r0 + lr, m = m_base + row, n0 = n_base + c8;
+            const float4 a = *(const float4 *)(stg + row * WE_LD + c8), b = *(const float4 *)(stg + row * WE_LD + c8 + 4);
+            if (m >= p.M) continue;
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (!epi_oct(p, m, n0, v)) { epi_quad<true>(p, 0, m, n0, a.x, a.y, a.z, a.w); epi_quad<true>(p, 0, m, n0 + 4, b.x, b.y, b.z, b.w); }
+        }
+        return;
+    }
+    const int lr = lane >> 4, c4 = (lane & 15) * 4, n0 = n_base + c4;
+    if (p.epi == EPI_RESID_F32) {
+        for (int r0 = 0; r0 < rows; r0 += 32) {          // rows is a multiple of 16: the second half of the last batch may be empty
+            float4 xq[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int row = r0 + k * 4 + lr, m = m_base + row;
+                xq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows && m < p.M) xq[k] = *(const float4 *)(p.resid + (size_t)m * p.ldo + n0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int row = r0 + k * 4 + lr, m = m_base + row;
+                if (row >= rows || m >= p.M) continue;
+                const float4 v = *(const float4 *)(stg + row * WE_LD + c4);
+                store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, make_float4(__builtin_fmaf(p.resid_scale, v.x, xq[k].x), __builtin_fmaf(p.resid_scale, v.y, xq[k].y),
+                                                                           __builtin_fmaf(p.resid_scale, v.z, xq[k].z), __builtin_fmaf(p.resid_scale, v.w, xq[k].w)));
+            }
+        }
+        return;
+    }
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int row = r0 + lr, m = m_base + row;
+        const float4 v = *(const float4 *)(stg + row * WE_LD + c4);
+        if (m >= p.M) continue;
+        if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
+        else if (p.epi == EPI_SILU_ACT) store_wt_u2((bf16_t *)p.out_act + (size_t)m * p.ldo_act + n0, pack4_bf16(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)));
+        else epi_quad<true>(p, 0, m, n0, v.x, v.y, v.z, v.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_gemm_wide2 (round 5): the same 224 x 256 tile, the same MFMAs in the same order (k ascending per accumulator: the bits of k_gemm_wide), another
+// loop.  k_gemm_wide's iteration is barrier -> 4 DMA instructions -> 6 + 5 ds_read_b128 -> wait -> 28 MFMAs: both waves of a SIMD stand in the same
+// phase, so the matrix pipe idles through every chunk's DMA issue (~100+ cycles each inside a phase that also reads, MI355X_MICROARCH.md) and LDS
+// latency -- ~2 200 cycles per chunk against 896 of MFMA.  Here the fragments of chunk i + 1 are read into a SECOND register set while chunk i's
+// MFMAs run (the barrier of iteration i certifies chunk i + 1, one ahead), and the DMA instructions of chunk i + 5 go out one by one between the
+// MFMA groups.  Five ring slots (150 KiB) keep the DMA look-ahead at four iterations.  Needs K / 32 even and >= 8.
+// ------------------------------------------------------------------------------------
+constexpr int W2_NS = 5;
+#ifdef NASR_GEMM_STAMPS
+#define GSTAMP(k) do { if (p.stamps && threadIdx.x == 0) { if ((k) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 3) p.stamps[(size_t)blockIdx.x * 8 + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define GSTAMP(k)
+#endif
+template <int BN, int MT>
+__global__ __launch_bounds__(512) void k_gemm_wide2(GemmParams p, int n_groups, int m_chunks) {
+    using C = WideCfg<BN, MT>;
+    constexpr int NS = W2_NS, NT = C::NT, DMA = C::DMA, BM = C::BM;
+    GSTAMP(0);
+    static_assert(MT >= DMA + 1, "one DMA instruction after each of the first DMA MFMA groups");
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    int mc, ng, split_unused;
+    tile_of(id, n_groups, m_chunks, p.tile_bands == 2 ? 2 : 1, mc, ng, split_unused);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nq = wave & 3, mh = wave >> 2, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, m0 = mc * BM;
+    const char *src[DMA];
+    unsigned dst[DMA];
+    int step[DMA];
+#pragma unroll
+    for (int u = 0; u < DMA; u++) {
+        int j = wave * DMA + u;
+        if (j >= C::PIECES) j = C::PIECES - 1;
+        if (j < C::NP) {
+            const int row = j * 16 + (lane >> 2);
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            src[u] = a_row_ptr(p, m, 2) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
+            dst[u] = (unsigned)(j * 1024);
+            step[u] = 64;
+        } else {
+            const int t = j - C::NP;
+            src[u] = (const char *)p.W + (size_t)(ng * (BN / 16) + t) * KT * 1024 + lane * 16;
+            dst[u] = (unsigned)(BM * 64 + t * 1024);
+            step[u] = 1024;
+        }
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 fw[2][NT], fa[2][MT];
+    const unsigned w_off = BM * 64 + nq * NT * 1024 + lane * 16;
+    unsigned a_off[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) a_off[mt] = panel32_off(mh * (BM / 2) + mt * 16 + r, q);
+    // prologue: chunks 0 .. NS - 1 on their way, chunk 0 landed, its fragments into set 0
+#pragma unroll
+    for (int c = 0; c < NS; c++)
+#pragma unroll
+        for (int u = 0; u < DMA; u++) glds16(src[u] + (size_t)c * step[u], ring_base + c * C::SLOT + dst[u]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA * (NS - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    GSTAMP(1);
+#pragma unroll
+    for (int j = 0; j < NT; j++) fw[0][j] = *(const uint4 *)(ring + w_off + j * 1024);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) fa[0][mt] = *(const uint4 *)(ring + a_off[mt]);
+    int slot = 0;          // slot of chunk i
+    auto body = [&](int i, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value, nxt = 1 - cur;
+        const bool has_next = i + 1 < KT;
+        const int nslot = slot + 1 == NS ? 0 : slot + 1;
+        if (has_next) {
+            const int left = KT - 2 - i;          // chunks after i + 1 that may still be in flight: min(left, NS - 2)
+            if (left >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA * (NS - 2)) : "memory");
+            else if (left == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA * 2) : "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // chunk i + 1 has landed (every wave's pieces); every wave holds chunk i in registers: its slot is free
+        }
+        const char *sp = ring + nslot * C::SLOT;
+        const bool more = i + NS < KT;
+        const unsigned sb = ring_base + slot * C::SLOT;
+        // the first MFMA group goes out before any new read: hipcc's own lgkmcnt wait in front of it (it cannot see the asm wait above) then waits for nothing
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[cur][j]), __builtin_bit_cast(bf16x8, fa[cur][mt]), acc[j][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                if (mt == 0) {
+#pragma unroll
+                    for (int j = 0; j < NT; j++) fw[nxt][j] = *(const uint4 *)(sp + w_off + j * 1024);
+                } else {
+#pragma unroll
+                    for (int k = 3 * (mt - 1); k < 3 * mt; k++)
+                        if (k < MT) fa[nxt][k] = *(const uint4 *)(sp + a_off[k]);
+                }
+            }
+            if (mt < DMA && more) glds16(src[mt] + (size_t)(i + NS) * step[mt], sb + dst[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+    };
+    for (int i = 0; i < KT; i += 2) {
+        body(i, std::integral_constant<int, 0>{});
+        body(i + 1, std::integral_constant<int, 1>{});
+    }
+    GSTAMP(2);
+    // epilogue, wave-private (round 5: in-kernel stamps of the staged four-pass form of k_gemm_wide: 23 000 cycles of a 71 500-cycle W1 tile, eight
+    // workgroup barriers with half of the waves idle in each staging step).  Every wave parks ITS 112 x 64 block in its own 17 KiB of the ring, 64 rows then
+    // 48, and writes it out row-wise: 128-byte (16-bit outputs) or 256-byte (f32) row segments, no barrier after the one that ends the K loop
+    // (a wave's LDS accesses execute in order).  Same epi_oct / epi_quad per item: same values.
+    __syncthreads();                           // every wave is done with the ring
+    float *stg = (float *)ring + wave * (64 * WE_LD);
+#pragma unroll
+    for (int part = 0; part < 2; part++) {
+        constexpr int HALF = BM / 2;
+        const int nmt = part ? MT - 4 : 4;
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int mt4 = 0; mt4 < 4; mt4++) {
+                if (part * 4 + mt4 >= MT) continue;
+                const f32x4 &a = acc[j][part * 4 + mt4];
+                *(float4 *)(stg + (mt4 * 16 + r) * WE_LD + j * 16 + q * 4) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        wave_epilogue_rows<NT * 16>(p, stg, nmt * 16, m0 + mh * HALF + part * 64, ng * BN + nq * (NT * 16), lane);
+    }
+    GSTAMP(3);
+}
+
 static size_t gemm_lds_bytes(int ns) {     // the ring, or the f32 tile the epilogue parks in it, whichever is larger
     const size_t ring = (size_t)ns * G2_SLOT, stage = (size_t)TM * STG_LD * 4;
     return ring > stage ? ring : stage;
@@ -1201,8 +1524,10 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_t64<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * T64_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_t64w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T64W_HALF);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_tiled3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NS * K32_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
+    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_PART_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_SILU_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
@@ -1211,8 +1536,10 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 8>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide2<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_NS * WideCfg<256, 7>::SLOT);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
+    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
     hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
@@ -1346,8 +1673,10 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 return;
             }
             if (best_mt == 7) {
-                if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_wide<256, 7, 1>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
+                if ((p.prio >> 2) == 4 && (p.K & 63) == 0 && p.K >= 256) hipLaunchKernelGGL((k_gemm_wide2<256, 7>), dim3((unsigned)best_tiles), dim3(512), (W2_NS * WideCfg<256, 7>::SLOT), st, p, p.N / 256, (p.M + 223) / 224);
+                else if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_wide<256, 7, 1>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_wide<256, 7, 2>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
+                else if ((p.prio >> 2) == 3) hipLaunchKernelGGL((k_gemm_wide<256, 7, 3>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 else hipLaunchKernelGGL((k_gemm_wide<256, 7>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 return;
             }
@@ -1367,9 +1696,14 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             }
         }
         dim3 grid(n_groups * m_chunks * p.splits);
+        if (gemm_coresident(p) && (p.prio >> 2) == 4 && ((p.K >> 6) / p.splits) * 2 >= 6 && (p.K >> 6) % p.splits == 0) {
+            hipLaunchKernelGGL(k_gemm_tiled3, grid, dim3(512), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);
+            return;
+        }
         if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU
             if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 1>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 2>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            else if ((p.prio >> 2) == 3) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 3>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             else hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             return;
         }

@@ -163,6 +163,9 @@ struct GemmParams {
     int t64_tiles_p1;
     int narrow_stores;    // 1: four columns per thread in every epilogue (engine option "epilogue16" = 0: rounds 1-4's 8-byte stores of the 16-bit outputs)
     ChainParams chain;
+#ifdef NASR_GEMM_STAMPS
+    unsigned long long *stamps;   // tests/micro/prio_probe.hip only (its own compile of kernels_gemm.hip): per workgroup 8 values, see k_gemm_wide2
+#endif
 };
 
 // ---- kernel launchers (defined in the .hip files) -----------------------------------

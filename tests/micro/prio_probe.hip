@@ -1,5 +1,5 @@
 // Round 5: wave priority around the MFMA cluster of the large-M GEMM loops (cdna_hip_programming.md: s_setprio(1) ... s_setprio(0) around the MFMAs of a phase), cold operands.
-// GemmParams::prio >> 2: 0 = shipped loop, 1 = setprio pair around the interleaved read + MFMA block, 2 = every fragment first, lgkmcnt(0), then the MFMAs as one prioritised cluster.
+// GemmParams::prio >> 2: 4 = k_gemm_wide2 (fragments of the next chunk read under this chunk's MFMAs, DMA between the MFMA groups, five slots), 3 = DMA between the MFMA groups only, 0 = shipped loop, 1 = setprio pair around the interleaved read + MFMA block, 2 = every fragment first, lgkmcnt(0), then the MFMAs as one prioritised cluster.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../nemotron-asr.cpp_amd/csrc -c prio_probe.hip -o /tmp/prp.o && hipcc --offload-arch=gfx950 -o prio_probe /tmp/prp.o ../../nemotron-asr.cpp_amd/csrc/kernels_gemm.o
 #include "nasr_internal.h"
 #include <cstdio>
@@ -27,9 +27,9 @@ int main(int argc, char **argv) {
         {"Wo  N=1024 K=1024 f32", 1024, 1024, EPI_PART_F32}, {"pw1 N=2048 K=1024 GLU", 2048, 1024, EPI_GLU}, {"QKV-shaped N=3072 K=1024 f32", 3072, 1024, EPI_PART_F32}};
     for (int M : Ms)
         for (const Shape &s : shapes) {
-            double us[3][2];
+            double us[5][2];
             for (int rep = 0; rep < 2; rep++)
-                for (int pv = 0; pv < 3; pv++) {
+                for (int pv = 0; pv < 5; pv++) {
                     GemmParams g;
                     memset(&g, 0, sizeof(g));
                     g.A = A; g.W = W; g.M = M; g.N = s.N; g.K = s.K; g.lda = s.K; g.splits = 1; g.epi = s.epi;
@@ -51,8 +51,10 @@ int main(int argc, char **argv) {
                     us[pv][rep] = 1e3 * ms / reps;
                 }
             const double fl = 2.0 * M * s.N * s.K * 1e-6;
-            printf("[cold] M = %5d  %-30s shipped %7.2f / %7.2f us (%5.0f TFLOP/s) | setprio pair %7.2f / %7.2f (%5.0f) | cluster %7.2f / %7.2f (%5.0f)\n", M, s.name,
-                   us[0][0], us[0][1], fl / us[0][1], us[1][0], us[1][1], fl / us[1][1], us[2][0], us[2][1], fl / us[2][1]);
+            printf("[cold] M = %5d  %-30s", M, s.name);
+            const char *nm[5] = {"shipped", "setprio pair", "cluster", "dma between", "wide2"};
+            for (int pv = 0; pv < 5; pv++) printf(" | %s %7.2f / %7.2f us (%5.0f TF)", nm[pv], us[pv][0], us[pv][1], fl / std::min(us[pv][0], us[pv][1]));
+            printf("\n");
         }
     return 0;
 }
