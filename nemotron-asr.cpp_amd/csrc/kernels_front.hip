@@ -213,11 +213,18 @@ __global__ __launch_bounds__(256) void k_sub_conv0_dw(const RowDesc *rows, int c
 #pragma unroll
                     for (int kh = 0; kh < 3; kh++)
 #pragma unroll
-                        for (int kw = 0; kw < 3; kw++) acc += w0[kh * 3 + kw] * p[2 * kh2 + kh][2 * kw2 + kw];
+                        for (int kw = 0; kw < 3; kw++) {
+                            // bf16 engine (OUT_BF16): fused multiply-adds -- this kernel runs at the f32 VALU's issue rate (134 M outputs x ~130 separate multiplies and
+                            // adds at 512 streams x R = 13: 500 us), the result is rounded to bf16 below and compared to the oracle with a tolerance.  The f32
+                            // engine keeps the reference's separate roundings (bit-identical subsampling, tests/test_gpu_parity.py).
+                            if (OUT_BF16) acc = __builtin_fmaf(w0[kh * 3 + kw], p[2 * kh2 + kh][2 * kw2 + kw], acc);
+                            else acc += w0[kh * 3 + kw] * p[2 * kh2 + kh][2 * kw2 + kw];
+                        }
                     a0 = fmaxf(acc + bias0, 0.0f);
                 }
                 if (kw2 == 2) carry[kh2] = a0;
-                acc2 += w2[kh2 * 3 + kw2] * a0;
+                if (OUT_BF16) acc2 = __builtin_fmaf(w2[kh2 * 3 + kw2], a0, acc2);
+                else acc2 += w2[kh2 * 3 + kw2] * a0;
             }
         }
         acc2 += bias2;

@@ -508,9 +508,15 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
 // k_gemm_tiled3 (round 5): k_gemm_tiled2_k32's tile, MFMAs and order with k_gemm_wide2's loop (below): the fragments of chunk i + 1 are read into a second
 // register set under chunk i's MFMAs, the two DMA instructions of chunk i + 5 go out between the MFMA pairs, five slots of 16 KiB (80 KiB: still two
 // workgroups per CU).  Needs an even number of chunks >= 6 per K slice; no chained head phase.
+#ifdef NASR_GEMM_STAMPS
+#define GSTAMP(k) do { if (p.stamps && threadIdx.x == 0) { if ((k) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 3) p.stamps[(size_t)blockIdx.x * 8 + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define GSTAMP(k)
+#endif
 constexpr int T3_NS = 5;
 __global__ __launch_bounds__(512) void k_gemm_tiled3(GemmParams p, int n_groups, int m_chunks) {
     constexpr int NS = T3_NS;
+    GSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int nblk = gridDim.x;
     int id = blockIdx.x;
@@ -551,6 +557,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled3(GemmParams p, int n_groups,
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
+    GSTAMP(1);
     fw[0][0] = *(const uint4 *)(ring + w_off); fw[0][1] = *(const uint4 *)(ring + w_off + 1024);
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) fa[0][mt] = *(const uint4 *)(ring + a_off[mt]);
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(512) void k_gemm_tiled3(GemmParams p, int n_groups,
         body(i, std::integral_constant<int, 0>{});
         body(i + 1, std::integral_constant<int, 1>{});
     }
+    GSTAMP(2);
     __syncthreads();                           // every wave is done with the ring
     float *stage = (float *)ring;
 #pragma unroll
@@ -600,6 +608,115 @@ __global__ __launch_bounds__(512) void k_gemm_tiled3(GemmParams p, int n_groups,
         for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (ng4 * 2 + j) * 16 + q * 4, acc[j][mt]);
     __syncthreads();
     staged_epilogue<512>(p, split, m0, ng * 128, stage);
+    GSTAMP(3);
+}
+
+// k_gemm_tiled4 (round 5): the 128 x 128 tile on FOUR waves of 64 x 64 (16 accumulators, 8 fragment reads for 16 MFMAs per chunk and wave instead of 6 for 8), k_gemm_tiled3's
+// loop.  In-kernel stamps of k_gemm_tiled3 at 896 rows, alone on the chip: 634 cycles per 32-deep chunk for 256 of MFMA per SIMD -- an iteration of eight MFMAs per
+// wave is shorter than the LDS latency + barrier it ends with.  Half the waves, twice the MFMAs each per barrier, and two workgroups still share a CU (80 KiB each).
+__global__ __launch_bounds__(256) void k_gemm_tiled4(GemmParams p, int n_groups, int m_chunks) {
+    constexpr int NS = T3_NS;
+    GSTAMP(0);
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int nblk = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    int mc, ng, split;
+    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nh = wave & 1, mh = wave >> 1, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5, kc_total = KT >> 1;
+    const int t0 = 2 * (int)((long)kc_total * split / p.splits), t1 = 2 * (int)((long)kc_total * (split + 1) / p.splits);
+    const int nchunks = t1 - t0, m0 = mc * TM;
+    // this wave's four DMA instructions per chunk: panel rows [32 wave, +16) and [32 wave + 16, +16), weight tiles 2 wave and 2 wave + 1 of the group's eight
+    const char *src[4];
+    unsigned dst[4];
+    int step[4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int row = (2 * wave + u) * 16 + (lane >> 2);
+        int m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        src[u] = a_row_ptr(p, m, 2) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4) + (size_t)t0 * 64;
+        dst[u] = (unsigned)((2 * wave + u) * 1024);
+        step[u] = 64;
+        src[2 + u] = (const char *)((const uint4 *)p.W + (size_t)(ng * 8 + 2 * wave + u) * KT * 64 + lane) + (size_t)t0 * 1024;
+        dst[2 + u] = (unsigned)(8192 + (2 * wave + u) * 1024);
+        step[2 + u] = 1024;
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 fw[2][4], fa[2][4];
+    const unsigned w_off = 8192 + nh * 4096 + lane * 16;
+    unsigned a_off[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) a_off[mt] = panel32_off((mh * 4 + mt) * 16 + r, q);
+#pragma unroll
+    for (int c = 0; c < NS; c++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) glds16(src[u] + (size_t)c * step[u], ring_base + c * K32_SLOT + dst[u]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    GSTAMP(1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) fw[0][j] = *(const uint4 *)(ring + w_off + j * 1024);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) fa[0][mt] = *(const uint4 *)(ring + a_off[mt]);
+    int slot = 0;
+    auto body = [&](int i, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value, nxt = 1 - cur;
+        const bool has_next = i + 1 < nchunks;
+        const int nslot = slot + 1 == NS ? 0 : slot + 1;
+        if (has_next) {
+            const int left = nchunks - 2 - i;
+            if (left >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");
+            else if (left == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // chunk i + 1 has landed; every wave holds chunk i in registers: its slot is free
+        }
+        const char *sp = ring + nslot * K32_SLOT;
+        const bool more = i + NS < nchunks;
+        const unsigned sb = ring_base + slot * K32_SLOT;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[cur][j]), __builtin_bit_cast(bf16x8, fa[cur][mt]), acc[j][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) {
+                if (mt == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fw[nxt][j] = *(const uint4 *)(sp + w_off + j * 1024);
+                }
+                if (mt == 1) { fa[nxt][0] = *(const uint4 *)(sp + a_off[0]); fa[nxt][1] = *(const uint4 *)(sp + a_off[1]); }
+                if (mt == 2) { fa[nxt][2] = *(const uint4 *)(sp + a_off[2]); fa[nxt][3] = *(const uint4 *)(sp + a_off[3]); }
+            }
+            if (more) glds16(src[mt] + (size_t)(i + NS) * step[mt], sb + dst[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
+    };
+    for (int i = 0; i < nchunks; i += 2) {
+        body(i, std::integral_constant<int, 0>{});
+        body(i + 1, std::integral_constant<int, 1>{});
+    }
+    GSTAMP(2);
+    __syncthreads();                           // every wave is done with the ring
+    float *stage = (float *)ring;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (nh * 4 + j) * 16 + q * 4, acc[j][mt]);
+    __syncthreads();
+    staged_epilogue<256>(p, split, m0, ng * 128, stage);
+    GSTAMP(3);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1313,17 +1430,17 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
     }
 }
 
-// Row-wise output of one wave's block parked in its own LDS region (stg[row][col], WE_LD floats per row): COLS = 64 columns, `rows` rows starting at
+// Row-wise output of one wave's block parked in its own LDS region (stg[row][col], WE_LD floats per row): COLS = 64 or 48 columns, `rows` rows starting at
 // (m_base, n_base) of the GEMM.  16-bit outputs: eight columns per lane, eight rows per wave instruction (128-byte segments); f32 outputs: four columns
 // per lane, four rows per instruction (256-byte segments); the residual form requests eight instructions' worth of residual values ahead.
 constexpr int WE_LD = 68;
 template <int COLS>
 __device__ __forceinline__ void wave_epilogue_rows(const GemmParams &p, const float *stg, int rows, int m_base, int n_base, int lane) {
-    static_assert(COLS == 64, "lane maps below");
+    static_assert(COLS == 64 || COLS == 48, "a wave's block is 64 or 48 columns wide");
     if (!p.narrow_stores && (p.epi == EPI_SILU_ACT || p.epi == EPI_GLU || p.epi == EPI_QKV)) {
-        const int lr = lane >> 3, c8 = (lane & 7) * 8;
-        for (int r0 = 0; r0 < rows; r0 += 8) {
-            const int row = r0 + lr, m = m_base + row, n0 = n_base + c8;
+        constexpr int PER = COLS / 8;          // items of eight columns per row
+        for (int e = lane; e < rows * PER; e += 64) {
+            const int row = e / PER, c8 = (e - row * PER) * 8, m = m_base + row, n0 = n_base + c8;
             const float4 a = *(const float4 *)(stg + row * WE_LD + c8), b = *(const float4 *)(stg + row * WE_LD + c8 + 4);
             if (m >= p.M) continue;
             const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -1331,29 +1448,29 @@ __device__ __forceinline__ void wave_epilogue_rows(const GemmParams &p, const fl
         }
         return;
     }
-    const int lr = lane >> 4, c4 = (lane & 15) * 4, n0 = n_base + c4;
+    constexpr int PER = COLS / 4;              // items of four columns per row
     if (p.epi == EPI_RESID_F32) {
-        for (int r0 = 0; r0 < rows; r0 += 32) {          // rows is a multiple of 16: the second half of the last batch may be empty
+        for (int e0 = lane; e0 < rows * PER; e0 += 8 * 64) {
             float4 xq[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int row = r0 + k * 4 + lr, m = m_base + row;
+                const int e = e0 + k * 64, row = e / PER, m = m_base + row;
                 xq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < rows && m < p.M) xq[k] = *(const float4 *)(p.resid + (size_t)m * p.ldo + n0);
+                if (e < rows * PER && m < p.M) xq[k] = *(const float4 *)(p.resid + (size_t)m * p.ldo + n_base + (e - row * PER) * 4);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int row = r0 + k * 4 + lr, m = m_base + row;
-                if (row >= rows || m >= p.M) continue;
+                const int e = e0 + k * 64, row = e / PER, c4 = (e - row * PER) * 4, m = m_base + row;
+                if (e >= rows * PER || m >= p.M) continue;
                 const float4 v = *(const float4 *)(stg + row * WE_LD + c4);
-                store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, make_float4(__builtin_fmaf(p.resid_scale, v.x, xq[k].x), __builtin_fmaf(p.resid_scale, v.y, xq[k].y),
-                                                                           __builtin_fmaf(p.resid_scale, v.z, xq[k].z), __builtin_fmaf(p.resid_scale, v.w, xq[k].w)));
+                store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n_base + c4, make_float4(__builtin_fmaf(p.resid_scale, v.x, xq[k].x), __builtin_fmaf(p.resid_scale, v.y, xq[k].y),
+                                                                                  __builtin_fmaf(p.resid_scale, v.z, xq[k].z), __builtin_fmaf(p.resid_scale, v.w, xq[k].w)));
             }
         }
         return;
     }
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        const int row = r0 + lr, m = m_base + row;
+    for (int e = lane; e < rows * PER; e += 64) {
+        const int row = e / PER, c4 = (e - row * PER) * 4, m = m_base + row, n0 = n_base + c4;
         const float4 v = *(const float4 *)(stg + row * WE_LD + c4);
         if (m >= p.M) continue;
         if (p.epi == EPI_PART_F32) store_wt_f4(p.out_f32 + (size_t)m * p.ldo + n0, v);
@@ -1371,11 +1488,9 @@ __device__ __forceinline__ void wave_epilogue_rows(const GemmParams &p, const fl
 // MFMA groups.  Five ring slots (150 KiB) keep the DMA look-ahead at four iterations.  Needs K / 32 even and >= 8.
 // ------------------------------------------------------------------------------------
 constexpr int W2_NS = 5;
-#ifdef NASR_GEMM_STAMPS
-#define GSTAMP(k) do { if (p.stamps && threadIdx.x == 0) { if ((k) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 3) p.stamps[(size_t)blockIdx.x * 8 + 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define GSTAMP(k)
-#endif
+template <int BN, int MT> constexpr int wide2_lds() {          // the ring, or the eight wave-private epilogue regions (64 rows x WE_LD floats each), whichever is larger
+    return W2_NS * WideCfg<BN, MT>::SLOT > 8 * 64 * 68 * 4 ? W2_NS * WideCfg<BN, MT>::SLOT : 8 * 64 * 68 * 4;
+}
 template <int BN, int MT>
 __global__ __launch_bounds__(512) void k_gemm_wide2(GemmParams p, int n_groups, int m_chunks) {
     using C = WideCfg<BN, MT>;
@@ -1525,6 +1640,7 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_t64w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T64W_HALF);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NS * K32_SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_tiled4, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NS * K32_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
@@ -1536,7 +1652,8 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_BIAS_RELU_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 8>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
-    hipFuncSetAttribute((const void *)k_gemm_wide2<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, W2_NS * WideCfg<256, 7>::SLOT);
+    hipFuncSetAttribute((const void *)k_gemm_wide2<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, wide2_lds<256, 7>());
+    hipFuncSetAttribute((const void *)k_gemm_wide2<192, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, wide2_lds<192, 7>());
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
@@ -1611,6 +1728,9 @@ static bool gemm_coresident(const GemmParams &p) {
     return p.M >= 1792 && tiles > g_num_cus;
 }
 
+// round 5's loops (k_gemm_wide2, k_gemm_tiled3) unless GemmParams::prio >> 2 asks for an older form: 5 = rounds 1-4's loops (engine option "gemm_prio" = 20: A/B
+// runs, gemm_variant_identity.py), 1-3 = the probes on the older kernels
+static bool gemm_new_loops(const GemmParams &p) { return (p.prio >> 2) == 0 || (p.prio >> 2) == 4; }
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
     if (p.splits < 1) p.splits = 1;
@@ -1643,6 +1763,18 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         // least 5 / 8 full, or three rounds and more (persist_probe, cold operands, us per launch against the per-tile pair: 7 168 rows W1 448
         // tiles 78 / 83, pw1 224 tiles 38 / 45, QKV 336 tiles 69 / 70: a wash, left alone; 15 360 rows N = 1024 240 tiles 109 / 160).  The
         // 256 x 128 form measured worse than the per-tile kernels with cold operands (W2 at 7 168 rows 92 / 77) and is not used.
+        // Synchronous steps only -- alone on the chip the QKV launch at 7 168 rows takes 52 us instead of 62, but a pipelined 512-stream step got SLOWER with it
+        // (13.65 against 13.50 ms, same box, three-way A/B): the half-empty round is where the other lanes' launches run.
+        // N = 3072 (QKV) on 224 x 192 tiles where 224 x 256 leaves a half-empty last round: 7 168 rows 384 tiles = 1.5 rounds -> 512 = two full rounds of
+        // 3 / 4-size tiles, 3 584 rows 192 tiles (0.75 of the chip) -> 256.  k_gemm_wide2 only (its wave-private epilogue takes 48-column blocks).
+        if (!p.no_wide && gemm_new_loops(p) && p.coresident != 1 && p.splits == 1 && p.M >= 1792 && (p.K & 63) == 0 && p.K >= 256 && p.N % 192 == 0 && p.N % 256 == 0) {
+            const long mw = (p.M + 223) / 224, t192 = (long)(p.N / 192) * mw, t256 = (long)(p.N / 256) * mw;
+            const long c192 = (t192 + g_num_cus - 1) / g_num_cus * 192, c256 = (t256 + g_num_cus - 1) / g_num_cus * 256;
+            if (c192 < c256 && t192 >= (long)g_num_cus * 7 / 8) {
+                hipLaunchKernelGGL((k_gemm_wide2<192, 7>), dim3((unsigned)t192), dim3(512), (wide2_lds<192, 7>()), st, p, p.N / 192, (int)mw);
+                return;
+            }
+        }
         if (!p.no_wide && p.splits == 1 && p.M >= (p.coresident == 1 ? 1344 : 1792) && (p.K & 31) == 0 && p.N % 256 == 0) {
             // 256- or 224-row tiles: whichever needs fewer rounds x rows (7 168 rows: N = 4096 two full rounds of 224-row tiles instead of
             // 1.75 of 256-row ones, N = 2048 one round of 256 smaller tiles; 15 360 rows stay at 256).  Cold operands, us per launch, 256 / 224 rows:
@@ -1673,7 +1805,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 return;
             }
             if (best_mt == 7) {
-                if ((p.prio >> 2) == 4 && (p.K & 63) == 0 && p.K >= 256) hipLaunchKernelGGL((k_gemm_wide2<256, 7>), dim3((unsigned)best_tiles), dim3(512), (W2_NS * WideCfg<256, 7>::SLOT), st, p, p.N / 256, (p.M + 223) / 224);
+                if (gemm_new_loops(p) && (p.K & 63) == 0 && p.K >= 256) hipLaunchKernelGGL((k_gemm_wide2<256, 7>), dim3((unsigned)best_tiles), dim3(512), (wide2_lds<256, 7>()), st, p, p.N / 256, (p.M + 223) / 224);
                 else if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_wide<256, 7, 1>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_wide<256, 7, 2>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 else if ((p.prio >> 2) == 3) hipLaunchKernelGGL((k_gemm_wide<256, 7, 3>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
@@ -1696,8 +1828,9 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             }
         }
         dim3 grid(n_groups * m_chunks * p.splits);
-        if (gemm_coresident(p) && (p.prio >> 2) == 4 && ((p.K >> 6) / p.splits) * 2 >= 6 && (p.K >> 6) % p.splits == 0) {
-            hipLaunchKernelGGL(k_gemm_tiled3, grid, dim3(512), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);
+        if (gemm_coresident(p) && gemm_new_loops(p) && ((p.K >> 6) / p.splits) * 2 >= 6 && (p.K >> 6) % p.splits == 0) {
+            if ((p.prio >> 2) == 4) hipLaunchKernelGGL(k_gemm_tiled3, grid, dim3(512), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);          // "gemm_prio" = 16: the eight-wave form
+            else hipLaunchKernelGGL(k_gemm_tiled4, grid, dim3(256), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);
             return;
         }
         if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU

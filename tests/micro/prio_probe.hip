@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
                     memset(&g, 0, sizeof(g));
                     g.A = A; g.W = W; g.M = M; g.N = s.N; g.K = s.K; g.lda = s.K; g.splits = 1; g.epi = s.epi;
                     g.out_f32 = outf; g.ldo = s.epi == EPI_GLU ? s.N / 2 : s.N; g.out_act = act; g.ldo_act = s.N; g.bias = bias;
-                    g.no_persist = 1; g.coresident = 1; g.prio = pv << 2;          // the engine's pipelined configuration
+                    g.no_persist = 1; g.coresident = 1; g.prio = (pv == 0 ? 5 : pv) << 2;          // the engine's pipelined configuration
                     for (int i = 0; i < 3; i++) launch_gemm_bf16(g, st);
                     hipEvent_t a, b;
                     CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));

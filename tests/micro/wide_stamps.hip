@@ -42,7 +42,8 @@ int main(int argc, char **argv) {
         CHK(hipStreamSynchronize(st));
         std::vector<unsigned long long> hs(1024 * 8);
         CHK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
-        const int tiles = (s.N / 256) * ((M + 223) / 224), KT = s.K / 32;
+        const bool small = M < 1344;          // below k_gemm_wide2's range: the 128 x 128 tiles of k_gemm_tiled3
+        const int tiles = small ? (s.N / 128) * ((M + 127) / 128) : (s.N == 3072 ? (s.N / 192) : (s.N / 256)) * ((M + 223) / 224), KT = s.K / 32;
         std::vector<double> pro, loop, epi, clk, start, end;
         unsigned long long r0 = ~0ull;
         for (int b = 0; b < tiles; b++) if (hs[b * 8 + 4]) r0 = std::min(r0, hs[b * 8 + 4]);
@@ -53,9 +54,10 @@ int main(int argc, char **argv) {
             clk.push_back((double)(t[3] - t[0]) / (double)(t[7] - t[4]) * 0.1);          // GHz: shader cycles per 10 ns tick
             start.push_back((t[4] - r0) * 0.01); end.push_back((t[7] - r0) * 0.01);      // us
         }
+        if (pro.empty()) { printf("M = %d %s: no stamps (another kernel took this shape)\n", M, s.name); continue; }
         int late = 0;
         for (double v : start) late += v > 2.0;
-        printf("M = %d %-30s %d tiles: in-kernel clock %.2f GHz | prologue %6.0f cyc (p90 %6.0f) | K loop %6.0f cyc per chunk (p10 %6.0f p90 %6.0f; MFMA alone: 896) | epilogue %6.0f cyc (p90 %6.0f) | "
+        printf("M = %d %-30s %d tiles: in-kernel clock %.2f GHz | prologue %6.0f cyc (p90 %6.0f) | K loop %6.0f cyc per chunk (p10 %6.0f p90 %6.0f; MFMA alone: 896 / 256 on 224 x 256 / 128 x 128 tiles) | epilogue %6.0f cyc (p90 %6.0f) | "
                "workgroups starting > 2 us after the first: %d; last end %.1f us, median end %.1f us\n",
                M, s.name, tiles, med(clk), med(pro), pct(pro, 0.9), med(loop), pct(loop, 0.1), pct(loop, 0.9), med(epi), pct(epi, 0.9), late, *std::max_element(end.begin(), end.end()), med(end));
     }
