@@ -611,113 +611,9 @@ __global__ __launch_bounds__(512) void k_gemm_tiled3(GemmParams p, int n_groups,
     GSTAMP(3);
 }
 
-// k_gemm_tiled4 (round 5): the 128 x 128 tile on FOUR waves of 64 x 64 (16 accumulators, 8 fragment reads for 16 MFMAs per chunk and wave instead of 6 for 8), k_gemm_tiled3's
-// loop.  In-kernel stamps of k_gemm_tiled3 at 896 rows, alone on the chip: 634 cycles per 32-deep chunk for 256 of MFMA per SIMD -- an iteration of eight MFMAs per
-// wave is shorter than the LDS latency + barrier it ends with.  Half the waves, twice the MFMAs each per barrier, and two workgroups still share a CU (80 KiB each).
-__global__ __launch_bounds__(256) void k_gemm_tiled4(GemmParams p, int n_groups, int m_chunks) {
-    constexpr int NS = T3_NS;
-    GSTAMP(0);
-    extern __shared__ __attribute__((aligned(16))) char ring[];
-    const int nblk = gridDim.x;
-    int id = blockIdx.x;
-    {
-        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
-        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
-    }
-    int mc, ng, split;
-    tile_of(id, n_groups, m_chunks, p.tile_bands, mc, ng, split);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nh = wave & 1, mh = wave >> 1, q = lane >> 4, r = lane & 15;
-    const int KT = p.K >> 5, kc_total = KT >> 1;
-    const int t0 = 2 * (int)((long)kc_total * split / p.splits), t1 = 2 * (int)((long)kc_total * (split + 1) / p.splits);
-    const int nchunks = t1 - t0, m0 = mc * TM;
-    // this wave's four DMA instructions per chunk: panel rows [32 wave, +16) and [32 wave + 16, +16), weight tiles 2 wave and 2 wave + 1 of the group's eight
-    const char *src[4];
-    unsigned dst[4];
-    int step[4];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int row = (2 * wave + u) * 16 + (lane >> 2);
-        int m = m0 + row;
-        if (m >= p.M) m = p.M - 1;
-        src[u] = a_row_ptr(p, m, 2) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4) + (size_t)t0 * 64;
-        dst[u] = (unsigned)((2 * wave + u) * 1024);
-        step[u] = 64;
-        src[2 + u] = (const char *)((const uint4 *)p.W + (size_t)(ng * 8 + 2 * wave + u) * KT * 64 + lane) + (size_t)t0 * 1024;
-        dst[2 + u] = (unsigned)(8192 + (2 * wave + u) * 1024);
-        step[2 + u] = 1024;
-    }
-    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) acc[j][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint4 fw[2][4], fa[2][4];
-    const unsigned w_off = 8192 + nh * 4096 + lane * 16;
-    unsigned a_off[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) a_off[mt] = panel32_off((mh * 4 + mt) * 16 + r, q);
-#pragma unroll
-    for (int c = 0; c < NS; c++)
-#pragma unroll
-        for (int u = 0; u < 4; u++) glds16(src[u] + (size_t)c * step[u], ring_base + c * K32_SLOT + dst[u]);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    GSTAMP(1);
-#pragma unroll
-    for (int j = 0; j < 4; j++) fw[0][j] = *(const uint4 *)(ring + w_off + j * 1024);
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) fa[0][mt] = *(const uint4 *)(ring + a_off[mt]);
-    int slot = 0;
-    auto body = [&](int i, auto cur_c) {
-        constexpr int cur = decltype(cur_c)::value, nxt = 1 - cur;
-        const bool has_next = i + 1 < nchunks;
-        const int nslot = slot + 1 == NS ? 0 : slot + 1;
-        if (has_next) {
-            const int left = nchunks - 2 - i;
-            if (left >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");
-            else if (left == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else if (left == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // chunk i + 1 has landed; every wave holds chunk i in registers: its slot is free
-        }
-        const char *sp = ring + nslot * K32_SLOT;
-        const bool more = i + NS < nchunks;
-        const unsigned sb = ring_base + slot * K32_SLOT;
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[cur][j]), __builtin_bit_cast(bf16x8, fa[cur][mt]), acc[j][mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) {
-                if (mt == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) fw[nxt][j] = *(const uint4 *)(sp + w_off + j * 1024);
-                }
-                if (mt == 1) { fa[nxt][0] = *(const uint4 *)(sp + a_off[0]); fa[nxt][1] = *(const uint4 *)(sp + a_off[1]); }
-                if (mt == 2) { fa[nxt][2] = *(const uint4 *)(sp + a_off[2]); fa[nxt][3] = *(const uint4 *)(sp + a_off[3]); }
-            }
-            if (more) glds16(src[mt] + (size_t)(i + NS) * step[mt], sb + dst[mt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        slot = nslot;
-    };
-    for (int i = 0; i < nchunks; i += 2) {
-        body(i, std::integral_constant<int, 0>{});
-        body(i + 1, std::integral_constant<int, 1>{});
-    }
-    GSTAMP(2);
-    __syncthreads();                           // every wave is done with the ring
-    float *stage = (float *)ring;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) stage_acc(stage, (mh * 4 + mt) * 16 + r, (nh * 4 + j) * 16 + q * 4, acc[j][mt]);
-    __syncthreads();
-    staged_epilogue<256>(p, split, m0, ng * 128, stage);
-    GSTAMP(3);
-}
+// (A four-wave form of this tile -- 64 x 64 per wave, 16 MFMAs and four DMA instructions per wave and chunk -- measured 1 092 cycles per chunk against 634 here
+// (in-kernel stamps, 896 rows) and 2.58 against 2.41 ms per pipelined 64-stream step: a wave's LDS-DMA instructions cost it ~100+ cycles of issue each, and with one wave
+// per SIMD nothing runs under them.  Removed; profiles/r5_gemm_tile_stamps.md.)
 
 // ------------------------------------------------------------------------------------
 // 128 (M) x 64 (N) tile of the same structure, for the split-K GEMMs with N = 1024 (W2, Wo, pw2) at M = 896: the 128 x 128
@@ -1640,7 +1536,6 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_t64w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T64W_HALF);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NS * K32_SLOT);
-    hipFuncSetAttribute((const void *)k_gemm_tiled4, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NS * K32_SLOT);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
@@ -1829,8 +1724,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
         }
         dim3 grid(n_groups * m_chunks * p.splits);
         if (gemm_coresident(p) && gemm_new_loops(p) && ((p.K >> 6) / p.splits) * 2 >= 6 && (p.K >> 6) % p.splits == 0) {
-            if ((p.prio >> 2) == 4) hipLaunchKernelGGL(k_gemm_tiled3, grid, dim3(512), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);          // "gemm_prio" = 16: the eight-wave form
-            else hipLaunchKernelGGL(k_gemm_tiled4, grid, dim3(256), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);
+            hipLaunchKernelGGL(k_gemm_tiled3, grid, dim3(512), T3_NS * K32_SLOT, st, p, n_groups, m_chunks);
             return;
         }
         if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU

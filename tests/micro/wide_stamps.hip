@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
         memset(&g, 0, sizeof(g));
         g.A = A; g.W = W; g.M = M; g.N = s.N; g.K = s.K; g.lda = s.K; g.splits = 1; g.epi = s.epi;
         g.out_f32 = outf; g.ldo = s.epi == EPI_GLU ? s.N / 2 : s.N; g.out_act = act; g.ldo_act = s.N; g.bias = bias;
-        g.no_persist = 1; g.coresident = 1; g.prio = 4 << 2; g.stamps = nullptr;
+        g.no_persist = 1; g.coresident = 1; g.prio = 0; g.stamps = nullptr;
         for (int i = 0; i < 200; i++) {          // ~15 ms of back-to-back launches first: the clock the chip holds under this load
             g.W = W + (size_t)(i % (4 * NW)) * ((size_t)1024 * 4096); g.A = A + (size_t)(i % NA) * Mmax * 4096;
             if (i == 199) { CHK(hipMemsetAsync(stamps, 0, 1024 * 64, st)); g.stamps = stamps; }
