@@ -600,10 +600,11 @@ def test_gemm_ring_variants_are_bit_identical():
     import sys
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "gemm_variant_identity.py"), "opt:gemm_cores=1", "opt:gemm_cores=0", "opt:persistent_gemm=1",
-                        "opt:persistent_gemm=1 opt:gemm_cores=0", "opt:wide_tiles=0 opt:tile_bands=0 opt:t64_tiles=127", "opt:wide_tiles=256 opt:tile_bands=1", "opt:resid_epilogue=0", "opt:resid_epilogue=2 opt:dwconv_stream=0", "opt:chain=2"],
+                        "opt:persistent_gemm=1 opt:gemm_cores=0", "opt:wide_tiles=0 opt:tile_bands=0 opt:t64_tiles=127", "opt:wide_tiles=256 opt:tile_bands=1", "opt:resid_epilogue=0", "opt:resid_epilogue=2 opt:dwconv_stream=0", "opt:chain=2",
+                        "opt:gemm_prio=20", "opt:gemm_prio=16 opt:epilogue16=0"],          # rounds 1-4's GEMM loops (k_gemm_wide, k_gemm_tiled2_k32); round 5's with 8-byte epilogue stores
                        capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert r.stdout.count("==") == 10 and "!=" not in r.stdout
+    assert r.stdout.count("==") == 12 and "!=" not in r.stdout
 
 
 def test_lanes_option_gives_queues_back_and_keeps_results(W2):
