@@ -378,7 +378,7 @@ __device__ __forceinline__ void chain_wait(const ChainParams &c, int mc, int chu
 
 constexpr int K32_SLOT = 16384;
 __device__ __forceinline__ int panel32_off(int row, int col) { return row * 64 + ((col ^ ((0 - (row >> 2)) & 3)) << 4); }
-template <int NS, int PV = 0>
+template <int NS>
 __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_groups, int m_chunks) {
     constexpr int P = NS - 1;
     extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -447,42 +447,6 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
         const char *sp = ring + slot * K32_SLOT;
         const char *wl = sp + 8192 + ng4 * 2048 + lane * 16;
         const uint4 w0 = *(const uint4 *)(wl), w1 = *(const uint4 *)(wl + 1024);
-        if constexpr (PV == 3) {          // probe: every fragment first, the two DMA instructions between the MFMA pairs
-            uint4 bvs[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
-            const bool more = i + P < nchunks;
-            const unsigned sb = ring_base + (slot == 0 ? NS - 1 : slot - 1) * K32_SLOT;
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, bvs[mt]), acc[0][mt], 0, 0, 0);
-                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, bvs[mt]), acc[1][mt], 0, 0, 0);
-                if (mt < 2) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) { if (mt == 0) glds16(asrc + (size_t)(t0 + i + P) * 64, sb + wave * 1024); else glds16(wpd + (size_t)(t0 + i + P) * 64, sb + 8192 + wave * 1024); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            slot = slot + 1 == NS ? 0 : slot + 1;
-            continue;
-        }
-        if constexpr (PV == 2) {          // probe: the DMA first, every fragment, then the eight MFMAs as one prioritised cluster
-            if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);
-            uint4 bvs[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, bvs[mt]), acc[0][mt], 0, 0, 0);
-                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, bvs[mt]), acc[1][mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            slot = slot + 1 == NS ? 0 : slot + 1;
-            continue;
-        }
-        if constexpr (PV == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) {
             const uint4 bv = *(const uint4 *)(sp + panel32_off((mh * 4 + mt) * 16 + r, q));
@@ -490,7 +454,6 @@ __global__ __launch_bounds__(512) void k_gemm_tiled2_k32(GemmParams p, int n_gro
             acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), bf, acc[0][mt], 0, 0, 0);
             acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), bf, acc[1][mt], 0, 0, 0);
         }
-        if constexpr (PV == 1) __builtin_amdgcn_s_setprio(0);
         if (i + P < nchunks) issue(t0 + i + P, slot == 0 ? NS - 1 : slot - 1);     // the slot chunk i - 1 has just left
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
@@ -1166,7 +1129,7 @@ template <int BN, int MT> struct WideCfg {
     static constexpr int STG_LD = BN + 4;                     // floats per staged row
     static constexpr size_t LDS = (size_t)WD_NS * SLOT > (size_t)64 * (BN + 4) * 4 ? (size_t)WD_NS * SLOT : (size_t)64 * (BN + 4) * 4;
 };
-template <int BN, int MT, int PV = 0>
+template <int BN, int MT>
 __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, int m_chunks) {
     using C = WideCfg<BN, MT>;
     constexpr int P = WD_NS - 1, NT = C::NT, DMA = C::DMA, BM = C::BM;
@@ -1225,48 +1188,17 @@ __global__ __launch_bounds__(512) void k_gemm_wide(GemmParams p, int n_groups, i
         else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
-        if (PV != 3 && i + P < KT) issue(i + P, slot == 0 ? WD_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
+        if (i + P < KT) issue(i + P, slot == 0 ? WD_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
         const char *sp = ring + slot * C::SLOT;
         uint4 wf[NT];
 #pragma unroll
         for (int j = 0; j < NT; j++) wf[j] = *(const uint4 *)(sp + BM * 64 + (nq * NT + j) * 1024 + lane * 16);
-        if constexpr (PV == 3) {          // probe: every fragment first, then the chunk's DMA instructions one by one BETWEEN the MFMA groups (their issue cost under the matrix pipe)
-            uint4 bvs[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
-            const bool more = i + P < KT;
-            const unsigned sb = ring_base + (slot == 0 ? WD_NS - 1 : slot - 1) * C::SLOT;
+        for (int mt = 0; mt < MT; mt++) {
+            const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, bvs[mt]), acc[j][mt], 0, 0, 0);
-                if (mt < DMA) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) glds16(src[mt] + (size_t)(i + P) * step[mt], sb + dst[mt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else if constexpr (PV == 2) {          // probe: every fragment first, then the MFMAs as one prioritised cluster (the guide's phase form)
-            uint4 bvs[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) bvs[mt] = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, bvs[mt]), acc[j][mt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        } else {
-            if constexpr (PV == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const uint4 bv = *(const uint4 *)(sp + panel32_off(mh * (BM / 2) + mt * 16 + r, q));
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, bv);
-#pragma unroll
-                for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
-            }
-            if constexpr (PV == 1) __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
         }
         slot = slot + 1 == WD_NS ? 0 : slot + 1;
     }
@@ -1536,9 +1468,6 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_t64w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T64W_HALF);
     hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_tiled3, hipFuncAttributeMaxDynamicSharedMemorySize, T3_NS * K32_SLOT);
-    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
-    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
-    hipFuncSetAttribute((const void *)k_gemm_tiled2_k32<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_k32_lds_bytes(4));
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_PART_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_SILU_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     hipFuncSetAttribute((const void *)k_gemm_persist<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
@@ -1549,9 +1478,6 @@ void init_gemm_kernel_attributes() {
     hipFuncSetAttribute((const void *)k_gemm_wide<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     hipFuncSetAttribute((const void *)k_gemm_wide2<256, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, wide2_lds<256, 7>());
     hipFuncSetAttribute((const void *)k_gemm_wide2<192, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, wide2_lds<192, 7>());
-    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
-    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
-    hipFuncSetAttribute((const void *)k_gemm_wide<256, 7, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<256, 7>::LDS);
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_num_cus = cus;
     hipFuncSetAttribute((const void *)k_gemm_f32_mfma<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, F32M_NS * 256 * 128);
@@ -1623,8 +1549,9 @@ static bool gemm_coresident(const GemmParams &p) {
     return p.M >= 1792 && tiles > g_num_cus;
 }
 
-// round 5's loops (k_gemm_wide2, k_gemm_tiled3) unless GemmParams::prio >> 2 asks for an older form: 5 = rounds 1-4's loops (engine option "gemm_prio" = 20: A/B
-// runs, gemm_variant_identity.py), 1-3 = the probes on the older kernels
+// round 5's loops (k_gemm_wide2, k_gemm_tiled3) unless GemmParams::prio >> 2 == 5: rounds 1-4's (engine option "gemm_prio" = 20: A/B runs, gemm_variant_identity.py).
+// The probes this field also selected during the round (s_setprio around the MFMA cluster, "every fragment first", DMA between the MFMA groups on the old kernels) are
+// gone from the tree: profiles/r5_gemm_tile_stamps.md, r5_gemm_loops_probe_{7168,896}.txt.
 static bool gemm_new_loops(const GemmParams &p) { return (p.prio >> 2) == 0 || (p.prio >> 2) == 4; }
 void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
     GemmParams p = p0;
@@ -1701,9 +1628,6 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             }
             if (best_mt == 7) {
                 if (gemm_new_loops(p) && (p.K & 63) == 0 && p.K >= 256) hipLaunchKernelGGL((k_gemm_wide2<256, 7>), dim3((unsigned)best_tiles), dim3(512), (wide2_lds<256, 7>()), st, p, p.N / 256, (p.M + 223) / 224);
-                else if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_wide<256, 7, 1>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
-                else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_wide<256, 7, 2>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
-                else if ((p.prio >> 2) == 3) hipLaunchKernelGGL((k_gemm_wide<256, 7, 3>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 else hipLaunchKernelGGL((k_gemm_wide<256, 7>), dim3((unsigned)best_tiles), dim3(512), (WideCfg<256, 7>::LDS), st, p, p.N / 256, (p.M + 223) / 224);
                 return;
             }
@@ -1728,10 +1652,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             return;
         }
         if (gemm_coresident(p)) {                  // 4 x 16 KiB ring (+ the staged tile: 66 KiB): two workgroups per CU
-            if ((p.prio >> 2) == 1) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 1>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
-            else if ((p.prio >> 2) == 2) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 2>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
-            else if ((p.prio >> 2) == 3) hipLaunchKernelGGL((k_gemm_tiled2_k32<4, 3>), grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
-            else hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
+            hipLaunchKernelGGL(k_gemm_tiled2_k32<4>, grid, dim3(512), gemm_k32_lds_bytes(4), st, p, n_groups, m_chunks);
             return;
         }
         constexpr int roles_min_chunks = 8;

@@ -1,6 +1,6 @@
-// Round 5: wave priority around the MFMA cluster of the large-M GEMM loops (cdna_hip_programming.md: s_setprio(1) ... s_setprio(0) around the MFMAs of a phase), cold operands.
-// GemmParams::prio >> 2: 4 = k_gemm_wide2 (fragments of the next chunk read under this chunk's MFMAs, DMA between the MFMA groups, five slots), 3 = DMA between the MFMA groups only, 0 = shipped loop, 1 = setprio pair around the interleaved read + MFMA block, 2 = every fragment first, lgkmcnt(0), then the MFMAs as one prioritised cluster.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../nemotron-asr.cpp_amd/csrc -c prio_probe.hip -o /tmp/prp.o && hipcc --offload-arch=gfx950 -o prio_probe /tmp/prp.o ../../nemotron-asr.cpp_amd/csrc/kernels_gemm.o
+// Round 5: the large-M GEMM loops alone on the chip with COLD operands, per launch: rounds 1-4's (k_gemm_wide, k_gemm_tiled2_k32: GemmParams::prio = 20) against round 5's
+// (k_gemm_wide2, k_gemm_tiled3).  Earlier in the round this probe also timed s_setprio around the MFMA cluster and two re-orderings of the old loops: profiles/r5_gemm_loops_probe_*.txt.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../nemotron-asr.cpp_amd/csrc -c gemm_loops_probe.hip -o /tmp/prp.o && hipcc --offload-arch=gfx950 -o gemm_loops_probe /tmp/prp.o ../../nemotron-asr.cpp_amd/csrc/kernels_gemm.o
 #include "nasr_internal.h"
 #include <cstdio>
 #include <cstring>
@@ -27,14 +27,14 @@ int main(int argc, char **argv) {
         {"Wo  N=1024 K=1024 f32", 1024, 1024, EPI_PART_F32}, {"pw1 N=2048 K=1024 GLU", 2048, 1024, EPI_GLU}, {"QKV-shaped N=3072 K=1024 f32", 3072, 1024, EPI_PART_F32}};
     for (int M : Ms)
         for (const Shape &s : shapes) {
-            double us[5][2];
+            double us[2][2];
             for (int rep = 0; rep < 2; rep++)
-                for (int pv = 0; pv < 5; pv++) {
+                for (int pv = 0; pv < 2; pv++) {
                     GemmParams g;
                     memset(&g, 0, sizeof(g));
                     g.A = A; g.W = W; g.M = M; g.N = s.N; g.K = s.K; g.lda = s.K; g.splits = 1; g.epi = s.epi;
                     g.out_f32 = outf; g.ldo = s.epi == EPI_GLU ? s.N / 2 : s.N; g.out_act = act; g.ldo_act = s.N; g.bias = bias;
-                    g.no_persist = 1; g.coresident = 1; g.prio = (pv == 0 ? 5 : pv) << 2;          // the engine's pipelined configuration
+                    g.no_persist = 1; g.coresident = 1; g.prio = (pv == 0 ? 5 : 0) << 2;          // the engine's pipelined configuration
                     for (int i = 0; i < 3; i++) launch_gemm_bf16(g, st);
                     hipEvent_t a, b;
                     CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
@@ -52,8 +52,8 @@ int main(int argc, char **argv) {
                 }
             const double fl = 2.0 * M * s.N * s.K * 1e-6;
             printf("[cold] M = %5d  %-30s", M, s.name);
-            const char *nm[5] = {"shipped", "setprio pair", "cluster", "dma between", "wide2"};
-            for (int pv = 0; pv < 5; pv++) printf(" | %s %7.2f / %7.2f us (%5.0f TF)", nm[pv], us[pv][0], us[pv][1], fl / std::min(us[pv][0], us[pv][1]));
+            const char *nm[2] = {"rounds 1-4 loops", "round 5 loops"};
+            for (int pv = 0; pv < 2; pv++) printf(" | %s %7.2f / %7.2f us (%5.0f TF)", nm[pv], us[pv][0], us[pv][1], fl / std::min(us[pv][0], us[pv][1]));
             printf("\n");
         }
     return 0;
