@@ -219,7 +219,10 @@ enum {
  * four rows on the FMA tile kernel instead of the f32 MFMA), "decode_graph_iterations" (>= 1, default 12: decode iterations a
  * pipelined step's decode graph carries before the eager fallback), "resid_epilogue" (0: every residual GEMM writes split-K partial
  * slabs and k_post adds them, as in rounds 1-4; default 1: the GEMM adds to the residual stream in its epilogue where one workgroup owns a tile's
- * whole K sum -- same bits), "ablate" (MEASUREMENT ONLY -- results
+ * whole K sum -- same bits), "gemm_prio" (default 0: round 5's GEMM loops -- k_gemm_wide2 / k_gemm_tiled3: the next chunk's fragments read under this chunk's
+ * MFMAs, wave-private epilogues; 20: rounds 1-4's loops; same bits), "epilogue16" (default 1: the GEMM epilogues with 16-bit outputs store eight columns = 16 bytes
+ * per thread; 0: four), "wide_min_tiles" (default 96: pipelined steps take the 224 x 256 tiles from this many of them), "split_tasks" (default 200: residual GEMMs take
+ * one K slice from this many 128 x 128 tiles), "ablate" (MEASUREMENT ONLY -- results
  * are invalid: bit mask of launches left out of a step: 1 residual + LayerNorm, 2 attention, 4 depthwise conv, 8 decode iterations, 16 front end, 32 encoder
  * GEMMs; what each costs a pipelined step: profiles/r5_ablation.md), "decode_lane" (0: the decode graphs run behind the last encoder
  * piece instead of on a stream of their own; read when the lanes are picked, so it is REJECTED after the first pipelined step or

@@ -1597,7 +1597,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 return;
             }
         }
-        if (!p.no_wide && p.splits == 1 && p.M >= (p.coresident == 1 ? 1344 : 1792) && (p.K & 31) == 0 && p.N % 256 == 0) {
+        if (!p.no_wide && p.splits == 1 && p.M >= (p.coresident == 1 ? (p.wide_min_rows > 0 ? p.wide_min_rows : 1344) : 1792) && (p.K & 31) == 0 && p.N % 256 == 0) {
             // 256- or 224-row tiles: whichever needs fewer rounds x rows (7 168 rows: N = 4096 two full rounds of 224-row tiles instead of
             // 1.75 of 256-row ones, N = 2048 one round of 256 smaller tiles; 15 360 rows stay at 256).  Cold operands, us per launch, 256 / 224 rows:
             // W1 at 7 168 rows 78.8 / 74.9, pw1 38.4 / 35.4, W1 at 3 584 rows 43.8 / 41.0; synchronous steps 512 streams 18.08 -> 17.82 ms, 256
@@ -1619,7 +1619,7 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
             // With it: 256 streams 8.00 -> 7.93, 384 streams 11.75 -> 11.43, 512 streams (every GEMM of the layer on these tiles) 15.31 -> 14.49.
             if (!best_mt && p.coresident == 1 && p.wide_rows != 2) {
                 const long tiles = (long)(p.N / 256) * ((p.M + 223) / 224);
-                if (tiles >= 96) { best_mt = 7; best_tiles = tiles; }
+                if (tiles >= (p.wide_min_tiles > 0 ? p.wide_min_tiles : 32)) { best_mt = 7; best_tiles = tiles; }          // engine option "wide_min_tiles"
             }
             if (p.wide_rows == 256 && best_mt) { best_mt = 8; best_tiles = (long)(p.N / 256) * ((p.M + 255) / 256); }      // engine option "wide_tiles" = 256: round 4's first form only
             if (best_mt == 8) {

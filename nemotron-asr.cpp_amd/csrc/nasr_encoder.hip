@@ -22,6 +22,8 @@ int run_gemm(nasr_engine *e, GemmParams &g, bool f32_weights, const char *tag) {
     g.t64_tiles_p1 = e->opt_t64_tiles + 1;
     g.narrow_stores = e->opt_epilogue16 ? 0 : 1;
     g.prio = e->opt_gemm_prio;
+    g.wide_min_tiles = e->opt_wide_min_tiles;
+    g.wide_min_rows = e->opt_wide_min_rows;
     if (e->opt_ablate & 32) return 0;
     if (use_bf16) launch_gemm_bf16(g, e->st);
     else launch_gemm_f32(g, e->st);

@@ -143,6 +143,8 @@ struct nasr_engine {
     int opt_tile_bands = -1;         // option "tile_bands": -1 = the rule (bands of column groups above 4 row chunks), 0 = never, 1 = always (same bits)
     int opt_wide_tiles = 1;          // option "wide_tiles": 256- / 224-row GEMM tiles from 1 792 rows where they fill the chip (k_gemm_wide; same bits); 256 = the 256-row form only, 0 = off
     bool opt_persist_gemm = false;   // option "persistent_gemm" = 1: GEMMs with >= 1.75 tiles of 128 x 128 per CU on the persistent tile loop (k_gemm_persist; same bits).  Off by default: alone on the chip with cache-resident operands it is 14-37 % faster at 7 168 rows, inside the engine (weights cold from HBM) 1 % -- profiles/r4_persistent_gemm.md
+    int opt_wide_min_tiles = 0;      // option "wide_min_tiles": pipelined steps take the 224 x 256 tiles from this many tiles (0 = the default of 32)
+    int opt_wide_min_rows = 0;       // option "wide_min_rows": ... and from this many rows (0 = the default of 1 344)
     int opt_gemm_prio = 0;           // option "gemm_prio": GemmParams::prio (probes of wave priority in the GEMM loops)
     bool opt_epilogue16 = true;      // option "epilogue16": SiLU rows, K / V ring rows and GLU pairs leave the GEMM epilogues as 16-byte stores (eight columns per thread; same values)
     bool opt_dwconv_stream = true;   // option "dwconv_stream": the depthwise conv with one workgroup per stream from 256 streams x 4 frames (k_dwconv_stream; same bits)

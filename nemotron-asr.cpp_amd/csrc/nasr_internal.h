@@ -161,6 +161,8 @@ struct GemmParams {
     int tile_bands;
     // engine option "t64_tiles" + 1 (0 = the default, 64): the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles
     int t64_tiles_p1;
+    int wide_min_tiles;   // pipelined steps: 224 x 256 tiles from this many of them (0 = 32)
+    int wide_min_rows;    // ... and from this many rows (0 = 1 344)
     int narrow_stores;    // 1: four columns per thread in every epilogue (engine option "epilogue16" = 0: rounds 1-4's 8-byte stores of the 16-bit outputs)
     ChainParams chain;
 #ifdef NASR_GEMM_STAMPS
