@@ -211,8 +211,8 @@ enum {
  * Kernel-selection switches for A/B runs and bit-identity tests (round 4: these were environment variables read inside the product path;
  * set them before the first step, results never depend on them): "gemm_cores" (-1 = the engine's rule, 0 / 1 = never / always the
  * large-M GEMM kernels of which two share a CU), "persistent_gemm" (1: GEMMs with several 128 x 128 tiles per CU on the persistent tile loop; default 0),
- * "wide_tiles" (default 1: 256- / 224-row tiles from 1 792 rows where their rounds fill the chip, in pipelined steps from 1 344 rows and 96 tiles;
- * 256: the 256-row form only; 3: without the pipelined steps' 96-tile rule; 0: off), 
+ * "wide_tiles" (default 1: 256- / 224-row tiles from 1 792 rows where their rounds fill the chip, in pipelined steps from 1 344 rows and 32 tiles ("wide_min_rows" / "wide_min_tiles"; rounds 4: 96);
+ * 256: the 256-row form only; 3: without the pipelined steps' tile-count rule; 0: off), 
  * "t64_tiles" (default 64, per engine: the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles; round 3: 127),
  * "tile_bands" (-1 = the rule: above 4 row chunks the tiles of a launch are handed to the XCDs in bands of column groups, so that the panels an XCD reads stay in its L2;
  * 0 / 1 = never / always), "f32_mfma" (0: f32 GEMMs above
@@ -221,7 +221,7 @@ enum {
  * slabs and k_post adds them, as in rounds 1-4; default 1: the GEMM adds to the residual stream in its epilogue where one workgroup owns a tile's
  * whole K sum -- same bits), "gemm_prio" (default 0: round 5's GEMM loops -- k_gemm_wide2 / k_gemm_tiled3: the next chunk's fragments read under this chunk's
  * MFMAs, wave-private epilogues; 20: rounds 1-4's loops; same bits), "epilogue16" (default 1: the GEMM epilogues with 16-bit outputs store eight columns = 16 bytes
- * per thread; 0: four), "wide_min_tiles" (default 96: pipelined steps take the 224 x 256 tiles from this many of them), "split_tasks" (default 200: residual GEMMs take
+ * per thread; 0: four), "wide_min_tiles" / "wide_min_rows" (defaults 32 / 1 344: pipelined steps take the 224 x 256 tiles from this many tiles and rows), "split_tasks" (default 200: residual GEMMs take
  * one K slice from this many 128 x 128 tiles), "ablate" (MEASUREMENT ONLY -- results
  * are invalid: bit mask of launches left out of a step: 1 residual + LayerNorm, 2 attention, 4 depthwise conv, 8 decode iterations, 16 front end, 32 encoder
  * GEMMs; what each costs a pipelined step: profiles/r5_ablation.md), "decode_lane" (0: the decode graphs run behind the last encoder

@@ -1611,7 +1611,8 @@ void launch_gemm_bf16(const GemmParams &p0, hipStream_t st) {
                 const long cost = (tiles + g_num_cus - 1) / g_num_cus * bm;
                 if (!best_mt || cost < best_cost) { best_mt = mt; best_cost = cost; best_tiles = tiles; }
             }
-            // Pipelined steps (other lanes' workgroups fill the CUs a launch leaves idle): 224-row tiles from 96 of them, where the rule above finds
+            // Pipelined steps (other lanes' workgroups fill the CUs a launch leaves idle): 224-row tiles from 32 of them (round 4: 96; round 5, profiles/r5_gemm_tile_stamps.md section 3:
+            // what a pipelined step pays for a GEMM is its CU-time, and a 224 x 256 tile costs 40 % less of it than four 128 x 128 ones -- 256 streams 7.4 -> 7.2 ms), where the rule above finds
             // too few to fill the chip.  What a pipelined step is short of is operand delivery -- at 64 streams the LDS fills of a step's
             // 128 x 128 tiles add up to 23 GB = 9.5 TB/s, between what the Infinity Cache (8.6) and an XCD's L2 (17-19) deliver -- and a
             // 224 x 256 tile moves 0.54 of the bytes per flop.  ms per step, four lanes, without / with: 96 streams 3.37 / 3.33, 128 streams

@@ -154,7 +154,7 @@ struct GemmParams {
     // 1 = never the 256-row tiles (k_gemm_wide): engine option "wide_tiles" = 0, the other side of their bit-identity test
     int no_wide;
     // 256 = of the wide tiles only the 256-row form (engine option "wide_tiles" = 256: A/B against the 224-row form); 2 = not the pipelined steps'
-    // 96-tile rule ("wide_tiles" = 3); 0 = the launcher's rule
+    // tile-count rule ("wide_tiles" = 3); 0 = the launcher's rule
     int wide_rows;
     // tile order of the LDS-tiled bf16 kernels (tile_of(), kernels_gemm.hip): 0 = bands of column groups above 4 row chunks, 1 = always,
     // 2 = never (the row chunk fastest; engine option "tile_bands" = 0: the order of rounds 1-3)
