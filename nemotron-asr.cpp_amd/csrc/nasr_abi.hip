@@ -21,6 +21,7 @@ extern "C" int nasr_engine_set_option(nasr_engine *e, const char *key, int value
         e->opt_decode_lane = value != 0;
     }
     else if (!strcmp(key, "wide_min_tiles")) e->opt_wide_min_tiles = value;
+    else if (!strcmp(key, "large_step_rows")) e->opt_large_step_rows = value;
     else if (!strcmp(key, "wide_min_rows")) e->opt_wide_min_rows = value;
     else if (!strcmp(key, "gemm_prio")) e->opt_gemm_prio = value;                    // probe: GemmParams::prio (measurement only)
     else if (!strcmp(key, "epilogue16")) e->opt_epilogue16 = value != 0;            // like "fused": set before the first step

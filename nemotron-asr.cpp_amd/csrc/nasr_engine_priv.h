@@ -138,7 +138,8 @@ struct nasr_engine {
     int opt_decode_graph_iters = 12;   // blind decode iterations a pipelined step's decode graph carries at most (option "decode_graph_iterations")
     bool opt_decode_lane = true;       // the decode graphs get a lane of their own when a queue is free (option "decode_lane")
     int opt_gemm_cores = -1;           // -1: the engine's rule; 0 / 1: never / always the GEMM kernels of which two share a CU (option "gemm_cores")
-    int opt_large_step_pieces = 3;   // option "large_step_pieces": most pieces of a pipelined step of 3 584 rows and more (0 = as many as "pipeline" says)
+    int opt_large_step_rows = 0;     // option "large_step_rows": the row count from which "large_step_pieces" applies (0 = the default of 5 600; round 4: 3 584)
+    int opt_large_step_pieces = 3;   // option "large_step_pieces": most pieces of a pipelined step of 5 600 rows and more (0 = as many as "pipeline" says)
     int opt_t64_tiles = 64;          // option "t64_tiles": the split-K GEMMs with N = 1024 take 128 x 64 tiles up to this many 128 x 128 tiles (per engine, carried in GemmParams)
     int opt_tile_bands = -1;         // option "tile_bands": -1 = the rule (bands of column groups above 4 row chunks), 0 = never, 1 = always (same bits)
     int opt_wide_tiles = 1;          // option "wide_tiles": 256- / 224-row GEMM tiles from 1 792 rows where they fill the chip (k_gemm_wide; same bits); 256 = the 256-row form only, 0 = off

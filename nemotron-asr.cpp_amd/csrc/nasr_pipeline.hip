@@ -312,9 +312,11 @@ int pipe_step(nasr_engine *e, nasr_stream *const *streams, int B, const int16_t 
     // pieces are faster than four.  ms per step at 2 / 3 / 4 pieces, R = 13 (with the pipelined steps' 224-row tiles): 512 streams 14.57 / 14.32 /
     // 14.61, 384 streams 11.51 / 10.95 / 11.06, 256 streams 7.99 / 7.93 / 7.97 (before those tiles two pieces were best: 15.29 / 15.60 / 15.97);
     // below 3 584 rows four win (192 streams 6.38 / 6.14 / 6.22 before the tiles, 128 streams 4.55 / 4.33 / 4.31, 64 streams 2.95 / 2.57 / 2.40) --
+    // Round 5 (GEMM launches of less CU-time: k_gemm_wide2, the 224 x 256 tiles from 32 of them): from 5 600 rows instead of 3 584 -- four pieces against three, same box, ms per step:
+    // 256 streams x R = 13 6.92-6.98 / 7.19-7.22, 320 streams 8.77-8.79 / 8.86-8.87, 384 streams 10.37-10.41 / 10.41-10.43, 512 streams 13.84-13.88 / 13.61 (option "large_step_rows").
     // profiles/r4_tile_order.md.  "pipeline" = E stays the upper bound, engine option "large_step_pieces" (default 3) is this one; a step's
     // tokens come back at most E calls later whatever the piece count.
-    if ((long)B * T * G >= 3584 && e->opt_large_step_pieces > 0) nseg = std::min(nseg, e->opt_large_step_pieces);
+    if ((long)B * T * G >= (e->opt_large_step_rows > 0 ? e->opt_large_step_rows : 5600) && e->opt_large_step_pieces > 0) nseg = std::min(nseg, e->opt_large_step_pieces);
     // steps in flight order their layers through the lanes (piece k of every step on lane k): a step cut differently from the ones before it
     // must not overtake them -- complete those first (a call population that crosses 3 584 rows, or an option change; never the steady state)
     if (e->pipe_last_nseg != nseg) {
