@@ -196,7 +196,7 @@ enum {
  * by side (it measures which streams share a hardware queue at the first pipelined step: normally 4).  The decode graphs run on
  * the last of these streams: a queue of their own up to E = 3, right behind the fourth piece at E = 4 (worth 1-5 % at 16-64
  * streams, nothing at one stream); fewer pieces when the process leaves the engine fewer queues, and at most three pieces whatever E from 5 600 rows ("large_step_rows"; round 4: 3 584) per
- * step (256 streams x R = 13: more lanes are more GEMM working sets in the same L2s; tokens then come back sooner; engine option "large_step_pieces",
+ * step (400+ streams x R = 13: more lanes are more GEMM working sets in the same L2s; tokens then come back sooner; engine option "large_step_pieces",
  * 0 = no such limit).  Throughput option for callers that push back to back
  * (a server draining a backlog, a file); a live stream keeps the default.
  * "pipeline" = 8 (round 3, experimental): for calls of one or two rows per step (one stream x R = 0 or 1, two streams x R = 0) the 8 steps in flight
