@@ -1310,10 +1310,12 @@ __device__ __forceinline__ void wave_epilogue_rows(const GemmParams &p, const fl
 // ------------------------------------------------------------------------------------
 // k_gemm_wide2 (round 5): the same 224 x 256 tile, the same MFMAs in the same order (k ascending per accumulator: the bits of k_gemm_wide), another
 // loop.  k_gemm_wide's iteration is barrier -> 4 DMA instructions -> 6 + 5 ds_read_b128 -> wait -> 28 MFMAs: both waves of a SIMD stand in the same
-// phase, so the matrix pipe idles through every chunk's DMA issue (~100+ cycles each inside a phase that also reads, MI355X_MICROARCH.md) and LDS
-// latency -- ~2 200 cycles per chunk against 896 of MFMA.  Here the fragments of chunk i + 1 are read into a SECOND register set while chunk i's
-// MFMAs run (the barrier of iteration i certifies chunk i + 1, one ahead), and the DMA instructions of chunk i + 5 go out one by one between the
-// MFMA groups.  Five ring slots (150 KiB) keep the DMA look-ahead at four iterations.  Needs K / 32 even and >= 8.
+// phase at the top of every chunk.  Here the fragments of chunk i + 1 are read into a SECOND register set while chunk i's MFMAs run (the barrier of
+// iteration i certifies chunk i + 1, one ahead), and the DMA instructions of chunk i + 5 go out one by one between the MFMA groups.  Five ring slots
+// (150 KiB) keep the DMA look-ahead at four iterations.  Needs K / 32 even and >= 8.
+// Measured (in-kernel stamps, tests/micro/wide_stamps.hip, profiles/r5_gemm_tile_stamps.md): the K loop stayed at ~1 300 cycles per chunk (896 of MFMA) -- what bounds it
+// is the issue of the LDS-DMA instructions themselves (~100+ cycles each), not the order around them; what the kernel gains (W2 at 7 168 rows 94 -> 84 us, W1 71 -> 68,
+// a 512-stream step 13.8 -> 13.5 ms) comes from the deeper ring, the reads off the critical path and the epilogue below.
 // ------------------------------------------------------------------------------------
 constexpr int W2_NS = 5;
 template <int BN, int MT> constexpr int wide2_lds() {          // the ring, or the eight wave-private epilogue regions (64 rows x WE_LD floats each), whichever is larger
