@@ -156,7 +156,7 @@ ge.load_package()
 from nemotron_asr_amd import synth
 from oracle import binding as ob, diar_binding as db
 W = synth.make_weights(n_layers=2)
-pcm = synth.make_pcm(5, 4.0)
+pcm = synth.make_pcm(5, 2.6)          # two 1.12 s chunks at R = 13, 30 at R = 0: enough for every code path, a third less time under ASan than 4 s
 toks = []
 for kwargs in ({{}}, {{"emulate_bf16": True}}):
     om = ob.OracleModel(W, 2, **kwargs)
@@ -164,13 +164,13 @@ for kwargs in ({{}}, {{"emulate_bf16": True}}):
         st = ob.OracleStream(om, R)
         st.enable_decision_log()
         t, o = [], 0
-        for n in (1, 999, 1280, 17920, 5, 30000, 64000):
+        for n in (1, 999, 1280, 17920, 5, 12000):
             t += st.process(pcm[o:o + n]); o += n
         t += st.process(pcm[o:]) + st.finalize()
         toks.append(t)
         assert len(st.decision_log()["margin"]) > 0
         st.reset(reference=True)
-        st.process(pcm[:20000])
+        st.process(pcm[:19000])
 Wv = synth.make_diar_weights(spk=False)
 p = db.DiarModel(Wv).vad_window(pcm[:10080].astype(np.float32) / 32768.0)
 import json
