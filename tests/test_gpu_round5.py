@@ -353,3 +353,16 @@ def test_256_streams_R13_vs_oracle(W2):
     kv = max(_spot_state_vs_oracle(sts[b], osts[b], L, T) for b in spots)
     assert kv < 1.2e-1, kv
     eng.close()
+
+
+def test_ragged_rows_on_the_wide_tiles_of_pipelined_steps():
+    """Round 5 lets pipelined steps take the 224 x 256 GEMM tiles from 32 tiles (was 96): at 100 / 130 streams x R = 13 (1 400 / 1 820 rows: ragged last row tile) W1, QKV (K / V ring
+    rows out of the epilogue) and pointwise_conv1 (GLU pairs) now run on k_gemm_wide2.  Same digest (tokens, encoder output, K and conv caches of every stream) as with 128 x 128 tiles
+    everywhere ("wide_tiles" = 0) and as rounds 1-4's loops ("gemm_prio" = 20): tests/micro/ragged_wide_check.py."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "micro" / "ragged_wide_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("==") == 3 and "!=" not in r.stdout
