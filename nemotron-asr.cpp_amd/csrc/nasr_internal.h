@@ -144,6 +144,7 @@ struct GemmParams {
     int coresident;       // 0: synchronous step, 1: pipelined step (the rule of kernels_gemm.hip decides), 2 / 3: always / never (engine option "gemm_cores")
     // wave priority of the co-resident kernels (round-4 probe, tests/micro/cores_probe.hip): bit 0 = s_setprio 3 for the whole kernel,
     // bit 1 = back to 0 before the epilogue.  0 = leave the default (what ships unless the probe says otherwise).
+    // prio >> 2 (round 5, engine option "gemm_prio"): 0 = round 5's loops (k_gemm_wide2, k_gemm_tiled3), 5 = rounds 1-4's (k_gemm_wide, k_gemm_tiled2_k32): A/B runs and the identity test
     int prio;
     // f32 GEMMs above four rows run on the f32-input MFMA (k_gemm_f32_mfma); 1 = the FMA tile kernel k_gemm_f32 instead (engine
     // option "f32_mfma" = 0: the other side of the bit-identity test)
