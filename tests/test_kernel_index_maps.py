@@ -130,3 +130,29 @@ def test_counted_waits_of_the_new_loops(NS, DMA, nchunks):
         if i + NS < nchunks:
             issued += 1
     assert issued == nchunks
+
+
+def panel32_off(row, col):          # byte offset in a [rows][32] bf16 panel (64-byte rows), the kernels' swizzle
+    return row * 64 + ((col ^ ((0 - (row >> 2)) & 3)) << 4)
+
+
+def test_activation_fragment_reads_are_bank_conflict_free():
+    """ds_read_b128 is served in four groups of 16 lanes (MI355X_MICROARCH.md, LDS table); bank of byte a = (a / 4) mod 64.  A fragment read of the 32-deep activation panel
+    (lane = (q, r): row r of a 16-row tile, 16-byte column q, swizzled by panel32_off) must put the 16 lanes of a group on 64 distinct banks; the weight tiles are lane-linear."""
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    groups += [[l + 32 for l in g] for g in groups]
+    assert sorted(sum(groups, [])) == list(range(64))
+    for row0 in (0, 16, 112, 208):
+        for g in groups:
+            banks = []
+            for lane in g:
+                a = panel32_off(row0 + (lane & 15), lane >> 4)
+                banks += [((a + 4 * d) // 4) % 64 for d in range(4)]
+            assert len(set(banks)) == 64, (row0, g)
+            lin = []
+            for lane in g:
+                lin += [((lane * 16 + 4 * d) // 4) % 64 for d in range(4)]
+            assert len(set(lin)) == 64
+    # the swizzle is an involution on the 16-byte column index: the DMA source applies it, the read applies it again
+    for row in range(224):
+        assert sorted(panel32_off(row, c) - row * 64 for c in range(4)) == [0, 16, 32, 48]
