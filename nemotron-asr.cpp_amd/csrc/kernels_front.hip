@@ -120,13 +120,25 @@ void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring
 // Rounds 1-4 issued 2 hipMemsetAsync per layer + 5 on the engine's stream for every stream that started (53 fills, 32 MB zeroed, in
 // front of the next step of every live stream).  What a fresh stream needs is much less: the conv caches (64 KB per layer), the decoder
 // state, the 9 literal-zero mel frames the first chunk reads, the 256 zero samples the audio buffer is pre-seeded with, last_sample
-// and the decoder control block.  The K/V rings are NOT touched: cache_valid_len = 0 hides every cached row behind the -1e9 mask
-// (weight exactly 0, :1037-1043 -- the reference's own reset relies on it, :95-115), the pool is zeroed once at nasr_engine_create and only
-// ever holds finite values the engine wrote itself (tests/test_gpu_parity.py::test_stale_kv_rows_never_reach_a_result).
-// blocks [0, n_layers): conv cache of that layer (skipped when the reference's reset semantics are asked for); block n_layers: the rest.
+// and the decoder control block.  Of the K/V rings only the 70 WINDOW rows in front of the stream's head are zeroed (round 6; 70 x 1024 x K, V
+// = 280 KB per layer in bf16, 6.9 MB per stream start): cache_valid_len = 0 hides every cached row behind the -1e9 mask (weight exactly 0,
+// :1037-1043 -- the reference's own reset relies on it, :95-115), but a weight of exactly 0 times a stale NaN / Inf is NaN, and a slot's
+// previous stream may have left one (float mel handed to nasr_engine_step_mel, a broken checkpoint).  The rows a masked key can ever name are
+// exactly those 70 (the mask shrinks by T per chunk while the window slides by T), so with them zeroed no stream inherits a non-finite value
+// from its slot (tests/test_gpu_round6.py::test_nan_in_a_recycled_slot_does_not_reach_the_next_stream); finite stale rows never mattered
+// (tests/test_gpu_parity.py::test_stale_kv_rows_never_reach_a_result).
+// blocks [0, n_layers): conv cache (skipped when the reference's reset semantics are asked for) + K/V window of that layer; block n_layers: the rest.
 __global__ __launch_bounds__(256) void k_stream_reset(StreamResetParams p) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((int)blockIdx.x < p.n_layers) {
+        // K/V window: logical keys 0 .. LCTX-1 = ring rows (kv_head + j) % KVC, of K (plane 0) and V (plane 1)
+        char *kv = (char *)p.kv_pools[blockIdx.x] + (size_t)p.slot * 2 * KVC * D * p.esz;
+        const int row_f4 = D * p.esz / 16;                      // float4 per ring row
+        for (int i = threadIdx.x; i < 2 * LCTX * row_f4; i += 256) {
+            const int plane = i / (LCTX * row_f4), r = i % (LCTX * row_f4);
+            const int ring = (p.kv_head + r / row_f4) % KVC;
+            ((float4 *)(kv + ((size_t)plane * KVC + ring) * D * p.esz))[r % row_f4] = z4;
+        }
         if (p.keep_reference_state) return;
         float4 *cc = (float4 *)(p.cc_pools[blockIdx.x] + (size_t)p.slot * p.cc_slot_floats);
         for (int i = threadIdx.x; i < p.cc_slot_floats / 4; i += 256) cc[i] = z4;

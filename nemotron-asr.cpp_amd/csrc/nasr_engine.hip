@@ -504,6 +504,8 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     if (!rc) {
         rc |= dalloc(e, &e->cc_ptrs_dev, Lr);
         if (!rc && hipMemcpy(e->cc_ptrs_dev, e->cc_pool.data(), Lr * sizeof(float *), hipMemcpyHostToDevice) != hipSuccess) rc = fail("hipMemcpy (conv-cache table) failed");
+        rc |= dalloc(e, &e->kv_ptrs_dev, Lr);
+        if (!rc && hipMemcpy(e->kv_ptrs_dev, e->kv_pool.data(), Lr * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) rc = fail("hipMemcpy (K/V ring table) failed");
     }
     rc |= dalloc(e, &e->dec_h, S * 4 * HID);
     rc |= dalloc(e, &e->dec_c, S * 4 * HID);
@@ -667,11 +669,13 @@ void engine_destroy_impl(nasr_engine *e) {
 // -1e9 and weight exactly 0) and the preprocessor's carry (un-framed samples, last_sample) survive.
 int stream_zero_state(nasr_stream *s, bool keep_reference_state) {
     nasr_engine *e = s->e;
-    // ONE launch (k_stream_reset, kernels_front.hip); the K/V rings are left alone: zeroed once at nasr_engine_create, hidden by
-    // cache_valid_len = 0 afterwards (rounds 1-4: 53 fills of 32 MB per stream start on the engine's stream)
+    // ONE launch (k_stream_reset, kernels_front.hip); of the K/V rings (zeroed once at nasr_engine_create, hidden by cache_valid_len = 0
+    // afterwards) only the 70 window rows in front of the head are zeroed, so that a non-finite value left by the slot's previous stream
+    // cannot meet a weight of 0 (rounds 1-4: 53 fills of 32 MB per stream start on the engine's stream)
     StreamResetParams rp;
     memset(&rp, 0, sizeof(rp));
     rp.cc_pools = e->cc_ptrs_dev; rp.n_layers = e->hp.n_layers; rp.slot = s->slot;
+    rp.kv_pools = e->kv_ptrs_dev; rp.esz = (int)e->esz; rp.kv_head = keep_reference_state ? s->kv_head : 0;
     rp.cc_slot_floats = 2 * (e->hp.kernel_size - 1) * D;
     rp.keep_reference_state = keep_reference_state ? 1 : 0;
     rp.abuf = e->abuf; rp.last_sample = e->last_sample; rp.mel_ring = e->mel_ring; rp.dec_h = e->dec_h; rp.dec_c = e->dec_c; rp.ctrl = e->ctrl;

@@ -121,6 +121,7 @@ struct nasr_engine {
     std::vector<void *> kv_pool;     // per layer [slot][2][KVC][1024] act dtype
     std::vector<float *> cc_pool;    // per layer [slot][2][ks-1][1024]
     float **cc_ptrs_dev = nullptr;   // device copy of cc_pool (k_stream_reset walks the layers in one launch)
+    void **kv_ptrs_dev = nullptr;    // device copy of kv_pool (same launch: the 70 window rows of a starting stream are zeroed)
     float *dec_h, *dec_c;
     DecCtrl *ctrl;
     int *tok_ring;

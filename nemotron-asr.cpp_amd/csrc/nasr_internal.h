@@ -201,6 +201,8 @@ void launch_mel_put(const float *staged, const PcmDesc *desc, int B, int max_fra
 void launch_mel_zero(const PcmDesc *desc, int B, int max_frames, float *mel_ring, hipStream_t st);
 struct StreamResetParams {      // one launch per stream start / reset (kernels_front.hip: k_stream_reset)
     float *const *cc_pools;     // device array [n_layers] of the layers' conv-cache pools
+    void *const *kv_pools;      // device array [n_layers] of the layers' K/V ring pools ([slot][2][KVC][1024], esz bytes per element)
+    int esz, kv_head;           // element size of the rings; ring index of logical key 0 (the 70 window rows from there are zeroed)
     int n_layers, slot;
     int cc_slot_floats;         // 2 * (ks - 1) * 1024
     int keep_reference_state;   // NASR_RESET_REFERENCE: conv caches, audio-buffer carry and last_sample survive

@@ -58,7 +58,8 @@ __device__ __forceinline__ void post_row(const PostParams &p, int m, int t256, f
 #pragma unroll
         for (int s = 1; s < 8; s++)
             if (s < p.splits) { o.x += t[s].x; o.y += t[s].y; o.z += t[s].z; o.w += t[s].w; }
-        v.x += p.scale * o.x; v.y += p.scale * o.y; v.z += p.scale * o.z; v.w += p.scale * o.w;
+        // an explicit fma: the same bits as the GEMM epilogues that fold this add (EPI_RESID_F32, __builtin_fmaf) whatever -ffp-contract says
+        v.x = __builtin_fmaf(p.scale, o.x, v.x); v.y = __builtin_fmaf(p.scale, o.y, v.y); v.z = __builtin_fmaf(p.scale, o.z, v.z); v.w = __builtin_fmaf(p.scale, o.w, v.w);
     }
     if (p.ln_out) v = ln4(v, w1, b1, sh, t256);
     if (live && (p.splits > 0 || p.ln_out)) store_wt_f4(p.x + (size_t)m * D + c4, v);

@@ -35,17 +35,29 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Write-through stores (sc0 sc1) for bulk outputs that the NEXT kernel reads: the bytes go to memory as they are produced
 // instead of sitting dirty in this XCD's L2 until the end-of-kernel write-back (tests/micro/gemm_probe.hip, mode 9).
+//
+// HAZARD (CDNA3/4 ISA, "VMEM store of more than 64 bits followed by a write of its data VGPRs": 2 wait states; cdna_hip_programming.md
+// section 5.7 item 1): hipcc's hazard recognizer does not look inside an asm string, so every > 64-bit store below ENDS with `s_nop 1`
+// inside the string -- whatever hipcc schedules behind the statement then finds the wait states already served.  Round 5 shipped the x4 form
+// without the pad (correct only by scheduling accident) and saw the uint4 form put wrong words into lanes 12-15 when the compiler's next
+// instruction (the v_perm/v_lshl_or packing of the following 16-bit group) rewrote the data registers one state after the store issued;
+// a wait state IN FRONT of the store cannot help with that.  tests/test_store_hazards.py disassembles every built code object and fails on
+// an asm-emitted dwordx3/x4 store whose data registers are written within two wait states.
 typedef __attribute__((ext_vector_type(4))) float wt_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned wt_u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned wt_u32x2;
 __device__ __forceinline__ void store_wt_f4(float *p, float4 v) {
     const wt_f32x4 w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
-// Sixteen bytes of packed 16-bit values: a PLAIN store.  The write-through asm form of it (global_store_dwordx4 ... sc0 sc1 with a uint vector operand)
-// put wrong words into memory for lanes 12-15 of every 16 (round 5, tests/micro/post_probe.hip: 1 element in 32 of k_post_wave's bf16 rows; a wait
-// state in front of the asm did not help, the compiler's own store of the same registers is right) -- not understood, not used.
+// Sixteen bytes of packed 16-bit values, write-through (see HAZARD above: the pad is what round 5's form lacked).
+__device__ __forceinline__ void store_wt_u4(void *p, uint4 v) {
+    const wt_u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+}
+// Sixteen bytes of packed 16-bit values: a PLAIN store (the compiler's own; it pads its hazards itself).
 __device__ __forceinline__ void store_u4(void *p, uint4 v) { *(uint4 *)p = v; }
-__device__ __forceinline__ void store_wt_u2(void *p, uint2 v) {
+__device__ __forceinline__ void store_wt_u2(void *p, uint2 v) {      // 64 bits: no data hazard (the rule is for > 64-bit stores)
     const wt_u32x2 w = {v.x, v.y};
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
 }
