@@ -1,0 +1,568 @@
+// kernels_spk.hip -- TitaNet-L on SEGMENT TILES (round 6; reference src/diarize_spk.cpp:320-515).
+//
+// Rounds 1-5 ran the speaker network layer by layer with f32 activations in memory between ~66 launches: per separable sub-block a depthwise
+// kernel (f32 in, bf16 out: 94 MB, 54-58 us) + a generic GEMM writing f32 (46 us), per block colmean + SE + mask_cvt + combine; the tail moved
+// 189 MB tensors five times.  0.076 of the MFMA peak.
+//
+// What makes TitaNet different from the ASR encoder: everything that couples rows -- the depthwise convs, the SE mean, the masked statistics,
+// the attentive pooling's softmax -- runs along the TIME axis of ONE sub-segment, 160 rows.  So the GEMM tile here is 160 rows x 256 columns
+// = one sub-segment x 256 channels, and whatever follows the pointwise conv happens in its epilogue while the tile is in LDS:
+//   SG_DW    bias + ReLU + mask, then the NEXT sub-block's depthwise conv along time          -> bf16 A operand of the next GEMM
+//   SG_Y     bias (last sub-block of a Jasper block)                                          -> Y f32 + the SE gate's masked column means
+//   SG_RES   residual 1x1 conv: relu(mask(Y) * sigmoid(z) + acc + bias) = the block's output  -> bf16 X (masked) + the next block's first depthwise conv
+//   SG_ASP   second attention conv: logits stay in LDS; softmax over the valid frames, weighted mean / std per channel -> pool (+ folded BN)
+// k_spk_tile does the same for the two places without a GEMM in front (block 0 / block 4: relu(mask(Y) * gate), then depthwise or masked statistics).
+// A call is ~40 launches; no f32 activation except Y touches memory; A / X operands are written once, as bf16, by the kernel that computes them.
+//
+// Main loop = k_gemm_wide's (kernels_gemm.hip) on a 160 x 128 tile, FOUR waves: 32-deep chunks (160 x 64 B activation panel + 8 weight tiles of 1 KiB)
+// by LDS-DMA into a 4-slot ring, three in flight; 4 waves = 2 row halves x 2 column halves, 80 x 64 per wave = 20 accumulators of 16 x 16;
+// v_mfma_f32_16x16x32_bf16, k ascending from zero per accumulator (the bits of every other bf16 GEMM of this library).
+// 72 KiB of LDS and <= 256 VGPRs: TWO workgroups per CU.  At K = 1024 a tile is 32 chunks: prologue + epilogue are as long as the K loop
+// (profiles/r5_gemm_tile_stamps.md), and with one 8-wave workgroup per CU (the first form of this kernel: 160 x 256 tiles, 384 of them on 256 CUs)
+// every CU stood in the same phase: SG_Y 61 us, SG_DW 74, SG_RES 107 per launch at 96 segments.  Two co-resident workgroups run one's epilogue under
+// the other's K loop, and 96 segments x 8 column tiles = 768 tiles = three per CU instead of 1.5 rounds of large ones.
+// The epilogue goes through LDS in two column halves of 64: stage[160][68] f32 (the two waves that own the half park it, all 256 threads work on it).
+#include "nasr_internal.h"
+#include "nasr_wave.h"
+
+namespace nasr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 sg_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float sg_f32x4;
+
+namespace {
+
+constexpr int SG_BM = SPK_T, SG_BN = 128, SG_MT = 5, SG_NT = 4, SG_NW = 4, SG_THREADS = 64 * SG_NW;
+constexpr int SG_SLOT = (SG_BM + SG_BN) * 64;                 // bytes per 32-deep chunk: 18 432
+constexpr int SG_NS = 4, SG_P = SG_NS - 1;                    // ring slots, chunks in flight
+constexpr int SG_NP = SG_BM / 16, SG_PIECES = SG_NP + SG_BN / 16, SG_DMA = (SG_PIECES + SG_NW - 1) / SG_NW;     // 10 + 8 pieces of 1 KiB, 5 DMA instructions per wave and chunk
+constexpr int SG_SLD = 68;                                    // floats per staged row (64 + 4)
+constexpr int SG_STAGE_FLOATS = SG_BM * SG_SLD;               // 10 880 floats = 43 520 B
+constexpr int SG_RED_FLOATS = 3 * 512;                        // three reduction scratch areas [time groups][64 channels] (512 floats each: up to 8 groups)
+constexpr int SG_LDS = SG_NS * SG_SLOT;                       // 73 728 B >= stage + red (49 664 B); two workgroups per CU
+static_assert(SG_LDS >= (SG_STAGE_FLOATS + SG_RED_FLOATS) * 4, "the epilogue's stage fits in the ring");
+static_assert(SG_BM == 160 && SPK_TVALID <= SG_BM, "one sub-segment per tile");
+
+__device__ __forceinline__ void sg_glds16(const void *gsrc, unsigned lds_dst) {      // cdna_hip_programming.md 5.7: M0 written in the statement that reads it
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// activation panel in LDS: row-major 64 B rows, the four 16-byte columns of a row rotated by the row's group of four (bank-conflict-free ds_read_b128 of a fragment)
+__device__ __forceinline__ int sg_panel_off(int row, int col) { return row * 64 + ((col ^ ((0 - (row >> 2)) & 3)) << 4); }
+
+__device__ __forceinline__ float sg_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }          // k_spk_combine's expression
+
+// ---- epilogue pieces on stage[160][SG_SLD] (64 channels of one sub-segment; rows >= L already zero), by NT threads -----------------------------
+// Every load below is UNCONDITIONAL (clamped address, select afterwards): a load inside `cond ? load : 0` is a branch per load, and the first form of
+// these kernels spent 200 us per launch in 20 dependent round trips of the pooling epilogue.
+
+// depthwise 'same' conv along time with taps w[i][.] (global [k][ldw]), src/diarize_spk.cpp:256-282: out row t >= L = 0.
+// Thread = (channel pair cp, group of TG frames); fma chain i ascending: k_spk_depthwise's order (same bits from the same f32 inputs).
+template <int KS, int NT>
+__device__ __forceinline__ void sg_dw_pass(const float *stage, const float *w, int ldw, int L, bf16_t *a_rows, int lda_out) {
+    constexpr int PAD = (KS - 1) / 2, TG = 10, WIN = TG + KS - 1, ROUNDS = SG_BM / (NT / 32) / TG;      // 10 frames per thread and round: the window stays at 24 registers pairs
+    const int cp = threadIdx.x & 31;
+    float2 wk[KS];
+#pragma unroll
+    for (int i = 0; i < KS; i++) wk[i] = *(const float2 *)(w + (size_t)i * ldw + 2 * cp);
+#pragma unroll 1
+    for (int rd = 0; rd < ROUNDS; rd++) {
+        const int t0 = ((threadIdx.x >> 5) * ROUNDS + rd) * TG;
+        float2 in[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; j++) {
+            const int tt = t0 + j - PAD, tc = tt < 0 ? 0 : (tt >= SG_BM ? SG_BM - 1 : tt);
+            const float2 v = *(const float2 *)(stage + tc * SG_SLD + 2 * cp);
+            in[j] = (tt >= 0 && tt < SG_BM) ? v : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < TG; u++) {
+            const int t = t0 + u;
+            float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+            for (int i = 0; i < KS; i++) {
+                ax = i == 0 ? in[u + i].x * wk[i].x : __builtin_fmaf(in[u + i].x, wk[i].x, ax);
+                ay = i == 0 ? in[u + i].y * wk[i].y : __builtin_fmaf(in[u + i].y, wk[i].y, ay);
+            }
+            if (t >= L) { ax = 0.0f; ay = 0.0f; }
+            *(uint32_t *)(a_rows + (size_t)t * lda_out + 2 * cp) = (uint32_t)f32_to_bf16(ax) | ((uint32_t)f32_to_bf16(ay) << 16);
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void sg_dw(const float *stage, const float *w, int ks, int ldw, int L, bf16_t *a_rows, int lda_out) {
+    if (ks == 7) sg_dw_pass<7, NT>(stage, w, ldw, L, a_rows, lda_out);
+    else if (ks == 11) sg_dw_pass<11, NT>(stage, w, ldw, L, a_rows, lda_out);
+    else if (ks == 15) sg_dw_pass<15, NT>(stage, w, ldw, L, a_rows, lda_out);
+    else if (ks == 3) sg_dw_pass<3, NT>(stage, w, ldw, L, a_rows, lda_out);
+}
+
+// column reductions: thread (c = tid & 63, g = tid >> 6) handles the RG = 160 / (NT / 64) frames of its group; partials go to red[g * 64 + c], the
+// caller's barrier, then sg_redsum adds them in group order
+template <int NT> __device__ __forceinline__ float sg_colsum_partial(const float *stage, int L) {
+    constexpr int RG = SG_BM / (NT / 64);
+    const int c = threadIdx.x & 63, t0 = (threadIdx.x >> 6) * RG;
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < RG; u++) { const float v = stage[(t0 + u) * SG_SLD + c]; s += (t0 + u < L) ? v : 0.0f; }
+    return s;
+}
+template <int NT> __device__ __forceinline__ float sg_redsum(const float *red, int c) {
+    if (NT == 512) return ((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c])) + ((red[256 + c] + red[320 + c]) + (red[384 + c] + red[448 + c]));
+    return (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+}
+template <int NT> __device__ __forceinline__ float sg_redmax(const float *red, int c) {
+    float m = fmaxf(fmaxf(red[c], red[64 + c]), fmaxf(red[128 + c], red[192 + c]));
+    if (NT == 512) m = fmaxf(m, fmaxf(fmaxf(red[256 + c], red[320 + c]), fmaxf(red[384 + c], red[448 + c])));
+    return m;
+}
+
+// relu(mask(y) * sigmoid(z) + v) for the whole 160 x 64 tile: stage holds v (or nothing: HAS_V = false) and receives the masked result; X (bf16) is written too.
+// Item e = tid + k NT <-> (row e >> 4, columns 4 (e & 15) ..); Y is read five items at a time (rows >= L too: the buffer has them; masked here).
+template <bool HAS_V, int NT>
+__device__ __forceinline__ void sg_combine(float *stage, const float *y_rows, int ldy, const float *zrow, int L, bf16_t *x_rows, int ldx) {
+    constexpr int PER = SG_BM * 16 / NT;
+    const float4 z = *(const float4 *)(zrow + (threadIdx.x & 15) * 4);          // NT is a multiple of 16: a thread keeps its four columns
+    const float4 g = make_float4(sg_sigmoid(z.x), sg_sigmoid(z.y), sg_sigmoid(z.z), sg_sigmoid(z.w));
+#pragma unroll 1
+    for (int k0 = 0; k0 < PER; k0 += 5) {
+        float4 yq[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = threadIdx.x + (k0 + k) * NT;
+            yq[k] = *(const float4 *)(y_rows + (size_t)(e >> 4) * ldy + (e & 15) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = threadIdx.x + (k0 + k) * NT, row = e >> 4, c4 = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HAS_V) v = *(const float4 *)(stage + row * SG_SLD + c4);
+            float4 o;
+            o.x = fmaxf(yq[k].x * g.x + v.x, 0.0f);
+            o.y = fmaxf(yq[k].y * g.y + v.y, 0.0f);
+            o.z = fmaxf(yq[k].z * g.z + v.z, 0.0f);
+            o.w = fmaxf(yq[k].w * g.w + v.w, 0.0f);
+            if (row >= L) o = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4 *)(stage + row * SG_SLD + c4) = o;
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+            *(uint2 *)(x_rows + (size_t)row * ldx + c4) = pk;
+        }
+    }
+}
+
+}  // namespace
+
+// ---- the GEMM ---------------------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
+    constexpr int NT = SG_THREADS;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int n_groups = p.N / SG_BN, nblk = gridDim.x;
+    int id = blockIdx.x;
+    {   // an XCD takes a contiguous run of tiles: the column tiles of a segment share its A panel in that XCD's L2
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = id & 7, loc = id >> 3;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    }
+    const int s = id / n_groups, ng = id - s * n_groups;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nq = wave & 1, mh = wave >> 1, q = lane >> 4, r = lane & 15;
+    const int KT = p.K >> 5;
+    const size_t m0 = (size_t)s * SG_BM;
+    const char *src[SG_DMA];
+    unsigned dst[SG_DMA];
+    int step[SG_DMA];
+#pragma unroll
+    for (int u = 0; u < SG_DMA; u++) {
+        int j = wave * SG_DMA + u;
+        if (j >= SG_PIECES) j = SG_PIECES - 1;          // the same bytes to the same place a second time: every wave's vmcnt arithmetic stays equal
+        if (j < SG_NP) {
+            const int row = j * 16 + (lane >> 2);
+            src[u] = (const char *)(p.A + (m0 + row) * p.lda) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
+            dst[u] = (unsigned)(j * 1024);
+            step[u] = 64;
+        } else {
+            const int t = j - SG_NP;
+            src[u] = (const char *)p.W + (size_t)(ng * (SG_BN / 16) + t) * KT * 1024 + lane * 16;
+            dst[u] = (unsigned)(SG_BM * 64 + t * 1024);
+            step[u] = 1024;
+        }
+    }
+    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    auto issue = [&](int kt, int slot) {
+        const unsigned sb = ring_base + slot * SG_SLOT;
+#pragma unroll
+        for (int u = 0; u < SG_DMA; u++) sg_glds16(src[u] + (size_t)kt * step[u], sb + dst[u]);
+    };
+    sg_f32x4 acc[SG_NT][SG_MT];
+#pragma unroll
+    for (int j = 0; j < SG_NT; j++)
+#pragma unroll
+        for (int mt = 0; mt < SG_MT; mt++) acc[j][mt] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SG_P; i++)
+        if (i < KT) issue(i, i);
+    const int L = p.lens[s];
+    int slot = 0;
+    for (int i = 0; i < KT; i++) {
+        const int left = KT - 1 - i;                            // chunks allowed to stay in flight: min(left, P - 1)
+        if (left >= SG_P - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA * (SG_P - 1)) : "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
+        if (i + SG_P < KT) issue(i + SG_P, slot == 0 ? SG_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
+        const char *sp = ring + slot * SG_SLOT;
+        uint4 wf[SG_NT];
+#pragma unroll
+        for (int j = 0; j < SG_NT; j++) wf[j] = *(const uint4 *)(sp + SG_BM * 64 + (nq * SG_NT + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int mt = 0; mt < SG_MT; mt++) {
+            const uint4 bv = *(const uint4 *)(sp + sg_panel_off(mh * (SG_BM / 2) + mt * 16 + r, q));
+            const sg_bf16x8 bf = __builtin_bit_cast(sg_bf16x8, bv);
+#pragma unroll
+            for (int j = 0; j < SG_NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
+        }
+        slot = slot + 1 == SG_NS ? 0 : slot + 1;
+    }
+
+    // ---- epilogue: two column halves of 64 through stage[160][68] ----
+    float *stage = (float *)ring, *red = stage + SG_STAGE_FLOATS;
+    for (int cq = 0; cq < SG_BN / 64; cq++) {
+        const int n0c = ng * SG_BN + cq * 64;                  // global column of the half's column 0
+        __syncthreads();                                        // the ring / the previous half's stage is no longer read
+        if (nq == cq) {
+#pragma unroll
+            for (int j = 0; j < SG_NT; j++) {
+                const float4 b = *(const float4 *)(p.bias + n0c + j * 16 + q * 4);
+#pragma unroll
+                for (int mt = 0; mt < SG_MT; mt++) {
+                    const int row = mh * (SG_BM / 2) + mt * 16 + r;
+                    float4 v = make_float4(acc[j][mt][0] + b.x, acc[j][mt][1] + b.y, acc[j][mt][2] + b.z, acc[j][mt][3] + b.w);
+                    if (MODE == SG_DW) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));      // ReLU between the sub-convs (:360-363)
+                    if (MODE != SG_RES && row >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);                                           // MaskedConv1d: frames >= L read as zero
+                    *(float4 *)(stage + row * SG_SLD + j * 16 + q * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (MODE == SG_DW) {
+            sg_dw<NT>(stage, p.dw_w + n0c, p.dw_k, p.N, L, p.a_out + m0 * p.lda_out + n0c, p.lda_out);
+        } else if (MODE == SG_Y) {
+#pragma unroll
+            for (int k = 0; k < SG_BM * 16 / NT; k++) {
+                const int e = threadIdx.x + k * NT, row = e >> 4, c4 = (e & 15) * 4;
+                *(float4 *)(p.y_out + (m0 + row) * p.N + n0c + c4) = *(const float4 *)(stage + row * SG_SLD + c4);
+            }
+            red[threadIdx.x] = sg_colsum_partial<NT>(stage, L);
+            __syncthreads();
+            if (threadIdx.x < 64) p.colmean[(size_t)s * p.N + n0c + threadIdx.x] = sg_redsum<NT>(red, threadIdx.x) * (1.0f / (float)L);
+        } else if (MODE == SG_RES) {
+            sg_combine<true, NT>(stage, p.y_in + m0 * p.N + n0c, p.N, p.z + (size_t)s * p.N + n0c, L, p.x_out + m0 * p.N + n0c, p.N);
+            if (p.dw_k > 1) {
+                __syncthreads();
+                sg_dw<NT>(stage, p.dw_w + n0c, p.dw_k, p.N, L, p.a_out + m0 * p.lda_out + n0c, p.lda_out);
+            }
+        } else if (MODE == SG_ASP) {
+            // attentive statistics (:432-487): per channel softmax over the valid frames of the logits in stage, weighted mean and std of x, folded BN
+            constexpr int RG = SG_BM / (NT / 64);
+            const int c = threadIdx.x & 63, t0 = (threadIdx.x >> 6) * RG;
+            const bf16_t *xp = p.x_in + (m0 + t0) * p.N + n0c + c;
+            float lg[RG], xv[RG];
+#pragma unroll
+            for (int u = 0; u < RG; u++) xv[u] = bf16_to_f32(xp[(size_t)u * p.N]);          // rows >= L: masked zeros (written so by k_spk_tile), weight 0 below
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < RG; u++) {
+                const float v = stage[(t0 + u) * SG_SLD + c];
+                lg[u] = t0 + u < L ? v : -INFINITY;
+                mx = fmaxf(mx, lg[u]);
+            }
+            red[threadIdx.x] = mx;
+            __syncthreads();
+            mx = sg_redmax<NT>(red, c);
+            float Z = 0.0f, sx = 0.0f;
+#pragma unroll
+            for (int u = 0; u < RG; u++) {
+                const float ev = expf(lg[u] - mx);                   // exp(-inf) = 0 exactly: frames >= L carry -1e9 in the reference, same weight
+                lg[u] = t0 + u < L ? ev : 0.0f;
+                Z += lg[u];
+                sx = __builtin_fmaf(xv[u], lg[u], sx);
+            }
+            red[512 + threadIdx.x] = Z;
+            red[1024 + threadIdx.x] = sx;
+            __syncthreads();
+            Z = sg_redsum<NT>(red + 512, c);
+            const float mu = sg_redsum<NT>(red + 1024, c) / Z;
+            float sg = 0.0f;
+#pragma unroll
+            for (int u = 0; u < RG; u++) { const float dlt = xv[u] - mu; sg = __builtin_fmaf(dlt * dlt, lg[u], sg); }
+            red[threadIdx.x] = sg;                               // red[0 .. NT): every thread has read its maxima (the barrier above)
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int C = p.N, ch = n0c + c;
+                const float sigma = sqrtf(fmaxf(sg_redsum<NT>(red, c) / Z, 1e-10f));
+                p.pool[(size_t)s * 2 * C + ch] = mu * p.bn_s[ch] + p.bn_b[ch];
+                p.pool[(size_t)s * 2 * C + C + ch] = sigma * p.bn_s[C + ch] + p.bn_b[C + ch];
+            }
+        }
+    }
+}
+
+// ---- the two places without a GEMM in front: relu(mask(Y) * sigmoid(z)) of a Jasper block without residual, then -----------------------------
+//   ST_DW     the next block's first depthwise conv (block 0 -> block 1)
+//   ST_STATS  masked mean / std over time of the encoder output (:392-410; block 4 -> pooling)
+// grid (C / 64, S), 512 threads; X (bf16, masked) is written in both.
+template <int MODE>
+__global__ __launch_bounds__(512) void k_spk_tile(SpkTileParams p) {
+    constexpr int NT = 512;
+    __shared__ __attribute__((aligned(16))) float stage[SG_STAGE_FLOATS + 1024];
+    float *red = stage + SG_STAGE_FLOATS;
+    const int s = blockIdx.y, n0c = blockIdx.x * 64, L = p.lens[s];
+    const size_t m0 = (size_t)s * SG_BM;
+    sg_combine<false, NT>(stage, p.y_in + m0 * p.C + n0c, p.C, p.z + (size_t)s * p.C + n0c, L, p.x_out + m0 * p.C + n0c, p.C);
+    __syncthreads();
+    if (MODE == ST_DW) {
+        sg_dw<NT>(stage, p.dw_w + n0c, p.dw_k, p.C, L, p.a_out + m0 * p.lda_out + n0c, p.lda_out);
+    } else {
+        constexpr int RG = SG_BM / (NT / 64);
+        const int c = threadIdx.x & 63, t0 = (threadIdx.x >> 6) * RG;
+        red[threadIdx.x] = sg_colsum_partial<NT>(stage, L);
+        __syncthreads();
+        const float inv = 1.0f / (float)L, m = sg_redsum<NT>(red, c) * inv;
+        float v = 0.0f;
+#pragma unroll
+        for (int u = 0; u < RG; u++) { const float dlt = stage[(t0 + u) * SG_SLD + c] - m; v += (t0 + u < L) ? dlt * dlt : 0.0f; }
+        red[512 + threadIdx.x] = v;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const float var = fminf(fmaxf(sg_redsum<NT>(red + 512, c) * inv, 1e-10f), 1e30f);
+            p.mean[(size_t)s * p.stat_ld + n0c + c] = m;
+            p.stdv[(size_t)s * p.stat_ld + n0c + c] = sqrtf(var);
+        }
+    }
+}
+
+// ---- front of the encoder: per-feature normalisation (src/diarize_audio.cpp:182-199) + block 0's depthwise conv (k = 3) in one launch --------
+// Rounds 1-5: k_diar_featnorm (80 threads per segment walking 150 frames three times in double: 70 us for 96 segments) + k_spk_depthwise (20 us).
+// Here one workgroup per sub-segment holds the 150 x 80 log-mel tile in LDS: mean and Bessel-corrected std in double as the reference (six partial
+// sums of 25 frames each per feature: double sums of floats of this range are exact, so the grouping does not show), the normalisation with the
+// reference's operation order, then the masked depthwise conv straight into the first GEMM's bf16 A operand [160][128] (channels 80 .. 127 = 0).
+constexpr int SF_P = 81;                                       // floats per staged mel row
+__global__ __launch_bounds__(512) void k_spk_front(const float *mel, int cpitch, const float *dw_w, const int *lens, bf16_t *a_out, int lda_out) {
+    __shared__ float tile[SPK_T * SF_P];
+    __shared__ double dred[6 * DIAR_NMEL];
+    __shared__ float s_mean[DIAR_NMEL], s_inv[DIAR_NMEL];
+    const int s = blockIdx.x, L = lens[s];
+    const float *ms = mel + (size_t)s * SPK_T * cpitch;
+    for (int e = threadIdx.x; e < SPK_T * DIAR_NMEL; e += 512) {
+        const int t = e / DIAR_NMEL, c = e - t * DIAR_NMEL;
+        tile[t * SF_P + c] = ms[(size_t)t * cpitch + c];        // frames >= 150 are zeros (k_diar_logmel)
+    }
+    __syncthreads();
+    const int c = threadIdx.x % DIAR_NMEL, g = threadIdx.x / DIAR_NMEL;          // 480 threads: 6 groups of 25 frames
+    constexpr int n_eff = SPK_TVALID, denom = n_eff - 1;
+    if (g < 6) {
+        double sum = 0.0;
+        for (int u = 0; u < 25; u++) sum += (double)tile[(g * 25 + u) * SF_P + c];
+        dred[g * DIAR_NMEL + c] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < DIAR_NMEL) {
+        double sum = 0.0;
+        for (int k = 0; k < 6; k++) sum += dred[k * DIAR_NMEL + threadIdx.x];
+        s_mean[threadIdx.x] = (float)(sum / n_eff);
+    }
+    __syncthreads();
+    if (g < 6) {
+        const float mean = s_mean[c];
+        double var = 0.0;
+        for (int u = 0; u < 25; u++) { const float d = __fsub_rn(tile[(g * 25 + u) * SF_P + c], mean); var += (double)d * (double)d; }
+        dred[g * DIAR_NMEL + c] = var;
+    }
+    __syncthreads();
+    if (threadIdx.x < DIAR_NMEL) {
+        double var = 0.0;
+        for (int k = 0; k < 6; k++) var += dred[k * DIAR_NMEL + threadIdx.x];
+        s_inv[threadIdx.x] = 1.0f / __fadd_rn(sqrtf((float)(var / denom)), 1e-5f);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_eff * DIAR_NMEL; e += 512) {
+        const int t = e / DIAR_NMEL, cc = e - t * DIAR_NMEL;
+        tile[t * SF_P + cc] = __fmul_rn(__fsub_rn(tile[t * SF_P + cc], s_mean[cc]), s_inv[cc]);
+    }
+    __syncthreads();
+    // depthwise k = 3, 'same', input frames >= L read as zero, output frames >= L zero (k_spk_depthwise's fma chain)
+    bf16_t *as = a_out + (size_t)s * SPK_T * lda_out;
+    for (int e = threadIdx.x; e < SPK_T * 128; e += 512) {
+        const int t = e >> 7, cc = e & 127;
+        float acc = 0.0f;
+        if (cc < DIAR_NMEL && t < L) {
+            const float x0 = t >= 1 ? tile[(t - 1) * SF_P + cc] : 0.0f, x1 = tile[t * SF_P + cc], x2 = t + 1 < L ? tile[(t + 1) * SF_P + cc] : 0.0f;
+            acc = x0 * dw_w[cc];
+            acc = __builtin_fmaf(x1, dw_w[DIAR_NMEL + cc], acc);
+            acc = __builtin_fmaf(x2, dw_w[2 * DIAR_NMEL + cc], acc);
+        }
+        as[(size_t)t * lda_out + cc] = f32_to_bf16(acc);
+    }
+}
+int launch_spk_front(const float *mel, int cpitch, const float *dw_w, const int *lens, bf16_t *a_out, int lda_out, int S, hipStream_t st) {
+    if (S < 1 || cpitch < DIAR_NMEL || lda_out < 128 || !mel || !dw_w || !lens || !a_out) return -1;
+    hipLaunchKernelGGL(k_spk_front, dim3((unsigned)S), dim3(512), 0, st, mel, cpitch, dw_w, lens, a_out, lda_out);
+    return 0;
+}
+
+// ---- the small linears over the segments (SE gates, the constant part of the attention conv, the embedding layer): out[m][n] = W[n] . x[m] + b[n] ----
+// M = segments of the call (<= a few hundred), K up to 6 144.  k_encproj (kernels_decode.hip) gives such a product N / 16 x M / 64 workgroups however
+// long K is: 24 workgroups streamed the embedding layer's 4.7 MB (63 us), 16 the attention constant's (68 us as a dot-product kernel).  Here K is
+// also split over blockIdx.z; a slice's four waves split it once more (f32 MFMA 16 x 16 x 4, weights in pack_mfma_f32 order: a wave-load of a
+// 16 x 16 weight block is one contiguous KiB).  Z = 1 finishes in the kernel (bias, optional ReLU); Z > 1 leaves partial sums that k_spk_fc_reduce adds
+// in slice order.
+typedef __attribute__((ext_vector_type(4))) float fc_f32x4;
+__global__ __launch_bounds__(256) void k_spk_fc(const float *x, int ldx, const float *wpk, const float *bias, float *out, int M, int K, int N, int relu) {
+    __shared__ float red[4][4][64][4];
+    const int nt = blockIdx.x, b0 = blockIdx.y * 64, z = blockIdx.z, Z = gridDim.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+    const int KG = K / 16, per_wave = KG / (4 * Z), kg0 = (z * 4 + wave) * per_wave, kg1 = kg0 + per_wave;
+    const float4 *w = (const float4 *)wpk + (size_t)nt * KG * 64 + lane;
+    const float *xr[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        int m = b0 + mt * 16 + r;
+        if (m >= M) m = M - 1;
+        xr[mt] = x + (size_t)m * ldx + q * 4;
+    }
+    fc_f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) acc[mt] = (fc_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kg = kg0; kg < kg1; kg++) {
+        const float4 wv = w[(size_t)kg * 64];
+        float4 xv[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) xv[mt] = *(const float4 *)(xr[mt] + kg * 16);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[mt].x, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[mt].y, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[mt].z, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[mt].w, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) red[wave][mt][lane][j] = acc[mt][j];
+    __syncthreads();
+    const int mt = wave, m = b0 + mt * 16 + r;                  // wave mt finishes m-tile mt: lane (q, r) holds columns nt*16 + 4q .. +4 of row m
+    if (m < M) {
+        float4 o;
+        float *op = (float *)&o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = ((red[0][mt][lane][j] + red[1][mt][lane][j]) + red[2][mt][lane][j]) + red[3][mt][lane][j];
+            if (Z == 1) { v += bias[nt * 16 + q * 4 + j]; if (relu) v = fmaxf(v, 0.0f); }
+            op[j] = v;
+        }
+        *(float4 *)(out + ((size_t)z * M + m) * N + nt * 16 + q * 4) = o;
+    }
+}
+__global__ __launch_bounds__(256) void k_spk_fc_reduce(const float *part, const float *bias, float *out, int M, int N, int Z, int relu) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * N / 4) return;
+    const int n4 = (e % (N / 4)) * 4;
+    float4 a = *(const float4 *)(part + (size_t)e * 4);
+    for (int z = 1; z < Z; z++) {
+        const float4 b = *(const float4 *)(part + ((size_t)z * M * N) + (size_t)e * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float4 bb = *(const float4 *)(bias + n4);
+    a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    *(float4 *)(out + (size_t)e * 4) = a;
+}
+// K slices so that the launch has a few hundred workgroups and every wave at least one 16-deep group of its own
+int spk_fc_slices(int M, int K, int N) {
+    const int KG = K / 16, wgs = (N / 16) * ((M + 63) / 64);
+    int Z = 1;
+    if (K < 1024) return 1;          // a short K is not worth a second launch
+    while (Z < 16 && wgs * Z < 256 && KG % (8 * Z) == 0) Z *= 2;
+    return Z;
+}
+// part: scratch of at least Z * M * N floats (only touched when spk_fc_slices() > 1)
+int launch_spk_fc(const float *x, int ldx, const float *wpk, const float *bias, float *out, float *part, int M, int K, int N, int relu, hipStream_t st) {
+    if (M < 1 || N < 16 || N % 16 || K < 64 || K % 64 || ldx < K || ldx % 4 || !x || !wpk || !bias || !out) return -1;
+    const int Z = spk_fc_slices(M, K, N);
+    if (Z > 1 && !part) return -1;
+    hipLaunchKernelGGL(k_spk_fc, dim3((unsigned)(N / 16), (unsigned)((M + 63) / 64), (unsigned)Z), dim3(256), 0, st, x, ldx, wpk, bias, Z > 1 ? part : out, M, K, N, relu);
+    if (Z > 1) hipLaunchKernelGGL(k_spk_fc_reduce, dim3((unsigned)((M * N / 4 + 255) / 256)), dim3(256), 0, st, part, bias, out, M, N, Z, relu);
+    return 0;
+}
+
+// ---- device-resident input buffers of a call gathered into the side-car's staging buffer in ONE launch ------------------------------------------
+// (rounds 1-5: one hipMemcpyAsync per buffer -- 96 sub-segments = 96 copies in front of every embedding call, 64 in front of every VAD call)
+__global__ __launch_bounds__(256) void k_gather_audio(const GatherDesc *tab, char *dst) {
+    const GatherDesc g = tab[blockIdx.y];
+    const char *src = (const char *)g.src;
+    char *out = dst + g.dst_off;
+    const long long stride = (long long)gridDim.x * 256;
+    if ((((size_t)src | (size_t)out) & 15) == 0) {
+        const long long n16 = g.bytes >> 4;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) ((uint4 *)out)[i] = ((const uint4 *)src)[i];
+        for (long long i = (n16 << 4) + 2 * ((long long)blockIdx.x * 256 + threadIdx.x); i < g.bytes; i += 2 * stride) *(uint16_t *)(out + i) = *(const uint16_t *)(src + i);
+    } else {
+        for (long long i = 2 * ((long long)blockIdx.x * 256 + threadIdx.x); i < g.bytes; i += 2 * stride) *(uint16_t *)(out + i) = *(const uint16_t *)(src + i);
+    }
+}
+void launch_gather_audio(const GatherDesc *tab_dev, int B, long long max_bytes, char *dst, hipStream_t st) {
+    if (B < 1 || max_bytes < 1) return;
+    long long blocks = (max_bytes / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_gather_audio, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, st, tab_dev, dst);
+}
+
+void init_spk_kernel_attributes() {
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_DW>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_Y>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_ASP>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+}
+
+// host-side shape check: a hand-written kernel never sees operands its indexing does not cover
+const char *spk_gemm_check(const SpkGemmParams &p) {
+    if (p.S < 1 || p.N < SG_BN || p.N % SG_BN) return "N must be a positive multiple of 128";
+    if (p.K < 32 || p.K % 32 || p.lda < p.K || p.lda % 8) return "K must be a positive multiple of 32, lda >= K and 16-byte rows";
+    if (!p.A || !p.W || !p.bias || !p.lens) return "null operand";
+    if (p.mode == SG_DW && (!p.a_out || !p.dw_w || (p.dw_k != 3 && p.dw_k != 7 && p.dw_k != 11 && p.dw_k != 15) || p.lda_out < p.N)) return "SG_DW: a_out / taps";
+    if (p.mode == SG_Y && (!p.y_out || !p.colmean)) return "SG_Y: y_out / colmean";
+    if (p.mode == SG_RES && (!p.y_in || !p.z || !p.x_out || (p.dw_k > 1 && (!p.a_out || !p.dw_w || (p.dw_k != 7 && p.dw_k != 11 && p.dw_k != 15) || p.lda_out < p.N)))) return "SG_RES: y_in / z / x_out / taps";
+    if (p.mode == SG_ASP && (!p.x_in || !p.bn_s || !p.bn_b || !p.pool)) return "SG_ASP: x_in / bn / pool";
+    return nullptr;
+}
+int launch_spk_gemm(const SpkGemmParams &p, hipStream_t st) {
+    if (spk_gemm_check(p)) return -1;
+    const dim3 grid((unsigned)(p.S * (p.N / SG_BN))), block(SG_THREADS);
+    switch (p.mode) {
+    case SG_DW: hipLaunchKernelGGL(k_spk_gemm<SG_DW>, grid, block, SG_LDS, st, p); break;
+    case SG_Y: hipLaunchKernelGGL(k_spk_gemm<SG_Y>, grid, block, SG_LDS, st, p); break;
+    case SG_RES: hipLaunchKernelGGL(k_spk_gemm<SG_RES>, grid, block, SG_LDS, st, p); break;
+    case SG_ASP: hipLaunchKernelGGL(k_spk_gemm<SG_ASP>, grid, block, SG_LDS, st, p); break;
+    default: return -1;
+    }
+    return 0;
+}
+int launch_spk_tile(const SpkTileParams &p, hipStream_t st) {
+    if (p.S < 1 || p.C < 64 || p.C % 64 || !p.y_in || !p.z || !p.x_out || !p.lens) return -1;
+    const dim3 grid((unsigned)(p.C / 64), (unsigned)p.S), block(512);
+    if (p.mode == ST_DW) {
+        if (!p.a_out || !p.dw_w || (p.dw_k != 7 && p.dw_k != 11 && p.dw_k != 15 && p.dw_k != 3) || p.lda_out < p.C) return -1;
+        hipLaunchKernelGGL(k_spk_tile<ST_DW>, grid, block, 0, st, p);
+    } else if (p.mode == ST_STATS) {
+        if (!p.mean || !p.stdv || p.stat_ld < p.C) return -1;
+        hipLaunchKernelGGL(k_spk_tile<ST_STATS>, grid, block, 0, st, p);
+    } else return -1;
+    return 0;
+}
+
+}  // namespace nasr

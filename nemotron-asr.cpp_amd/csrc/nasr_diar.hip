@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -20,6 +21,10 @@ using namespace nasr;
 
 void api_lock_shared();
 void api_unlock_shared();
+namespace nasr_eng {
+void api_capture_begin();            // shared -> exclusive: stream capture is broken by what other threads do meanwhile (nasr_engine_priv.h)
+void api_capture_end();
+}
 namespace {
 struct Guard { Guard() { api_lock_shared(); } ~Guard() { api_unlock_shared(); } };
 
@@ -69,6 +74,14 @@ struct nasr_diar {
     float *s_mel = nullptr, *X0 = nullptr, *X1 = nullptr, *Y = nullptr, *R = nullptr, *se_z = nullptr, *st_mean = nullptr, *st_std = nullptr;
     float *att_c = nullptr, *att_g = nullptr, *pool = nullptr, *emb = nullptr, *se_h = nullptr;
     void *A = nullptr; int *s_lens = nullptr; long long *s_off = nullptr;
+    // segment-tile path (bf16 engine, kernels_spk.hip): A operands ping-pong [M][1024], block outputs [M][1024] x 2, encoder output [M][3072], all bf16
+    bf16_t *sA[2] = {nullptr, nullptr}, *sX[2] = {nullptr, nullptr}, *sX4 = nullptr;
+    float *st_ms = nullptr, *a1ms_w = nullptr, *fc_part = nullptr;      // [S][2 C] masked mean ; std, the mean / std thirds of the attention conv (pack_mfma_f32), split-K scratch
+    // one hipGraph per (segments in the call, sample type): the ~45 launches of an embedding call replayed as one (the pointers inside are the
+    // engine's own persistent buffers; the staged audio buffer is part of the key's validity: spk_graph_audio)
+    std::map<std::pair<int, uint32_t>, hipGraphExec_t> spk_graphs;
+    const void *spk_graph_audio = nullptr;
+    bool spk_use_graph = true;       // NASR_DIAR_NO_GRAPH=1: eager launches (A/B, debugging)
     // scratch
     char *audio = nullptr; size_t audio_cap = 0;        // staged input samples (float or s16), capacities in bytes
     char *pin_audio = nullptr; size_t pin_audio_cap = 0;
@@ -77,6 +90,7 @@ struct nasr_diar {
     int *win_row = nullptr; size_t win_cap = 0;
     float *prob = nullptr; size_t prob_cap = 0;
     char *pin = nullptr; size_t pin_cap = 0;             // pinned staging for descriptors / results
+    GatherDesc *gather_dev = nullptr, *gather_pin = nullptr; size_t gather_cap = 0;   // device-resident inputs: (source, destination, bytes) per buffer
 };
 
 namespace {
@@ -269,7 +283,7 @@ int stage_audio(nasr_diar *d, const float *const *audio, const int32_t *n, int B
     const size_t esz = (flags & NASR_FLAG_AUDIO_S16) ? sizeof(int16_t) : sizeof(float);
     size_t total = 0;
     base.resize(B);
-    for (int b = 0; b < B; b++) { base[b] = (long long)total; total += (size_t)std::max(n[b], 0); }
+    for (int b = 0; b < B; b++) { base[b] = (long long)total; total += ((size_t)std::max(n[b], 0) + 7) & ~(size_t)7; }     // every buffer starts on 16 bytes
     if (total * esz > d->audio_cap) {
         DCHK(hipStreamSynchronize(d->st));
         if (d->audio) hipFree(d->audio);
@@ -278,8 +292,25 @@ int stage_audio(nasr_diar *d, const float *const *audio, const int32_t *n, int B
         DCHK(hipMalloc((void **)&d->audio, d->audio_cap));
     }
     if (on_device) {
-        for (int b = 0; b < B; b++)
-            if (n[b] > 0) DCHK(hipMemcpyAsync(d->audio + (size_t)base[b] * esz, audio[b], (size_t)n[b] * esz, hipMemcpyDeviceToDevice, d->st));
+        // one table upload + ONE gather launch (rounds 1-5: a hipMemcpyAsync per buffer)
+        if ((size_t)B > d->gather_cap) {
+            DCHK(hipStreamSynchronize(d->st));
+            if (d->gather_dev) hipFree(d->gather_dev);
+            if (d->gather_pin) hipHostFree(d->gather_pin);
+            d->gather_dev = nullptr; d->gather_pin = nullptr;
+            d->gather_cap = (size_t)B + 64;
+            DCHK(hipMalloc((void **)&d->gather_dev, d->gather_cap * sizeof(GatherDesc)));
+            DCHK(hipHostMalloc((void **)&d->gather_pin, d->gather_cap * sizeof(GatherDesc), hipHostMallocDefault));
+        }
+        long long max_bytes = 0;
+        for (int b = 0; b < B; b++) {                   // every entry point of this file ends with a stream synchronise: the pinned table is free again
+            d->gather_pin[b].src = audio[b];
+            d->gather_pin[b].dst_off = base[b] * (long long)esz;
+            d->gather_pin[b].bytes = (long long)std::max(n[b], 0) * (long long)esz;
+            max_bytes = std::max(max_bytes, d->gather_pin[b].bytes);
+        }
+        DCHK(hipMemcpyAsync(d->gather_dev, d->gather_pin, (size_t)B * sizeof(GatherDesc), hipMemcpyHostToDevice, d->st));
+        launch_gather_audio(d->gather_dev, B, max_bytes, d->audio, d->st);
     } else {
         // host hand-over: gather into one pinned block, one H2D copy (pageable sources would be staged piecewise by the runtime)
         if (total * esz > d->pin_audio_cap) {
@@ -309,6 +340,7 @@ static void diar_destroy_impl(nasr_diar *d) {
     if (!d) return;
     hipSetDevice(d->device);
     if (d->st) hipStreamSynchronize(d->st);
+    for (auto &kv : d->spk_graphs) hipGraphExecDestroy(kv.second);
     for (void *p : d->allocs) hipFree(p);
     if (d->audio) hipFree(d->audio);
     if (d->fr_desc) hipFree(d->fr_desc);
@@ -317,6 +349,8 @@ static void diar_destroy_impl(nasr_diar *d) {
     if (d->prob) hipFree(d->prob);
     if (d->pin) hipHostFree(d->pin);
     if (d->pin_audio) hipHostFree(d->pin_audio);
+    if (d->gather_dev) hipFree(d->gather_dev);
+    if (d->gather_pin) hipHostFree(d->gather_pin);
     if (d->st && !d->st_borrowed) hipStreamDestroy(d->st);
     else if (d->st && d->st_lent) lent_stream_release(d->st);
     delete d;
@@ -380,6 +414,8 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const
     if (!d->has_vad && !d->has_spk) { delete d; return failf("no 'vad.*' or 'spk.*' tensors among the %d weights", n_weights); }
     if (hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking) != hipSuccess) { delete d; return failf("hipStreamCreate failed"); }
     init_diar_kernel_attributes();
+    init_spk_kernel_attributes();
+    if (const char *ng = getenv("NASR_DIAR_NO_GRAPH")) d->spk_use_graph = !(ng[0] && ng[0] != '0');
     d->pin_cap = (size_t)(d->max_windows + d->max_segments * SPK_EMB + 4096) * 16;
     if (hipHostMalloc((void **)&d->pin, d->pin_cap, hipHostMallocDefault) != hipSuccess) { diar_destroy_impl(d); return failf("hipHostMalloc failed"); }
     int rc = 0;
@@ -563,7 +599,15 @@ static int nasr_diar_load_spk(nasr_diar *d) {
             const auto *pw = get(d, pre + ".mconv." + std::to_string(5 * s + 1) + ".conv.weight", (size_t)t.cout * cin);
             std::vector<float> sc, bi;
             if (!dw || !pw || fold_bn(d, pre + ".mconv." + std::to_string(5 * s + 2), t.cout, 1e-3f, sc, bi)) return -1;   // encoder BN eps 1e-3 (:36-41)
-            if (upload(d, *dw, &ss.dw) || upload_gemm_weight(d, *pw, &sc, t.cout, cin, cin_pad, &ss.pw) || upload(d, bi, &ss.bias)) return -1;
+            // bf16 engine (segment tiles): a depthwise conv of kernel 1 is a per-channel scaling of the pointwise conv's input (:263-267) -- folded into
+            // the pointwise weights, so that block 4's GEMM reads the masked bf16 output of block 3 directly
+            std::vector<float> pwf;
+            if (d->bf16 && t.kernel == 1) {
+                pwf = *pw;
+                for (int o = 0; o < t.cout; o++)
+                    for (int i = 0; i < cin; i++) pwf[(size_t)o * cin + i] *= (*dw)[i];
+            }
+            if (upload(d, *dw, &ss.dw) || upload_gemm_weight(d, pwf.empty() ? *pw : pwf, &sc, t.cout, cin, cin_pad, &ss.pw) || upload(d, bi, &ss.bias)) return -1;
         }
         if (t.residual) {
             nasr_diar::SpkSub &rs = blk.res;
@@ -592,6 +636,9 @@ static int nasr_diar_load_spk(nasr_diar *d) {
     if (fold_bn(d, dp + "._pooling.attention_layer.0.bn", A, 1e-5f, as, ab) || fold_bn(d, dp + ".emb_layers.0.0", 2 * C, 1e-5f, es, ebn)) return -1;   // decoder BN eps 1e-5
     std::vector<float> a1x((size_t)A * C);                     // the x third of the attention conv: a GEMM; the rest: k_spk_att_const
     for (int a = 0; a < A; a++) memcpy(&a1x[(size_t)a * C], &(*a1w)[(size_t)a * 3 * C], (size_t)C * sizeof(float));
+    std::vector<float> a1ms((size_t)A * 2 * C);                // the mean / std thirds: one [A][2 C] linear over the segments (segment-tile path)
+    for (int a = 0; a < A; a++) memcpy(&a1ms[(size_t)a * 2 * C], &(*a1w)[(size_t)a * 3 * C + C], (size_t)2 * C * sizeof(float));
+    if (d->bf16 && upload(d, pack_mfma_f32(a1ms, A, 2 * C), &d->a1ms_w)) return -1;
     std::vector<float> zeros((size_t)std::max(C, 1024), 0.0f);
     if (upload_gemm_weight(d, a1x, nullptr, A, C, C, &d->a1x_w) || upload(d, *a1w, &d->a1_w) || upload(d, *a1b, &d->a1_b) ||
         upload(d, as, &d->a_bn_s) || upload(d, ab, &d->a_bn_b) || upload(d, zeros, &d->zero_bias) ||
@@ -606,6 +653,9 @@ static int nasr_diar_load_spk(nasr_diar *d) {
         dalloc(d, &d->pool, S * 2 * C) || dalloc(d, &d->emb, S * SPK_EMB) || dalloc(d, &d->s_lens, S) || dalloc(d, &d->s_off, S))
         return -1;
     d->A = a;
+    if (d->bf16 && (dalloc(d, &d->sA[0], M * 1024) || dalloc(d, &d->sA[1], M * 1024) || dalloc(d, &d->sX[0], M * 1024) || dalloc(d, &d->sX[1], M * 1024) ||
+                    dalloc(d, &d->sX4, M * C) || dalloc(d, &d->st_ms, S * 2 * C) || dalloc(d, &d->fc_part, 16 * S * 512)))
+        return -1;
     return 0;
 }
 
@@ -618,6 +668,96 @@ static void spk_gemm(nasr_diar *d, const void *A, int lda, const void *W, int M,
     g.coresident = 1;        // M = 160 rows per sub-segment: several tiles per CU, two workgroups per CU overlap fill / multiply / store (96 segments: 3.66 -> 3.41 ms per call)
     if (d->bf16) launch_gemm_bf16(g, d->st);
     else launch_gemm_f32(g, d->st);
+}
+
+// SE gate pre-activation (:303-315): z = fc2 . relu(fc1 . mean) over the segments (the sigmoid is applied where the gate is used)
+static int spk_se(nasr_diar *d, nasr_diar::SpkBlock &blk, const float *mean, int St) {
+    if (launch_spk_fc(mean, blk.cout, blk.fc1, d->zero_bias, d->se_h, d->fc_part, St, blk.cout, blk.cout / 8, 1, d->st) ||
+        launch_spk_fc(d->se_h, blk.cout / 8, blk.fc2, d->zero_bias, d->se_z, d->fc_part, St, blk.cout / 8, blk.cout, 0, d->st))
+        return failf("TitaNet-L SE gate: bad operands");
+    return 0;
+}
+
+// The bf16 engine's encoder + pooling on SEGMENT TILES (round 6, kernels_spk.hip): every pointwise conv is a GEMM whose tile is one sub-segment x 256
+// channels, and the depthwise conv of the NEXT sub-block, the SE mean, the block's combine and the attentive pooling run in the epilogues.
+// s_mel / s_lens are set; leaves d->pool.  ~40 launches, no f32 activation in memory except each block's Y.
+static int spk_embed_segment_tiles(nasr_diar *d, int St) {
+    float *mean = d->se_z + (size_t)d->max_segments * SPK_C;
+    int a = 0, xb = 0;                                            // sA[a]: the A operand the next GEMM reads; sX[xb]: the last block output
+    auto gemm = [&](SpkGemmParams &g) -> int {
+        g.S = St; g.lens = d->s_lens;
+        if (const char *why = spk_gemm_check(g)) return failf("TitaNet-L segment GEMM (mode %d, N %d, K %d): %s", g.mode, g.N, g.K, why);
+        return launch_spk_gemm(g, d->st);
+    };
+    {   // block 0 (:28): depthwise k = 3 on the 80 mel channels (K padded to 128), pointwise -> Y, SE, relu(Y * gate) -> X + block 1's first depthwise conv
+        nasr_diar::SpkBlock &blk = d->spk[0];
+        nasr_diar::SpkSub &ss = blk.sub[0];
+        if (ss.kernel != 3 || ss.cin != DIAR_NMEL || launch_spk_front(d->s_mel, 96, ss.dw, d->s_lens, d->sA[a], ss.cin_pad, St, d->st))
+            return failf("TitaNet-L front kernel: block 0 is not the 80 -> 1024, k = 3 sub-block of src/diarize_spk.cpp:28");
+        SpkGemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = d->sA[a]; g.lda = ss.cin_pad; g.W = (const bf16_t *)ss.pw; g.N = ss.cout; g.K = ss.cin_pad; g.bias = ss.bias;
+        g.mode = SG_Y; g.y_out = d->Y; g.colmean = mean;
+        if (gemm(g)) return -1;
+        if (spk_se(d, blk, mean, St)) return -1;
+        SpkTileParams t;
+        memset(&t, 0, sizeof(t));
+        t.y_in = d->Y; t.z = d->se_z; t.lens = d->s_lens; t.S = St; t.C = blk.cout; t.mode = ST_DW; t.x_out = d->sX[xb];
+        t.dw_w = d->spk[1].sub[0].dw; t.dw_k = d->spk[1].sub[0].kernel; t.a_out = d->sA[a ^ 1]; t.lda_out = d->spk[1].sub[0].cin_pad;
+        if (launch_spk_tile(t, d->st)) return failf("TitaNet-L block 0 tile kernel: bad operands");
+        a ^= 1;
+    }
+    for (int b = 1; b <= 3; b++) {                                // Jasper blocks with residual (:351-383)
+        nasr_diar::SpkBlock &blk = d->spk[b];
+        for (int r = 0; r < blk.repeat; r++) {
+            nasr_diar::SpkSub &ss = blk.sub[r];
+            SpkGemmParams g;
+            memset(&g, 0, sizeof(g));
+            g.A = d->sA[a]; g.lda = ss.cin_pad; g.W = (const bf16_t *)ss.pw; g.N = ss.cout; g.K = ss.cin_pad; g.bias = ss.bias;
+            if (r + 1 < blk.repeat) {
+                g.mode = SG_DW; g.dw_w = blk.sub[r + 1].dw; g.dw_k = blk.sub[r + 1].kernel; g.a_out = d->sA[a ^ 1]; g.lda_out = blk.sub[r + 1].cin_pad;
+            } else {
+                g.mode = SG_Y; g.y_out = d->Y; g.colmean = mean;
+            }
+            if (gemm(g)) return -1;
+            if (r + 1 < blk.repeat) a ^= 1;
+        }
+        if (spk_se(d, blk, mean, St)) return -1;
+        SpkGemmParams g;                                          // residual 1 x 1 conv + combine (+ the next block's first depthwise conv)
+        memset(&g, 0, sizeof(g));
+        g.A = d->sX[xb]; g.lda = blk.cin; g.W = (const bf16_t *)blk.res.pw; g.N = blk.cout; g.K = blk.cin; g.bias = blk.res.bias;
+        g.mode = SG_RES; g.y_in = d->Y; g.z = d->se_z; g.x_out = d->sX[xb ^ 1];
+        nasr_diar::SpkSub &nx = d->spk[b + 1].sub[0];
+        if (nx.kernel > 1) { g.dw_w = nx.dw; g.dw_k = nx.kernel; g.a_out = d->sA[a ^ 1]; g.lda_out = nx.cin_pad; }
+        if (gemm(g)) return -1;
+        xb ^= 1;
+        if (nx.kernel > 1) a ^= 1;
+    }
+    {   // block 4 (:34): kernel 1 (folded into the weights at load), 1024 -> 3072, SE, relu(Y * gate) -> X4 + masked statistics (:392-410)
+        nasr_diar::SpkBlock &blk = d->spk[4];
+        nasr_diar::SpkSub &ss = blk.sub[0];
+        SpkGemmParams g;
+        memset(&g, 0, sizeof(g));
+        g.A = d->sX[xb]; g.lda = ss.cin_pad; g.W = (const bf16_t *)ss.pw; g.N = ss.cout; g.K = ss.cin_pad; g.bias = ss.bias;
+        g.mode = SG_Y; g.y_out = d->Y; g.colmean = mean;
+        if (gemm(g)) return -1;
+        if (spk_se(d, blk, mean, St)) return -1;
+        SpkTileParams t;
+        memset(&t, 0, sizeof(t));
+        t.y_in = d->Y; t.z = d->se_z; t.lens = d->s_lens; t.S = St; t.C = blk.cout; t.mode = ST_STATS; t.x_out = d->sX4;
+        t.mean = d->st_ms; t.stdv = d->st_ms + SPK_C; t.stat_ld = 2 * SPK_C;
+        if (launch_spk_tile(t, d->st)) return failf("TitaNet-L block 4 tile kernel: bad operands");
+    }
+    // attentive statistics pooling (:384-500): the x third of the attention conv is a GEMM on X4, the second conv's logits never leave LDS
+    const int M = St * SPK_T;
+    if (launch_spk_fc(d->st_ms, 2 * SPK_C, d->a1ms_w, d->a1_b, d->att_c, d->fc_part, St, 2 * SPK_C, SPK_ATT, 0, d->st)) return failf("TitaNet-L attention constant: bad operands");
+    spk_gemm(d, d->sX4, SPK_C, d->a1x_w, M, SPK_ATT, SPK_C, d->zero_bias, false, d->att_g);
+    launch_spk_att_post(d->att_g, d->att_c, d->a_bn_s, d->a_bn_b, d->A, 1, SPK_ATT, St, d->st);
+    SpkGemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t *)d->A; g.lda = SPK_ATT; g.W = (const bf16_t *)d->a2_w; g.N = SPK_C; g.K = SPK_ATT; g.bias = d->a2_b;
+    g.mode = SG_ASP; g.x_in = d->sX4; g.bn_s = d->e_bn_s; g.bn_b = d->e_bn_b; g.pool = d->pool;
+    return gemm(g);
 }
 
 // spk_session_run_chunk (src/diarize_spk.cpp:601-626) for S sub-segments in one launch sequence
@@ -647,6 +787,42 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         mp.win_off = d->s_off; mp.n_win = SPK_SEGMENT; mp.T_pad = SPK_T; mp.t_valid = SPK_TVALID;
         mp.cpitch = 96; mp.mel = d->s_mel; mp.window = d->window; mp.fbT = d->spk_fbT; mp.fb_band = d->spk_band;
         mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+        if (d->bf16) {
+            // front end + encoder + pooling + embedding layer: eager, or one graph per (St, sample type) replayed
+            auto enqueue = [&]() -> int {
+                launch_diar_logmel(mp, St, false, d->st);               // the per-feature normalisation (:578) is the first step of k_spk_front
+                if (spk_embed_segment_tiles(d, St)) return -1;
+                if (launch_spk_fc(d->pool, 2 * SPK_C, d->emb_w, d->emb_b, d->emb, d->fc_part, St, 2 * SPK_C, SPK_EMB, 0, d->st))      // [S][6144] x [192][6144]^T, always f32
+                    return failf("TitaNet-L embedding layer: bad operands");
+                return 0;
+            };
+            if (!d->spk_use_graph) {
+                if (enqueue()) return -1;
+            } else {
+                if (d->spk_graph_audio != (const void *)d->audio) {     // the staging buffer was reallocated: every captured pointer to it is stale
+                    for (auto &kv : d->spk_graphs) hipGraphExecDestroy(kv.second);
+                    d->spk_graphs.clear();
+                    d->spk_graph_audio = d->audio;
+                }
+                const std::pair<int, uint32_t> key(St, flags & NASR_FLAG_AUDIO_S16);
+                auto it = d->spk_graphs.find(key);
+                if (it == d->spk_graphs.end()) {
+                    hipGraph_t graph = nullptr;
+                    hipGraphExec_t exec = nullptr;
+                    nasr_eng::api_capture_begin();
+                    hipError_t be = hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal);
+                    int rc = be == hipSuccess ? enqueue() : -1;
+                    hipError_t ce = be == hipSuccess ? hipStreamEndCapture(d->st, &graph) : be;
+                    nasr_eng::api_capture_end();
+                    if (rc || ce != hipSuccess) { if (graph) hipGraphDestroy(graph); return rc ? -1 : failf("TitaNet-L graph capture failed: %s", hipGetErrorString(ce)); }
+                    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                    hipGraphDestroy(graph);
+                    if (ie != hipSuccess) return failf("hipGraphInstantiate (TitaNet-L) failed: %s", hipGetErrorString(ie));
+                    it = d->spk_graphs.emplace(key, exec).first;
+                }
+                DCHK(hipGraphLaunch(it->second, d->st));
+            }
+        } else {
         launch_diar_logmel(mp, St, true, d->st);                        // per-feature normalisation on (:578)
         const float *x = d->s_mel;
         int x_pitch = 96;
@@ -691,6 +867,7 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         spk_gemm(d, d->A, SPK_ATT, d->a2_w, M, SPK_C, SPK_ATT, d->a2_b, false, d->Y);                   // attention logits
         launch_spk_asp(x, d->Y, SPK_C, d->s_lens, d->e_bn_s, d->e_bn_b, d->pool, St, d->st);
         launch_encproj(d->pool, d->emb_w, d->emb_b, d->emb, St, 2 * SPK_C, SPK_EMB, d->st);      // [S][6144] x [192][6144]^T, always f32
+        }
         float *h_emb = (float *)(d->pin + (size_t)d->max_segments * (sizeof(long long) + sizeof(int)));
         DCHK(hipMemcpyAsync(h_emb, d->emb, (size_t)St * SPK_EMB * sizeof(float), hipMemcpyDeviceToHost, d->st));
         DCHK(hipStreamSynchronize(d->st));

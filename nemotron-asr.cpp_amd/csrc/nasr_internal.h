@@ -340,6 +340,42 @@ void launch_vad_marblenet_f16(const VadNet &net, const float *shared, const floa
                               float *prob, int W, hipStream_t st);        // ... on the f16 MFMA, IEEE-half planes (pw16 = half tiles)
 void init_diar_kernel_attributes();
 
+// TitaNet-L on segment tiles (round 6, kernels_spk.hip; the bf16 engine's path): the pointwise convs as GEMMs whose tile is ONE sub-segment
+// (160 rows) x 256 channels, with what follows the conv along the time axis done in the epilogue while the tile is in LDS
+enum { SG_DW = 0, SG_Y = 1, SG_RES = 2, SG_ASP = 3 };
+struct SpkGemmParams {
+    const bf16_t *A; int lda;        // [S * 160][lda] bf16, rows >= lens masked to zero by whoever wrote them
+    const bf16_t *W;                 // packed 16 x 32 tiles [N / 16][K / 32] (launch_pack_weight_bf16), folded BN scale inside
+    int S, N, K, mode;
+    const float *bias;               // [N] folded BN bias / conv bias
+    const int *lens;                 // [S] valid frames
+    const float *dw_w; int dw_k;     // SG_DW / SG_RES: taps [dw_k][N] of the NEXT depthwise conv (SG_RES: dw_k <= 1 = none)
+    bf16_t *a_out; int lda_out;      // ... its output = the next GEMM's A operand
+    float *y_out, *colmean;          // SG_Y: [S * 160][N] f32, [S][N] masked mean over time (SE gate input)
+    const float *y_in, *z;           // SG_RES: Y of the block, SE gate pre-activation [S][N]
+    bf16_t *x_out;                   // SG_RES: the block's output, masked, [S * 160][N]
+    const bf16_t *x_in;              // SG_ASP: encoder output [S * 160][N]
+    const float *bn_s, *bn_b; float *pool;   // SG_ASP: folded BN of the embedding layer [2 N], pool [S][2 N]
+};
+int launch_spk_gemm(const SpkGemmParams &p, hipStream_t st);      // -1: operands the kernel's indexing does not cover (nothing launched)
+const char *spk_gemm_check(const SpkGemmParams &p);
+enum { ST_DW = 0, ST_STATS = 1 };
+struct SpkTileParams {               // relu(mask(Y) * sigmoid(z)) of a block without residual -> X bf16, then the next depthwise conv or the masked statistics
+    const float *y_in, *z; const int *lens; int S, C, mode;
+    bf16_t *x_out;
+    const float *dw_w; int dw_k; bf16_t *a_out; int lda_out;
+    float *mean, *stdv; int stat_ld;     // ST_STATS: [S][stat_ld] each (the two may be halves of one [S][2 C] buffer: stat_ld = 2 C)
+};
+int launch_spk_tile(const SpkTileParams &p, hipStream_t st);
+void init_spk_kernel_attributes();
+struct GatherDesc { const void *src; long long dst_off, bytes; };          // bytes: a multiple of 2 (s16 or f32 samples)
+void launch_gather_audio(const GatherDesc *tab_dev, int B, long long max_bytes, char *dst, hipStream_t st);
+// per-feature normalisation + block 0's depthwise conv (k = 3): log-mel [S][160][cpitch] -> bf16 A operand [S * 160][lda_out >= 128]
+int launch_spk_front(const float *mel, int cpitch, const float *dw_w, const int *lens, bf16_t *a_out, int lda_out, int S, hipStream_t st);
+// out[m][n] = W[n] . x[m] + b[n] (optional ReLU) for a few rows and long K: f32 MFMA, weights in pack_mfma_f32 order, K split over workgroups
+int spk_fc_slices(int M, int K, int N);
+int launch_spk_fc(const float *x, int ldx, const float *wpk, const float *bias, float *out, float *part, int M, int K, int N, int relu, hipStream_t st);
+
 // TitaNet-L pieces (src/diarize_spk.cpp:320-515); activations [S * 160][C] f32, channels innermost
 void launch_spk_depthwise(const float *x, int x_pitch, const float *w, int kernel, int C, int Cpad, const int *lens, void *a_out,
                           int out_bf16, int S, hipStream_t st);               // masked 'same' depthwise conv -> GEMM A operand
