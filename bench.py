@@ -495,8 +495,10 @@ def main():
     # the CPU baseline's threads: one per core, neighbours close (before torch / the oracle load an OpenMP runtime, which reads these once)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
-    # OMP_WAIT_POLICY is left to the runtime's default (round 5 set "passive", which slows an oracle made of many short parallel regions
-    # and moved the baseline in the GPU's favour: advisor, round 5); the entry reports whatever the environment says
+    # the CPU baseline's team is one thread per CPU the box gives the job, so its threads may spin between the oracle's many short parallel regions
+    # (round 5 ran it "passive", which slows exactly that and moved the baseline in the GPU's favour: advisor, round 5; oracle/binding.py's own
+    # default stays passive for the test suite, where teams can be oversubscribed); the entry reports what was in force
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -30,6 +30,12 @@ namespace nasr {
 typedef __attribute__((ext_vector_type(8))) __bf16 sg_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float sg_f32x4;
 
+#ifdef SG_STAMPS
+#define SGSTAMP(i) do { if (threadIdx.x == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SGSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int SG_BM = SPK_T, SG_BN = 128, SG_MT = 5, SG_NT = 4, SG_NW = 4, SG_THREADS = 64 * SG_NW;
@@ -160,6 +166,7 @@ template <int MODE>
 __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     constexpr int NT = SG_THREADS;
     extern __shared__ __attribute__((aligned(16))) char ring[];
+    SGSTAMP(0);
     const int n_groups = p.N / SG_BN, nblk = gridDim.x;
     int id = blockIdx.x;
     {   // an XCD takes a contiguous run of tiles: the column tiles of a segment share its A panel in that XCD's L2
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     const int L = p.lens[s];
     int slot = 0;
     for (int i = 0; i < KT; i++) {
+        if (i == 1) SGSTAMP(1);
         const int left = KT - 1 - i;                            // chunks allowed to stay in flight: min(left, P - 1)
         if (left >= SG_P - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA * (SG_P - 1)) : "memory");
         else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA) : "memory");
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
         slot = slot + 1 == SG_NS ? 0 : slot + 1;
     }
 
+    SGSTAMP(2);
     // ---- epilogue: two column halves of 64 through stage[160][68] ----
     float *stage = (float *)ring, *red = stage + SG_STAGE_FLOATS;
     for (int cq = 0; cq < SG_BN / 64; cq++) {
@@ -308,6 +317,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
             }
         }
     }
+    SGSTAMP(3);
 }
 
 // ---- the two places without a GEMM in front: relu(mask(Y) * sigmoid(z)) of a Jasper block without residual, then -----------------------------

@@ -356,6 +356,9 @@ struct SpkGemmParams {
     bf16_t *x_out;                   // SG_RES: the block's output, masked, [S * 160][N]
     const bf16_t *x_in;              // SG_ASP: encoder output [S * 160][N]
     const float *bn_s, *bn_b; float *pool;   // SG_ASP: folded BN of the embedding layer [2 N], pool [S][2 N]
+#ifdef SG_STAMPS
+    unsigned long long *stamps;      // diagnostic build (tests/micro/spk_gemm_probe.hip): 8 real-time stamps (100 MHz) per workgroup
+#endif
 };
 int launch_spk_gemm(const SpkGemmParams &p, hipStream_t st);      // -1: operands the kernel's indexing does not cover (nothing launched)
 const char *spk_gemm_check(const SpkGemmParams &p);
