@@ -714,13 +714,12 @@ def main():
 
     # ---- diarization side-car beside the ASR engine (configs[4]) ---------------------------------------------------------
     def diarization_entry(r, n_ov):
-        # The ASR engine and the side-car share the runtime's four hardware queues.  The side-car's two networks are independent
-        # of each other (VAD on every 10 ms window, TitaNet-L on 1.5 s sub-segments), so each gets a queue of its own, lent by the
-        # ASR engine (nasr_engine_lend_stream x 2), and a host thread of its own; the ASR engine keeps two lanes (two encoder
-        # pieces, the decode behind the second).  Measured against ONE side-car stream running VAD then embeddings beside three ASR
-        # streams (round 2): 7.1 ms per step -> see `split_streams` in bench_details.json.
-        split = os.environ.get("NASR_DIAR_SPLIT", "1") != "0" and not args.sync_steps
-        side_depth = 0 if args.sync_steps else min(args.pipeline_depth, 2)
+        # The ASR engine and the side-car share the runtime's four hardware queues.  Round 6 (segment-tile TitaNet-L: an embedding call 3.4 -> 1.25 ms): ONE
+        # side-car queue, lent by the ASR engine (nasr_engine_lend_stream), one host thread calling VAD then embeddings, and the ASR engine keeps THREE lanes
+        # (4.50 ms per step; two side-car queues + two ASR lanes, the round-2 arrangement: 4.91; profiles/r6_configs4.md).  NASR_DIAR_SPLIT=1 / NASR_DIAR_ASR_LANES=n
+        # select the other arrangements.
+        split = os.environ.get("NASR_DIAR_SPLIT", "0") != "0" and not args.sync_steps
+        side_depth = 0 if args.sync_steps else min(args.pipeline_depth, int(os.environ.get("NASR_DIAR_ASR_LANES", "2" if split else "3")))
         r.drain()
         dW = synth.make_diar_weights()
         dvad = capi.Diar(dW, dtype=capi.DTYPE_BF16 | (0 if os.environ.get("NASR_DIAR_VAD_F32") else capi.DIAR_VAD_F16), max_segments=max(8, 2 * r.B), device=local_rank)
@@ -784,8 +783,8 @@ def main():
         details["diarize"] = dict(runs_ms_per_step=[round(1e3 * x, 3) for x in ovs], steps_per_region=n_ov, vad_windows_per_step=int(sum(x.size for x in pv)),
                                   embeddings_per_step=n_seg, asr_pipeline_depth=side_depth, split_streams=split,
                                   note="side-car (MarbleNet VAD on every 10 ms window + TitaNet-L embeddings of 1.5 s sub-segments at a 0.75 s shift, random-init "
-                                       "weights) on the streams' own s16 PCM, device-resident; VAD and embeddings each on a HIP stream lent by the ASR engine, "
-                                       "each from its own host thread, beside the ASR step; vad_ms / embed_ms: each call run alone")
+                                       "weights) on the streams' own s16 PCM, device-resident, on HIP stream(s) lent by the ASR engine (split_streams: VAD and embeddings each "
+                                       "on their own stream and host thread; otherwise one stream, one thread), beside the ASR step; vad_ms / embed_ms: each call run alone")
         dvad.close()
         if split:
             demb.close()

@@ -25,11 +25,18 @@
 #include "nasr_internal.h"
 #include "nasr_wave.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace nasr {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 sg_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float sg_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned sg_u32x4;          // a plain vector type: asm operands of HIP's uint4 class live in memory
 
+#ifndef SG_ABLATE
+#define SG_ABLATE 0          // probe builds only: 1 = no MFMAs, 2 = no loads (LDS-DMA / register loads), 3 = no fragment reads and no loads (MFMAs alone), 4 = no barrier
+#endif
 #ifdef SG_STAMPS
 #define SGSTAMP(i) do { if (threadIdx.x == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -162,7 +169,16 @@ __device__ __forceinline__ void sg_combine(float *stage, const float *y_rows, in
 }  // namespace
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------------------------------------
-template <int MODE>
+// LOOP 0: both operands through the LDS ring (4 slots of 18 KiB, three in flight), waves 2 x 2 (80 rows x 64 columns each).  Stamps of that form with cold
+//         operands (tests/micro/spk_gemm_probe.hip, 96 segments): 0.5-0.7 us per 32-deep chunk against 0.13 us of MFMA time -- the two co-resident
+//         workgroups keep 2 x 3 x 18 KiB = 110 KB in flight, and 110 KB per ~2 us of memory latency is exactly the 55 GB/s per CU they move: the
+//         loop is bound by the BYTES IN FLIGHT the LDS can hold, not by issue, LDS bandwidth or the matrix pipe.
+// LOOP 1: the registers take half of the in-flight bytes.  Waves 1 x 4: a wave owns 32 columns and ALL 160 rows, so its two weight fragments per chunk are its own
+//         (no second wave needs them): they come straight from global memory into a ring of 8 VGPR sets (global_load_dwordx4 in asm, counted by hand: 2 KB per
+//         wave and chunk, contiguous KiB in the packed weight layout), six chunks ahead; the LDS ring carries only the activation panel (10 KiB per chunk,
+//         7 slots, six in flight).  Per workgroup 6 x (10 + 8) = 108 KB in flight instead of 55.  One s_waitcnt vmcnt(25) per chunk covers both queues:
+//         every iteration issues the same group (3 LDS-DMA + 2 register loads) in the same order.  Needs K / 32 a multiple of 8.
+template <int MODE, int LOOP>
 __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     constexpr int NT = SG_THREADS;
     extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -175,64 +191,141 @@ __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     }
     const int s = id / n_groups, ng = id - s * n_groups;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nq = wave & 1, mh = wave >> 1, q = lane >> 4, r = lane & 15;
+    const int nq = wave & 1, mh = wave >> 1, q = lane >> 4, r = lane & 15;          // LOOP 0: the wave's column half / row half
     const int KT = p.K >> 5;
     const size_t m0 = (size_t)s * SG_BM;
-    const char *src[SG_DMA];
-    unsigned dst[SG_DMA];
-    int step[SG_DMA];
-#pragma unroll
-    for (int u = 0; u < SG_DMA; u++) {
-        int j = wave * SG_DMA + u;
-        if (j >= SG_PIECES) j = SG_PIECES - 1;          // the same bytes to the same place a second time: every wave's vmcnt arithmetic stays equal
-        if (j < SG_NP) {
-            const int row = j * 16 + (lane >> 2);
-            src[u] = (const char *)(p.A + (m0 + row) * p.lda) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
-            dst[u] = (unsigned)(j * 1024);
-            step[u] = 64;
-        } else {
-            const int t = j - SG_NP;
-            src[u] = (const char *)p.W + (size_t)(ng * (SG_BN / 16) + t) * KT * 1024 + lane * 16;
-            dst[u] = (unsigned)(SG_BM * 64 + t * 1024);
-            step[u] = 1024;
-        }
-    }
-    const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
-    auto issue = [&](int kt, int slot) {
-        const unsigned sb = ring_base + slot * SG_SLOT;
-#pragma unroll
-        for (int u = 0; u < SG_DMA; u++) sg_glds16(src[u] + (size_t)kt * step[u], sb + dst[u]);
-    };
-    sg_f32x4 acc[SG_NT][SG_MT];
-#pragma unroll
-    for (int j = 0; j < SG_NT; j++)
-#pragma unroll
-        for (int mt = 0; mt < SG_MT; mt++) acc[j][mt] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < SG_P; i++)
-        if (i < KT) issue(i, i);
     const int L = p.lens[s];
-    int slot = 0;
-    for (int i = 0; i < KT; i++) {
-        if (i == 1) SGSTAMP(1);
-        const int left = KT - 1 - i;                            // chunks allowed to stay in flight: min(left, P - 1)
-        if (left >= SG_P - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA * (SG_P - 1)) : "memory");
-        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
-        if (i + SG_P < KT) issue(i + SG_P, slot == 0 ? SG_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
-        const char *sp = ring + slot * SG_SLOT;
-        uint4 wf[SG_NT];
+    // 20 accumulators of 16 x 16.  LOOP 0: acc[j * 5 + mt] = columns nq * 64 + j * 16 .., rows mh * 80 + mt * 16 ..;  LOOP 1: acc[j * 10 + mt] = columns wave * 32 + j * 16 .., rows mt * 16 ..
+    sg_f32x4 acc[20];
 #pragma unroll
-        for (int j = 0; j < SG_NT; j++) wf[j] = *(const uint4 *)(sp + SG_BM * 64 + (nq * SG_NT + j) * 1024 + lane * 16);
-#pragma unroll
-        for (int mt = 0; mt < SG_MT; mt++) {
-            const uint4 bv = *(const uint4 *)(sp + sg_panel_off(mh * (SG_BM / 2) + mt * 16 + r, q));
-            const sg_bf16x8 bf = __builtin_bit_cast(sg_bf16x8, bv);
-#pragma unroll
-            for (int j = 0; j < SG_NT; j++) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wf[j]), bf, acc[j][mt], 0, 0, 0);
+    for (int a = 0; a < 20; a++) acc[a] = (sg_f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (LOOP == 0) {
+        const char *src[SG_DMA];
+        unsigned dst[SG_DMA];
+        int step[SG_DMA];
+    #pragma unroll
+        for (int u = 0; u < SG_DMA; u++) {
+            int j = wave * SG_DMA + u;
+            if (j >= SG_PIECES) j = SG_PIECES - 1;          // the same bytes to the same place a second time: every wave's vmcnt arithmetic stays equal
+            if (j < SG_NP) {
+                const int row = j * 16 + (lane >> 2);
+                src[u] = (const char *)(p.A + (m0 + row) * p.lda) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
+                dst[u] = (unsigned)(j * 1024);
+                step[u] = 64;
+            } else {
+                const int t = j - SG_NP;
+                src[u] = (const char *)p.W + (size_t)(ng * (SG_BN / 16) + t) * KT * 1024 + lane * 16;
+                dst[u] = (unsigned)(SG_BM * 64 + t * 1024);
+                step[u] = 1024;
+            }
         }
-        slot = slot + 1 == SG_NS ? 0 : slot + 1;
+        const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+        auto issue = [&](int kt, int slot) {
+            const unsigned sb = ring_base + slot * SG_SLOT;
+    #pragma unroll
+            for (int u = 0; u < SG_DMA; u++) sg_glds16(src[u] + (size_t)kt * step[u], sb + dst[u]);
+        };
+    #pragma unroll
+        for (int i = 0; i < SG_P; i++)
+            if (i < KT) issue(i, i);
+        int slot = 0;
+        for (int i = 0; i < KT; i++) {
+            if (i == 1) SGSTAMP(1);
+            const int left = KT - 1 - i;                            // chunks allowed to stay in flight: min(left, P - 1)
+            if (left >= SG_P - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA * (SG_P - 1)) : "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave's part of chunk i has landed; chunk i - 1 is fully consumed
+            if (i + SG_P < KT) issue(i + SG_P, slot == 0 ? SG_NS - 1 : slot - 1);          // into the slot chunk i - 1 has just left
+            const char *sp = ring + slot * SG_SLOT;
+            // ALL nine fragment reads of the chunk go out before the first MFMA (stamps of the first form: hipcc's schedule read two fragments, waited, issued four
+            // MFMAs, read two more ...: five dependent LDS round trips per chunk, ~1 100 cycles per wave and chunk against 320 of MFMA)
+            uint4 wf[SG_NT], bv[SG_MT];
+    #pragma unroll
+            for (int j = 0; j < SG_NT; j++) wf[j] = *(const uint4 *)(sp + SG_BM * 64 + (nq * SG_NT + j) * 1024 + lane * 16);
+    #pragma unroll
+            for (int mt = 0; mt < SG_MT; mt++) bv[mt] = *(const uint4 *)(sp + sg_panel_off(mh * (SG_BM / 2) + mt * 16 + r, q));
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int mt = 0; mt < SG_MT; mt++) {
+                const sg_bf16x8 bf = __builtin_bit_cast(sg_bf16x8, bv[mt]);
+    #pragma unroll
+                for (int j = 0; j < SG_NT; j++) acc[j * SG_MT + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wf[j]), bf, acc[j * SG_MT + mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot + 1 == SG_NS ? 0 : slot + 1;
+        }
+
+    } else {
+        constexpr int D = 6, NSA = 7, ASLOT = SG_BM * 64, GROUP = 5;          // chunks ahead, activation ring slots of 10 KiB, VMEM instructions per wave and chunk
+        static_assert(NSA * ASLOT <= SG_LDS && NSA == D + 1, "the activation ring fits the allocation; chunk i + D goes into the slot chunk i - 1 left");
+        // activation panel: 10 pieces of 16 rows x 64 B; wave w issues pieces 3 w .. 3 w + 2 (pieces 10, 11 repeat piece 9: every wave's count stays 3)
+        const char *asrc[3];
+        unsigned adst[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            int j = wave * 3 + u;
+            if (j >= SG_NP) j = SG_NP - 1;
+            const int row = j * 16 + (lane >> 2);
+            asrc[u] = (const char *)(p.A + (m0 + row) * p.lda) + (((lane & 3) ^ ((0 - (row >> 2)) & 3)) << 4);
+            adst[u] = (unsigned)(j * 1024);
+        }
+        const char *wsrc[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) wsrc[j] = (const char *)p.W + (size_t)(ng * (SG_BN / 16) + wave * 2 + j) * KT * 1024 + lane * 16;
+        const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+        // the weight fragments' register ring: set (chunk & 7) = wA<set>, wB<set> -- sixteen named uint4 (an array reached through a lambda or an index would live in scratch)
+        sg_u32x4 wA0, wB0, wA1, wB1, wA2, wB2, wA3, wB3, wA4, wB4, wA5, wB5, wA6, wB6, wA7, wB7;
+        unsigned a_off[10];
+#pragma unroll
+        for (int mt = 0; mt < 10; mt++) a_off[mt] = (unsigned)sg_panel_off(mt * 16 + r, q);
+        // one group = the wave's VMEM instructions of a chunk, always in this order: 3 LDS-DMA, 2 register loads
+#define SG_GROUP(kt, set)                                                                                                        \
+        do {                                                                                                                     \
+            const unsigned sb_ = ring_base + (unsigned)((kt) % NSA) * ASLOT;                                                     \
+            sg_glds16(asrc[0] + (size_t)(kt) * 64, sb_ + adst[0]);                                                               \
+            sg_glds16(asrc[1] + (size_t)(kt) * 64, sb_ + adst[1]);                                                               \
+            sg_glds16(asrc[2] + (size_t)(kt) * 64, sb_ + adst[2]);                                                               \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wA##set) : "v"(wsrc[0] + (size_t)(kt) * 1024) : "memory");     \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wB##set) : "v"(wsrc[1] + (size_t)(kt) * 1024) : "memory");     \
+        } while (0)
+        // chunk i with its weight fragments in set `set`; the group of chunk i + D goes into set `nset` = (set + D) & 7
+#define SG_BODY(i_, set, nset)                                                                                                   \
+        do {                                                                                                                     \
+            const int i = (i_);                                                                                                  \
+            if (i == 1) SGSTAMP(1);                                                                                              \
+            const int left = KT - 1 - i;          /* groups younger than chunk i's that may stay in flight: min(left, D - 1) */  \
+            if (left >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP * (D - 1)) : "memory");                            \
+            else if (left == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP * 4) : "memory");                                 \
+            else if (left == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP * 3) : "memory");                                 \
+            else if (left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP * 2) : "memory");                                 \
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUP) : "memory");                                     \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                \
+            if (SG_ABLATE != 4) __builtin_amdgcn_s_barrier();         /* every wave's pieces of chunk i have landed; every wave is done with chunk i - 1 */ \
+            if (i + D < KT && SG_ABLATE != 2 && SG_ABLATE != 3) SG_GROUP(i + D, nset);                                           \
+            /* this wave's weight fragments of chunk i are in set `set` (its own loads, waited for above): opaque from here, so that no MFMA is scheduled above the wait */ \
+            asm volatile("" : "+v"(wA##set), "+v"(wB##set));                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            const char *sp = ring + (i % NSA) * ASLOT;                                                                           \
+            uint4 bv[10];                        /* all ten fragment reads go out before the first MFMA */                       \
+            _Pragma("unroll") for (int mt = 0; mt < 10; mt++) bv[mt] = SG_ABLATE == 3 ? make_uint4(i, mt, 3, 4) : *(const uint4 *)(sp + a_off[mt]);                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < 10; mt++) {                                                                  \
+                const sg_bf16x8 bf = __builtin_bit_cast(sg_bf16x8, bv[mt]);                                                      \
+                if (SG_ABLATE == 1) { acc[mt][0] += __uint_as_float(bv[mt].x ^ wA##set[0]); acc[10 + mt][0] += __uint_as_float(bv[mt].y ^ wB##set[1]); continue; } \
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wA##set), bf, acc[mt], 0, 0, 0); \
+                acc[10 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wB##set), bf, acc[10 + mt], 0, 0, 0); \
+            }                                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        } while (0)
+        SG_GROUP(0, 0); SG_GROUP(1, 1); SG_GROUP(2, 2); SG_GROUP(3, 3); SG_GROUP(4, 4); SG_GROUP(5, 5);
+        if (SG_ABLATE == 2 || SG_ABLATE == 3) { wA6 = wA0; wB6 = wB0; wA7 = wA1; wB7 = wB1; }          // probe builds: sets 6, 7 are never loaded
+        for (int i0 = 0; i0 < KT; i0 += 8) {
+            SG_BODY(i0, 0, 6); SG_BODY(i0 + 1, 1, 7); SG_BODY(i0 + 2, 2, 0); SG_BODY(i0 + 3, 3, 1);
+            SG_BODY(i0 + 4, 4, 2); SG_BODY(i0 + 5, 5, 3); SG_BODY(i0 + 6, 6, 4); SG_BODY(i0 + 7, 7, 5);
+        }
+#undef SG_BODY
+#undef SG_GROUP
     }
 
     SGSTAMP(2);
@@ -241,17 +334,21 @@ __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     for (int cq = 0; cq < SG_BN / 64; cq++) {
         const int n0c = ng * SG_BN + cq * 64;                  // global column of the half's column 0
         __syncthreads();                                        // the ring / the previous half's stage is no longer read
-        if (nq == cq) {
+        // the waves that own columns of this half park them: LOOP 0: waves with nq == cq, 4 column blocks x 5 row blocks; LOOP 1: waves 2 cq, 2 cq + 1, 2 x 10
+        constexpr int PJ = LOOP == 0 ? SG_NT : 2, PM = LOOP == 0 ? SG_MT : 10;
+        if ((LOOP == 0 ? nq : (wave >> 1)) == cq) {
+            const int col0 = LOOP == 0 ? 0 : (wave & 1) * 32, row0 = LOOP == 0 ? mh * (SG_BM / 2) : 0;
 #pragma unroll
-            for (int j = 0; j < SG_NT; j++) {
-                const float4 b = *(const float4 *)(p.bias + n0c + j * 16 + q * 4);
+            for (int j = 0; j < PJ; j++) {
+                const float4 b = *(const float4 *)(p.bias + n0c + col0 + j * 16 + q * 4);
 #pragma unroll
-                for (int mt = 0; mt < SG_MT; mt++) {
-                    const int row = mh * (SG_BM / 2) + mt * 16 + r;
-                    float4 v = make_float4(acc[j][mt][0] + b.x, acc[j][mt][1] + b.y, acc[j][mt][2] + b.z, acc[j][mt][3] + b.w);
+                for (int mt = 0; mt < PM; mt++) {
+                    const int row = row0 + mt * 16 + r;
+                    const sg_f32x4 &a = acc[j * PM + mt];
+                    float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
                     if (MODE == SG_DW) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));      // ReLU between the sub-convs (:360-363)
                     if (MODE != SG_RES && row >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);                                           // MaskedConv1d: frames >= L read as zero
-                    *(float4 *)(stage + row * SG_SLD + j * 16 + q * 4) = v;
+                    *(float4 *)(stage + row * SG_SLD + col0 + j * 16 + q * 4) = v;
                 }
             }
         }
@@ -533,10 +630,14 @@ void launch_gather_audio(const GatherDesc *tab_dev, int B, long long max_bytes, 
 }
 
 void init_spk_kernel_attributes() {
-    hipFuncSetAttribute((const void *)k_spk_gemm<SG_DW>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
-    hipFuncSetAttribute((const void *)k_spk_gemm<SG_Y>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
-    hipFuncSetAttribute((const void *)k_spk_gemm<SG_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
-    hipFuncSetAttribute((const void *)k_spk_gemm<SG_ASP>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_DW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_Y, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_RES, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_ASP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_DW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_Y, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_RES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
+    hipFuncSetAttribute((const void *)k_spk_gemm<SG_ASP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS);
 }
 
 // host-side shape check: a hand-written kernel never sees operands its indexing does not cover
@@ -553,13 +654,18 @@ const char *spk_gemm_check(const SpkGemmParams &p) {
 int launch_spk_gemm(const SpkGemmParams &p, hipStream_t st) {
     if (spk_gemm_check(p)) return -1;
     const dim3 grid((unsigned)(p.S * (p.N / SG_BN))), block(SG_THREADS);
+    // the register-ring loop where K / 32 is a multiple of 8 (the 1024-deep GEMMs); the all-LDS loop for the two 128-deep ones.  NASR_SPK_LOOP=0 forces the latter (A/B)
+    static const int force0 = []() { const char *e = getenv("NASR_SPK_LOOP"); return e && e[0] == '0' ? 1 : 0; }();
+    const bool regs = !force0 && (p.K / 32) % 8 == 0;
+#define SG_LAUNCH(M_) do { if (regs) hipLaunchKernelGGL((k_spk_gemm<M_, 1>), grid, block, SG_LDS, st, p); else hipLaunchKernelGGL((k_spk_gemm<M_, 0>), grid, block, SG_LDS, st, p); } while (0)
     switch (p.mode) {
-    case SG_DW: hipLaunchKernelGGL(k_spk_gemm<SG_DW>, grid, block, SG_LDS, st, p); break;
-    case SG_Y: hipLaunchKernelGGL(k_spk_gemm<SG_Y>, grid, block, SG_LDS, st, p); break;
-    case SG_RES: hipLaunchKernelGGL(k_spk_gemm<SG_RES>, grid, block, SG_LDS, st, p); break;
-    case SG_ASP: hipLaunchKernelGGL(k_spk_gemm<SG_ASP>, grid, block, SG_LDS, st, p); break;
+    case SG_DW: SG_LAUNCH(SG_DW); break;
+    case SG_Y: SG_LAUNCH(SG_Y); break;
+    case SG_RES: SG_LAUNCH(SG_RES); break;
+    case SG_ASP: SG_LAUNCH(SG_ASP); break;
     default: return -1;
     }
+#undef SG_LAUNCH
     return 0;
 }
 int launch_spk_tile(const SpkTileParams &p, hipStream_t st) {
