@@ -780,6 +780,23 @@ def main():
         r.eng.set_option("pipeline", depth)
         t_ov = statistics.median(ovs)
         d = dict(value=round(r.audio_per_step / t_ov, 1), ms_per_step=round(1e3 * t_ov, 3), vad_ms=round(1e3 * t_vad, 3), embed_ms=round(1e3 * t_spk, 3))
+        # roofline of the side-car's dominant launch sequence, measured live: HIP events on the side-car's own stream around the kernels of an embedding
+        # call run alone (nasr_diar_last_gpu_ms).  Algorithmic flops: TitaNet-L = 2 x 160 frames x 16 646 144 MAC of pointwise / attention
+        # GEMMs per 1.5 s sub-segment (src/diarize_spk.cpp:28-34: 80->1024, 9 + 3 x 1024->1024, 1024->3072, 3072->128->3072), MarbleNet = 11.4 MFLOP per 0.63 s
+        # window (src/diarize_vad.cpp:25-32: 89 k MAC per frame x 64 frames); the depthwise taps (< 1 %) and the small linears are not counted.
+        spk_flops, vad_flops = n_seg * 2.0 * 160 * 16646144, float(sum(x.size for x in pv)) * 11.4e6
+        demb.embed_device_s16(seg_ptrs)
+        emb_gpu_ms = demb.last_gpu_ms("embed")
+        dvad.vad_device_s16(vad_ptrs, vad_n)
+        vad_gpu_ms = dvad.last_gpu_ms("vad")
+        asr = step_roofline(args.layers, r.B, r.R, t_ov, 1.0625 if args.weights == "q8_0" else 2.0)
+        if emb_gpu_ms > 0:
+            ach = spk_flops / (emb_gpu_ms * 1e-3) / 1e12
+            d["roofline"] = dict(bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                                 kernel="TitaNet-L launch sequence of one nasr_diar_embed call (13 x k_spk_gemm at 160 x 128 segment tiles + front / SE / pooling kernels), run alone",
+                                 avg_launch_us=round(1e3 * emb_gpu_ms, 1), launches_per_step=1)
+        d["step_mfma_frac"] = round((asr["flops_per_step"] + spk_flops + vad_flops) / t_ov / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        d["embed_gpu_ms"], d["vad_gpu_ms"] = round(emb_gpu_ms, 3), round(vad_gpu_ms, 3)
         details["diarize"] = dict(runs_ms_per_step=[round(1e3 * x, 3) for x in ovs], steps_per_region=n_ov, vad_windows_per_step=int(sum(x.size for x in pv)),
                                   embeddings_per_step=n_seg, asr_pipeline_depth=side_depth, split_streams=split,
                                   note="side-car (MarbleNet VAD on every 10 ms window + TitaNet-L embeddings of 1.5 s sub-segments at a 0.75 s shift, random-init "

@@ -294,6 +294,11 @@ int  nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, const int32_t
  * padded by the caller), lens_samples[s] of them real; emb_out = [S][192]. */
 int  nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, const int32_t *lens_samples, float *emb_out, uint32_t flags);
 
+/* measurement: device time (ms) of the LAST nasr_diar_vad (which = 0) / nasr_diar_embed (which = 1) call's launch sequence, from HIP events on the
+ * side-car's own stream around its kernels (staging copies and the read-back excluded) -- what bench.py prices configs[4]'s roofline with.  The
+ * reference has no counterpart (it times whole sessions on the host, src/diarize_pipeline.cpp). */
+int  nasr_diar_last_gpu_ms(nasr_diar *d, int which, float *ms_out);
+
 /* parity tap: diarize_compute_logmel (src/diarize_audio.cpp:136-227) of one whole host buffer on the device front end,
  * which = 0: the 'vad.*' filterbank, 1: 'spk.*'.  mel_out = [80][t_padded] row-major like the reference's output
  * (t_padded = t_valid rounded up to 16, t_valid = n_samples / 160); this is what tests/test_diarize_preproc.cpp checks

@@ -29,7 +29,7 @@ EXPORTS = [
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
     "nasr_engine_profile_read", "nasr_engine_hip_stream", "nasr_engine_lend_stream", "nasr_device_alloc", "nasr_device_free",
     "nasr_device_upload", "nasr_engine_synchronize", "nasr_engine_get_counter", "nasr_stream_debug_fill_kv",
-    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_set_stream", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel",
+    "nasr_diar_create", "nasr_diar_destroy", "nasr_diar_set_stream", "nasr_diar_vad", "nasr_diar_embed", "nasr_diar_logmel", "nasr_diar_last_gpu_ms",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         L.nasr_diar_destroy.restype = None
         L.nasr_diar_vad.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
         L.nasr_diar_embed.argtypes = [vp, C.c_int, C.POINTER(vp), ip, C.POINTER(C.c_float), C.c_uint32]
+        L.nasr_diar_last_gpu_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
         L.nasr_diar_logmel.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int32, C.c_int, C.POINTER(C.c_float), C.c_int64, ip]
         L.nasr_stream_get_token_frames.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
         L.nasr_engine_step.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), ip, C.POINTER(vp), ip, ip, C.c_uint32]
@@ -268,6 +269,12 @@ class Diar:
         out = np.zeros((S, 192), np.float32)
         _chk(lib().nasr_diar_embed(self.h, S, ap, ln, out.ctypes.data_as(C.POINTER(C.c_float)), FLAG_AUDIO_S16 | FLAG_PCM_DEVICE))
         return out
+
+    def last_gpu_ms(self, which: str) -> float:
+        """device time of the last vad() / embed() call's launch sequence (HIP events on the side-car's stream)"""
+        ms = C.c_float(0.0)
+        _chk(lib().nasr_diar_last_gpu_ms(self.h, 0 if which == "vad" else 1, C.byref(ms)))
+        return float(ms.value)
 
     def logmel(self, audio: np.ndarray, which: str = "vad", normalize: bool = False):
         """parity tap: diarize_compute_logmel of one buffer on the device front end -> ([80][t_padded], t_valid)"""

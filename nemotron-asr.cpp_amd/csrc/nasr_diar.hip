@@ -82,6 +82,8 @@ struct nasr_diar {
     std::map<std::pair<int, uint32_t>, hipGraphExec_t> spk_graphs;
     const void *spk_graph_audio = nullptr;
     bool spk_use_graph = true;       // NASR_DIAR_NO_GRAPH=1: eager launches (A/B, debugging)
+    hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [vad / embed][begin / end] of the last call's launch sequence (nasr_diar_last_gpu_ms)
+    float last_ms[2] = {0.f, 0.f};
     // scratch
     char *audio = nullptr; size_t audio_cap = 0;        // staged input samples (float or s16), capacities in bytes
     char *pin_audio = nullptr; size_t pin_audio_cap = 0;
@@ -341,6 +343,7 @@ static void diar_destroy_impl(nasr_diar *d) {
     hipSetDevice(d->device);
     if (d->st) hipStreamSynchronize(d->st);
     for (auto &kv : d->spk_graphs) hipGraphExecDestroy(kv.second);
+    for (auto &pair : d->ev) for (auto &e : pair) if (e) hipEventDestroy(e);
     for (void *p : d->allocs) hipFree(p);
     if (d->audio) hipFree(d->audio);
     if (d->fr_desc) hipFree(d->fr_desc);
@@ -416,6 +419,7 @@ extern "C" int nasr_diar_create(nasr_diar **out, int device_id, int dtype, const
     init_diar_kernel_attributes();
     init_spk_kernel_attributes();
     if (const char *ng = getenv("NASR_DIAR_NO_GRAPH")) d->spk_use_graph = !(ng[0] && ng[0] != '0');
+    for (auto &pair : d->ev) for (auto &e : pair) if (hipEventCreate(&e) != hipSuccess) { diar_destroy_impl(d); return failf("hipEventCreate failed"); }
     d->pin_cap = (size_t)(d->max_windows + d->max_segments * SPK_EMB + 4096) * 16;
     if (hipHostMalloc((void **)&d->pin, d->pin_cap, hipHostMallocDefault) != hipSuccess) { diar_destroy_impl(d); return failf("hipHostMalloc failed"); }
     int rc = 0;
@@ -506,15 +510,25 @@ extern "C" int nasr_diar_vad(nasr_diar *d, int B, const float *const *audio, con
     memset(&mp, 0, sizeof(mp));
     set_audio(d, flags, mp);
     mp.window = d->window; mp.fbT = d->vad_fbT; mp.fb_band = d->vad_band; mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+    DCHK(hipEventRecord(d->ev[0][0], d->st));
     launch_diar_frames(mp, d->fr_desc, (int)n_frames, d->fr_mel, d->st);
     (d->vad_f16 ? launch_vad_marblenet_f16 : d->vad_bf16 ? launch_vad_marblenet_bf16 : launch_vad_marblenet)(d->vad, d->fr_mel, d->fr_mel + n_shared * DIAR_NMEL, d->win_row, d->win_row + W, d->prob, W, d->st);
+    DCHK(hipEventRecord(d->ev[0][1], d->st));
     DCHK(hipMemcpyAsync(h_prob, d->prob, (size_t)W * sizeof(float), hipMemcpyDeviceToHost, d->st));
     DCHK(hipStreamSynchronize(d->st));
+    if (hipEventElapsedTime(&d->last_ms[0], d->ev[0][0], d->ev[0][1]) != hipSuccess) d->last_ms[0] = 0.f;
     for (int b = 0; b < B; b++) {
         const int nw = first[b + 1] - first[b];
         const int cap = probs_out && probs_out[b] && probs_cap ? probs_cap[b] : 0;
         for (int i = 0; i < nw && i < cap; i++) probs_out[b][i] = h_prob[first[b] + i];
     }
+    return 0;
+}
+
+// device time of the last call's launch sequence (HIP events on the side-car's stream around its kernels; staging copies and the read-back excluded)
+extern "C" int nasr_diar_last_gpu_ms(nasr_diar *d, int which, float *ms_out) {
+    if (!d || !ms_out || (which != 0 && which != 1)) return failf("nasr_diar_last_gpu_ms: which = 0 (VAD) or 1 (embeddings)");
+    *ms_out = d->last_ms[which];
     return 0;
 }
 
@@ -787,6 +801,7 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         mp.win_off = d->s_off; mp.n_win = SPK_SEGMENT; mp.T_pad = SPK_T; mp.t_valid = SPK_TVALID;
         mp.cpitch = 96; mp.mel = d->s_mel; mp.window = d->window; mp.fbT = d->spk_fbT; mp.fb_band = d->spk_band;
         mp.cos_t = d->cos_t; mp.sin_t = d->sin_t;
+        DCHK(hipEventRecord(d->ev[1][0], d->st));
         if (d->bf16) {
             // front end + encoder + pooling + embedding layer: eager, or one graph per (St, sample type) replayed
             auto enqueue = [&]() -> int {
@@ -869,8 +884,12 @@ extern "C" int nasr_diar_embed(nasr_diar *d, int S, const float *const *audio, c
         launch_encproj(d->pool, d->emb_w, d->emb_b, d->emb, St, 2 * SPK_C, SPK_EMB, d->st);      // [S][6144] x [192][6144]^T, always f32
         }
         float *h_emb = (float *)(d->pin + (size_t)d->max_segments * (sizeof(long long) + sizeof(int)));
+        DCHK(hipEventRecord(d->ev[1][1], d->st));
         DCHK(hipMemcpyAsync(h_emb, d->emb, (size_t)St * SPK_EMB * sizeof(float), hipMemcpyDeviceToHost, d->st));
         DCHK(hipStreamSynchronize(d->st));
+        float tile_ms = 0.f;
+        if (hipEventElapsedTime(&tile_ms, d->ev[1][0], d->ev[1][1]) != hipSuccess) tile_ms = 0.f;
+        d->last_ms[1] = (s0 == 0 ? 0.f : d->last_ms[1]) + tile_ms;
         memcpy(emb_out + (size_t)s0 * SPK_EMB, h_emb, (size_t)St * SPK_EMB * sizeof(float));
     }
     return 0;

@@ -3,7 +3,7 @@
 set -x
 mkdir -p gpurun_out/r6
 COMMON="--batch 64 --right-context 13 --weights q8_0 --steps 40 --warmup 5 --diarize --no-extra-configs --no-cpu-baseline --no-f32-engine --no-buffered --no-grouped --no-host-pcm --no-profile-pass --no-b512"
-for v in "0 3" "0 4"; do
+for v in "0 3"; do
   set -- $v; s=$1; export NASR_DIAR_ASR_LANES=$2
   NASR_DIAR_SPLIT=$s python bench.py $COMMON > gpurun_out/r6/cfg4_split$s.json 2> gpurun_out/r6/cfg4_split$s.err
   python - <<PY
