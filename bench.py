@@ -627,7 +627,12 @@ def main():
     tokens_timed, chunks_timed = run.tokens, run.streams[0].progress().chunks
     per_rank = None
     if dist is not None:                       # what every rank did in the same timed regions (N > 1: tokens must match a single-process run of the same streams)
-        mine = dict(rank=rank, device=local_rank, stream_ids=[run_ids[0], run_ids[-1]], tokens_emitted=tokens_timed, lanes=run.eng.counter("lanes"),
+        try:
+            aff = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            aff = []
+        mine = dict(rank=rank, device=local_rank, stream_ids=dict(first=run_ids[0], stride=world, count=len(run_ids)), tokens_emitted=tokens_timed,
+                    lanes=run.eng.counter("lanes"), cpu_affinity=(f"{aff[0]}-{aff[-1]} ({len(aff)})" if aff else None),
                     ms_per_step=round(1e3 * statistics.median(run.local_regions[-args.regions:]) / args.steps, 4) if getattr(run, "local_regions", None) else None)
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
@@ -1027,7 +1032,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": workload, "streams_per_gpu": B, "right_context": R, "parallelism": f"stream-sharded x{world}, no collectives",
+            "config": {"workload": workload, "streams_per_gpu": B, "right_context": R, "parallelism": f"stream-sharded x{world} ({sharding.PLACEMENT}: the server's --devices rule), no collectives",
                        **({"rehearsal": f"all {world} ranks on device {args.share_device}, gloo barrier (one-GPU box)"} if args.share_device >= 0 else {}),
                        "pcm": "device-resident", "checkpoint": "speech" if speech else "random", "pipeline": depth, "tokens_emitted": tokens_timed,
                        "bracket": (f"primed: {prime} untimed steps fill the pipeline, K timed calls, no drain inside the region (idle-to-idle: cold_ms_per_step; "

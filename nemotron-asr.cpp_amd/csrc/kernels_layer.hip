@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
 // VALU kernel; within the stated bf16 tolerance).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+#ifdef ATTN_STAMPS          // tests/micro/attn_probe.hip: 8 real-time stamps (100 MHz) per workgroup
+__device__ unsigned long long *g_attn_stamps;
+#define ASTAMP(i) do { if (threadIdx.x == 0 && g_attn_stamps) g_attn_stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     // LDS (round 5): the V^T image (32 KiB) is needed in phase 3 only, the query images and the score tiles in phases 0-2 only: they share one region,
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     char *const qu_s = lds, *const qv_s = lds + 4096;                  // [16][256 B] each                     phases 0-1
     float *const sk = (float *)(lds + 8192), *const sp = (float *)(lds + 8192 + 16 * SKP * 4);      // score tiles   phases 1-2 (ends at 22 016 < 32 768)
     char *const w_s = lds + 128 * 256;                                 // softmax weights [16][256 B]          phases 2-3
+    ASTAMP(0);
     const int h = blockIdx.x, b = blockIdx.y, T = p.T, KV = LCTX + T, n_rel = KV + T - 1;
     const int TS = p.TS > 0 ? p.TS : p.T;
     const int QB = T <= 2 ? 16 : T;                          // query rows per workgroup
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         *(bf16_t *)(qv_s + off) = f32_to_bf16(qq + p.bias_v[h * DH + d]);
     }
     __syncthreads();
+    ASTAMP(1);
     // ---- phase 1: 6 key tiles + 7 relative-position tiles on the MFMA -------------------------------
 #pragma unroll
     for (int n = 0; n < 4; n++) {
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         }
     }
     __syncthreads();
+    ASTAMP(2);
     // ---- phase 2: rel-shift gather + mask + softmax -> bf16 weights over the span (zero outside the row's window) ----
     const float scale = 0.08838834764831845f;
     for (int i = wave; i < 16; i += 4) {
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         *(bf16_t *)(w_s + i * 256 + ((((p1 >> 3) ^ i) & 15) << 4) + (p1 & 7) * 2) = f32_to_bf16(e1 * inv);
     }
     __syncthreads();                          // every read of the query images and the score tiles is done: their region becomes the V^T image
+    ASTAMP(3);
     // V^T image: row d = 256 B = 16 chunks of 8 keys; chunk (j >> 3) sits at ((j >> 3) ^ d ^ (d >> 4)) & 15.  The 16 lanes
     // that hold the 16 d-groups of one key write 16 different chunks (d & 15 alone takes two values there: 16-way
     // conflicts, SQ_LDS_BANK_CONFLICT 85 % of the LDS cycles of this kernel before)
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
         }
     }
     __syncthreads();
+    ASTAMP(4);
     // ---- phase 3: O^T[d][i] = V^T . w^T, 8 d-tiles x 3 k-steps ---------------------------------------
     for (int dt = wave * 2; dt < wave * 2 + 2; dt++) {
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
             store_wt_u2((bf16_t *)p.ctx_out + (row0 + r) * D + h * DH + dt * 16 + q * 4, o);
         }
     }
+    ASTAMP(5);
 }
 
 // ---- one new row per stream (T = 1: every R = 0 batch), bf16 caches ------------------------------------------------------------

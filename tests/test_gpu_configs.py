@@ -154,6 +154,9 @@ def test_config3_full_size_one_step_and_q8_semantics(Q24):
     _report("config3_full_size", rep)
     # the engine (bf16 operands) must be no further from ggml's Q8_0 semantics than 3x what those semantics are from f32
     assert rep["engine_vs_q8_act_oracle"]["mean"] < 3 * max(rep["q8_act_oracle_vs_f32_oracle"]["mean"], 5e-3), rep
+    # THE tolerance of the bf16 path, against the PINNED F32 oracle -- not only against the oracle's own bf16 emulation:
+    # 24 layers, near-tie (random) checkpoint: max < 8e-2, mean < 1.6e-2 of |x| <= 4 (measured 5.7e-2 / 1.2e-2; the reference's f32 ladder is 5e-3, tests/test_compute.cpp:2351)
+    assert rep["engine_vs_f32_oracle"]["max"] < 8e-2 and rep["engine_vs_f32_oracle"]["mean"] < 1.6e-2, rep["engine_vs_f32_oracle"]
 
 
 def _run_engine_tokens(eng, R, pcms, n):
@@ -558,7 +561,7 @@ def test_progress_does_not_drain_the_pipeline(W2):
     eng.close()
 
 
-@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1200", "7", "8"), ("1000", "3", "4", "L4", "SOAK_STREAMS=13x72,0x4"),
+@pytest.mark.parametrize("args", [("800", "11"), ("1200", "7", "4", "L8"), ("1000", "3", "4", "L4", "SOAK_STREAMS=13x72,0x4"),      # ("1200", "7", "8") moved out (round 6: suite time); run it with tests/micro/soak_pipeline.py
                                   ("300", "11", "4", "L4", "SOAK_STREAMS=13x100", "SOAK_OPTS=large_step_pieces=2")])
 def test_pipelined_engine_soak(args):
     """tests/micro/soak_pipeline.py, short form: random push sizes (partial chunks, several chunks, ragged groups), random subsets of

@@ -78,11 +78,13 @@ def test_two_rank_gloo_sharding(tmp_path):
         st = ob.OracleStream(model, 0)
         ref = st.process(synth.make_pcm(sid, 0.8)) + st.finalize()
         assert list(merged[sid]) == ref
-        assert sharding.owner_of(sid, B) == sid // B
+        assert sharding.owner_of(sid, world) == sid % world       # the server's rule: stream s on device s mod count
     assert float((tmp_path / "rtfx.txt").read_text()) > 0
 
 
 def test_stream_partition_is_exact():
     for world in (1, 2, 4, 8):
-        ids = sum((sharding.stream_ids(r, world, 64) for r in range(world)), [])
-        assert ids == list(range(64 * world))
+        per_rank = [sharding.stream_ids(r, world, 64) for r in range(world)]
+        assert sorted(sum(per_rank, [])) == list(range(64 * world))                     # every stream exactly once
+        assert all(len(ids) == 64 for ids in per_rank)
+        assert all(sharding.owner_of(s, world) == r for r, ids in enumerate(per_rank) for s in ids)
