@@ -292,6 +292,10 @@ __global__ __launch_bounds__(256) void k_attention_mfma(AttnParams p) {
     ASTAMP(5);
 }
 
+// (round 6, measured and removed: a form of this kernel in which a workgroup walks four streams of a head with the NEXT stream's rows in flight in a second
+// register set and the relative-position tiles loaded once -- bit-identical, 252 VGPRs, two workgroups per CU.  Alone with cold rings 86.9 -> 67.9 us at 512
+// streams (tests/micro/attn_probe.hip), inside the engine SLOWER: 512 streams pipelined 13.05 -> 13.23 ms, synchronous 14.90 -> 15.20, 256 streams 6.70 -> 6.77
+// on the same box: there four workgroups per CU win over two with a deeper queue.  profiles/r6_attention.md)
 // ---- one new row per stream (T = 1: every R = 0 batch), bf16 caches ------------------------------------------------------------
 // k_attention_mfma feeds its MFMAs with 16-byte loads in the operand layout (16 lanes = 16 different rows): at T = 1 there is
 // next to no arithmetic and the kernel is bound by its address unit (12.4 us per launch at 64 streams, the same as at T = 14).

@@ -50,17 +50,27 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int l = 0; l < NL; l++) { p.kv_pool = kv[l]; launch_attention(p, 0); }
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < REPS; r++) { p.kv_pool = kv[r % NL]; launch_attention(p, 0); }
-    CK(hipEventRecord(e1, 0));
-    CK(hipEventSynchronize(e1));
-    float ms = 0;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    const double us = 1e3 * ms / REPS;
     const double bytes = (double)B * NH * ((2.0 * (LCTX + T) * DH * 2) + T * DH * 4 + T * DH * 2);
-    printf("k_attention_mfma B=%d T=%d: %.1f us per launch, %.2f TB/s of K/V + q + ctx (%.0f MB)\n", B, T, us, bytes / (us * 1e-6) / 1e12, bytes / 1e6);
+    std::vector<bf16_t> out[2];
+    for (int variant = 0; variant < 1; variant++) {          // (round 6 also timed a four-streams-per-workgroup form here: profiles/r6_attention.md)
+        p.ablate = variant ? 0 : 4;
+        for (int l = 0; l < NL; l++) { p.kv_pool = kv[l]; launch_attention(p, 0); }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < REPS; r++) { p.kv_pool = kv[r % NL]; launch_attention(p, 0); }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / REPS;
+        printf("%s B=%d T=%d: %.1f us per launch, %.2f TB/s of K/V + q + ctx (%.0f MB)\n", variant ? "k_attention_mfma_ps" : "k_attention_mfma   ", B, T, us, bytes / (us * 1e-6) / 1e12, bytes / 1e6);
+        CK(hipMemset(ctx, 0, M * D * 2));
+        p.kv_pool = kv[1]; launch_attention(p, 0);
+        CK(hipDeviceSynchronize());
+        out[variant].resize(M * D);
+        CK(hipMemcpy(out[variant].data(), ctx, M * D * 2, hipMemcpyDeviceToHost));
+    }
+    p.ablate = 4;
     const int QB = T <= 2 ? 16 : T, nz = (T + QB - 1) / QB;
     const size_t nwg = (size_t)NH * B * nz;
     unsigned long long *st;
