@@ -113,6 +113,11 @@ int nasr_abi_version(void);
  * and nemo_free (:521-540).  max_streams sizes the per-stream state pool. ------------- */
 int  nasr_engine_create(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
                         const nasr_weight_desc *weights, int n_weights, int max_streams);
+/* the same with the row capacity of one launch sequence stated: workspace_rows >= max_streams x 14 lets a call hand several whole chunks of EVERY
+ * stream to the engine at once (B streams x G chunks x (1 + right_context) rows <= workspace_rows): a server working off a backlog then runs
+ * GEMMs of G times the rows (host/nemo_server.cpp --backlog-chunks).  0 = the default, max(max_streams x 14, 256).  ~45 KB of HBM per row and step in flight. */
+int  nasr_engine_create_ex(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
+                           const nasr_weight_desc *weights, int n_weights, int max_streams, int workspace_rows);
 void nasr_engine_destroy(nasr_engine *e);
 
 /* ---- streams: replaces nemo_stream_init (src/nemo-stream.cpp:696-733 -> ::init :36-93:

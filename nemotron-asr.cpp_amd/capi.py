@@ -23,7 +23,7 @@ RESET_FRESH, RESET_REFERENCE = 0, 1
 TAP_MEL, TAP_SUBSAMPLED, TAP_LAYER_OUT, TAP_ENCODER_OUT, TAP_K_CACHE, TAP_V_CACHE, TAP_CONV_CACHE, TAP_DEC_STATE = range(8)
 
 EXPORTS = [
-    "nasr_last_error", "nasr_abi_version", "nasr_tensor_to_f32", "nasr_engine_create", "nasr_engine_destroy",
+    "nasr_last_error", "nasr_abi_version", "nasr_tensor_to_f32", "nasr_engine_create", "nasr_engine_create_ex", "nasr_engine_destroy",
     "nasr_stream_create", "nasr_stream_reset", "nasr_stream_reset_ex", "nasr_stream_destroy", "nasr_stream_set_prompt",
     "nasr_stream_get_stats", "nasr_stream_get_progress", "nasr_stream_get_token_frames", "nasr_engine_step", "nasr_engine_step_mel", "nasr_engine_finalize",
     "nasr_engine_collect", "nasr_engine_set_option", "nasr_engine_set_debug", "nasr_stream_get_tap", "nasr_engine_profile",
@@ -67,6 +67,7 @@ def lib():
         vp, ip = C.c_void_p, C.POINTER(C.c_int32)
         L.nasr_last_error.restype = C.c_char_p
         L.nasr_engine_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(HParams), C.POINTER(WeightDesc), C.c_int, C.c_int]
+        L.nasr_engine_create_ex.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(HParams), C.POINTER(WeightDesc), C.c_int, C.c_int, C.c_int]
         L.nasr_engine_destroy.argtypes = [vp]
         L.nasr_engine_destroy.restype = None
         L.nasr_tensor_to_f32.argtypes = [C.POINTER(WeightDesc), C.POINTER(C.c_float), C.c_int64]

@@ -456,8 +456,13 @@ void use_ws(nasr_engine *e, const nasr_engine::WS &w) {
 }  // namespace nasr_eng
 extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
                                   const nasr_weight_desc *weights, int n_weights, int max_streams) {
+    return nasr_engine_create_ex(out, device_id, dtype, hp, weights, n_weights, max_streams, 0);
+}
+extern "C" int nasr_engine_create_ex(nasr_engine **out, int device_id, int dtype, const nasr_hparams *hp,
+                                     const nasr_weight_desc *weights, int n_weights, int max_streams, int workspace_rows) {
     ApiGuard api_guard;
     if (!out || !hp || !weights) return fail("nasr_engine_create: null argument");
+    if (workspace_rows < 0 || workspace_rows > (1 << 20)) return fail("workspace_rows out of range");
     *out = nullptr;
     if (dtype != NASR_DTYPE_F32 && dtype != NASR_DTYPE_BF16) return fail("unsupported dtype %d", dtype);
     if (hp->d_model != D || hp->n_heads != NH || hp->d_head != DH || hp->d_ff != FF || hp->n_mels != NMEL ||
@@ -485,7 +490,7 @@ extern "C" int nasr_engine_create(nasr_engine **out, int device_id, int dtype, c
     if (load_weights(e, weights, n_weights)) { engine_destroy_impl(e); return -1; }
 
     const size_t S = (size_t)max_streams, Lr = (size_t)hp->n_layers, ks1 = (size_t)hp->kernel_size - 1;
-    e->w_rows = std::max(max_streams * TMAX, MAXNEW);
+    e->w_rows = std::max(std::max(max_streams * TMAX, MAXNEW), workspace_rows);      // workspace_rows: room for several chunks of every stream in ONE launch sequence (a server's backlog)
     const size_t M = (size_t)e->w_rows;
     int rc = 0;
     rc |= dalloc(e, &e->abuf, S * 2 * ABUF_CAP);

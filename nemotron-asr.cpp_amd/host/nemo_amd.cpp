@@ -60,6 +60,9 @@ std::vector<timed_token> nemo_stream_get_timed_tokens(nemo_stream_context *sctx)
 }
 
 nemo_context *nemo_init_with_device(const char *model_path, int device, int dtype, int max_streams) {
+    return nemo_init_with_rows(model_path, device, dtype, max_streams, 0);
+}
+nemo_context *nemo_init_with_rows(const char *model_path, int device, int dtype, int max_streams, int workspace_rows) {
     if (!model_path) return nullptr;
     GgufFile g;
     std::string err;
@@ -121,12 +124,13 @@ nemo_context *nemo_init_with_device(const char *model_path, int device, int dtyp
     nh.n_layers = hp.n_layers; nh.vocab_size = hp.vocab_size; nh.decoder_dim = hp.decoder_dim; nh.joint_dim = hp.joint_dim;
     nh.subsampling_factor = hp.subsampling_factor; nh.att_left_context = hp.att_left_context; nh.kernel_size = hp.kernel_size;
     nh.num_prompts = hp.num_prompts;
-    if (nasr_engine_create(&ctx->engine, device, dtype, &nh, descs.data(), (int)descs.size(), max_streams) < 0) {
+    if (nasr_engine_create_ex(&ctx->engine, device, dtype, &nh, descs.data(), (int)descs.size(), max_streams, workspace_rows) < 0) {
         fprintf(stderr, "%s: %s\n", __func__, nasr_last_error());
         delete ctx;
         return nullptr;
     }
     ctx->max_streams = max_streams;
+    ctx->workspace_rows = std::max(std::max(max_streams * 14, 256), workspace_rows);
     return ctx;
 }
 

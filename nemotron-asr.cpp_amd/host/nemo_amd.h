@@ -26,6 +26,7 @@ struct nemo_context {               // reference: nemo_context / nemo_model (src
     int prompt_index = -1;          // default language prompt (101 = "auto") for multilingual models
     nasr_engine *engine = nullptr;
     int max_streams = 0;
+    int workspace_rows = 0;          // rows one engine call may carry (streams x chunks x (1 + right_context)); nasr_engine_create_ex
 };
 
 enum class nemo_latency_mode { PURE_CAUSAL = 0, ULTRA_LOW = 1, LOW = 6, DEFAULT = 13 };   // src/nemo-stream.h:15-20
@@ -58,6 +59,8 @@ struct nemo_stream_context {        // reference src/nemo-stream.h:177-262 (host
 // ---- model (reference src/nemo-ggml.cpp:444-540) ------------------------------------------------
 // dtype: 0 = f32, 1 = bf16 (NASR_DTYPE_*).  Returns nullptr on failure (message on stderr).
 nemo_context *nemo_init_with_device(const char *model_path, int device, int dtype, int max_streams);
+// ... with room for several chunks of every stream in one engine call (a server's backlog): workspace_rows >= max_streams x 14, 0 = default
+nemo_context *nemo_init_with_rows(const char *model_path, int device, int dtype, int max_streams, int workspace_rows);
 nemo_context *nemo_init(const char *model_path);              // device 0, bf16, 64 streams
 void nemo_free(nemo_context *ctx);
 bool nemo_set_language(nemo_context *ctx, const char *lang);  // default prompt for new streams

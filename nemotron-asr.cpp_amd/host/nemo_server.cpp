@@ -170,7 +170,7 @@ void worker_loop(Lane *lane) {
     std::vector<uint32_t> ending;               // sessions whose STREAM_END has been read
     std::map<int, uint64_t> b_hist;               // streams per engine call -> calls (printed at exit: tests/server_load.py reads it)
     std::set<uint32_t> in_flight;               // --pipeline: sessions whose last steps may still be on the GPU
-    const int row_budget = std::max(model->max_streams * 14, 256);      // rows one launch sequence may carry (csrc/nasr_engine.hip: w_rows, nasr_engine_create)
+    const int row_budget = std::max(model->workspace_rows, std::max(model->max_streams * 14, 256));      // rows one launch sequence may carry (csrc/nasr_engine.hip: w_rows, nasr_engine_create_ex)
     auto drain = [&]() {                         // complete the steps in flight and send their text (FIFO empty, END, LANG)
         if (in_flight.empty()) return;
         std::map<int, std::vector<uint32_t>> by_T;         // one collect per right_context: an engine call takes streams of one lookahead
@@ -224,10 +224,28 @@ void worker_loop(Lane *lane) {
             const int T = g.first;
             std::vector<uint32_t> ids = g.second;
             if ((int)ids.size() * T > row_budget) { ids.resize((size_t)(row_budget / T)); more = true; }
-            int G = INT32_MAX;
-            for (uint32_t id : ids) G = std::min(G, sessions[id].whole_chunks_pending());
-            G = std::max(1, std::min(G, std::min(row_budget / ((int)ids.size() * T), 248 / T)));      // 248: a call's samples stay below the engine's MAX_PUSH (256 encoder frames)
-            while (G & (G - 1)) G &= G - 1;       // a power of two: every (streams, chunks) pair is a step shape with graphs of its own (~20 ms to capture); a backlog is worked off in 8 + 4 + 2 + 1 rather than in 13 different sizes
+            // chunks per session in this call: the power of two G (every (streams, chunks) pair is a step shape with graphs of its own, ~20 ms to capture: a backlog
+            // is worked off in 8 + 4 + 2 + 1 rather than in 13 different sizes) that carries the most rows -- sessions holding fewer than G chunks wait for the
+            // next call instead of pulling the whole call down to their count (round 6: one late session made a 64-stream call single-chunk)
+            int G = 1;
+            {
+                // 248: a call's samples stay below the engine's MAX_PUSH (256 encoder frames); and no more chunks per session than leave room for EVERY
+                // session of a full server in the call (a few sessions with a deep backlog must not crowd the others out of the launch)
+                const int gmax = std::max(1, std::min(248 / T, row_budget / (std::max(1, model->max_streams) * T)));
+                long best_rows = 0;
+                for (int g = 1; g <= gmax; g <<= 1) {
+                    int n_g = 0;
+                    for (uint32_t id : ids) n_g += sessions[id].whole_chunks_pending() >= g;
+                    n_g = std::min(n_g, row_budget / (g * T));
+                    if (n_g > 0 && (long)n_g * g >= best_rows) { best_rows = (long)n_g * g; G = g; }
+                }
+                std::vector<uint32_t> keep;
+                for (uint32_t id : ids) {
+                    if (sessions[id].whole_chunks_pending() >= G && (int)keep.size() < row_budget / (G * T)) keep.push_back(id);
+                    else more = true;
+                }
+                ids.swap(keep);
+            }
             std::vector<size_t> n(ids.size());
             for (size_t b = 0; b < ids.size(); b++) {
                 Session &s = sessions[ids[b]];
@@ -464,18 +482,19 @@ void on_signal(int) { g_stop = true; if (g_listen_fd >= 0) ::shutdown(g_listen_f
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--pipeline E] [--prewarm R[,R...] | --no-prewarm] [--cpu | --cuda]\n"
+        fprintf(stderr, "Usage: %s <model.gguf> [--tcp host:port | --unix path] [--right-context R] [--device N | --devices N,M,...] [--f32] [--max-streams N] [--backlog-chunks K] [--pipeline E] [--prewarm R[,R...] | --no-prewarm] [--cpu | --cuda]\n"
                         "  --prewarm: capture the step graphs of every batch size 1..max-streams for these right_context values before listening (~20 ms each);\n"
                         "             with --pipeline the default right_context is prewarmed unless --no-prewarm\n"
                         "  --tcp: default 127.0.0.1:8300 (the reference's port, src/nemo-server.cpp:411; the reference binds every interface when no host is given, this server binds loopback unless told otherwise: --tcp 0.0.0.0:8300)\n"
                         "  --pipeline E: consecutive engine calls overlap on the GPU (E = 0..4; 4 pieces on 4 hardware queues is the throughput optimum, 0 the lowest latency); a stream's text arrives\n"
                         "                E calls later while the FIFO is busy and at once when it runs empty\n"
-                        "  --devices: one engine + worker per listed GPU; stream s is served by entry s mod count\n", argv[0]);
+                        "  --devices: one engine + worker per listed GPU; stream s is served by entry s mod count\n"
+                        "  --backlog-chunks K: an engine call may carry up to K whole chunks of every stream (default 4; 1 = one chunk per stream and call)\n", argv[0]);
         return 1;
     }
     std::string tcp = "127.0.0.1:8300", unix_path;
     std::vector<int> devices{0};
-    int dtype = 1, max_streams = 64;
+    int dtype = 1, max_streams = 64, backlog_chunks = 4;
     std::vector<int> prewarm_rc;
     bool no_prewarm = false;
     for (int i = 2; i < argc; i++) {
@@ -494,6 +513,7 @@ int main(int argc, char **argv) {
             if (devices.empty()) { fprintf(stderr, "--devices needs a comma-separated list\n"); return 1; }
         }
         else if (a == "--max-streams" && i + 1 < argc) max_streams = atoi(argv[++i]);
+        else if (a == "--backlog-chunks" && i + 1 < argc) backlog_chunks = std::max(1, std::min(16, atoi(argv[++i])));
         else if (a == "--f32") dtype = 0;
         else if (a == "--cpu" || a == "--cuda" || a == "--metal") {
             // the reference server's backend switches (src/nemo-server.cpp:405-406): accepted so that its invocations run unchanged
@@ -513,7 +533,9 @@ int main(int argc, char **argv) {
     if (prewarm_rc.empty() && !no_prewarm && g_pipeline > 0) prewarm_rc.push_back(g_default_rc);     // a throughput server: the default lookahead's shapes are ready when the socket opens
     for (int dev : devices) {
         std::unique_ptr<Lane> ln(new Lane());
-        ln->model = nemo_init_with_device(argv[1], dev, dtype, max_streams);
+        // room for backlog_chunks whole chunks of EVERY stream at the longest lookahead in one engine call: sessions that hold several chunks (a file, a client
+        // that fell behind) are worked off in GEMMs of that many times the rows (64 streams x R = 13: 896 -> 3 584 rows)
+        ln->model = nemo_init_with_rows(argv[1], dev, dtype, max_streams, max_streams * 14 * backlog_chunks);
         if (!ln->model) { fprintf(stderr, "Failed to load ASR model on device %d\n", dev); return 1; }
         if (g_pipeline > 0 && !nemo_set_pipeline(ln->model, g_pipeline)) return 1;
         // one step shape per batch size and right_context in use, and as many again for the multi-chunk shapes of a backlog (chunk counts are

@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--warmup-seconds", type=float, default=0.0,
                     help="a first load of this many seconds per stream on the same server (graph captures, lane picking), not reported")
     ap.add_argument("--conns", type=int, default=8)
+    ap.add_argument("--backlog-chunks", type=int, default=0, help="passed to the server (0: its default): whole chunks of every stream one engine call may carry")
     ap.add_argument("--devices", default="", help="passed to the server: one engine + worker per entry (\"0,0,0,0\": four engines on the one GPU of a test box), stream s on entry s mod count")
     args = ap.parse_args()
     wd = Path(args.workdir)
@@ -301,6 +302,8 @@ def main():
     n_dev = len(args.devices.split(",")) if args.devices else 1
     if args.devices:
         extra += ("--devices", args.devices)
+    if args.backlog_chunks:
+        extra += ("--backlog-chunks", str(args.backlog_chunks))
     proc = start_server(model, sock_path, -(-args.streams // n_dev) if args.devices else args.streams, args.pipeline, extra=extra)
     try:
         if args.warmup_seconds > 0:
@@ -310,6 +313,7 @@ def main():
         srv, err = stop_server(proc)
     rep["server"] = srv
     rep["pipeline"] = args.pipeline
+    rep["backlog_chunks"] = args.backlog_chunks or "server default (4)"
     if args.devices:
         rep["devices"] = args.devices
         rep["server_stderr_tail"] = [ln for ln in err.splitlines() if "worker" in ln or "device" in ln][-12:]
