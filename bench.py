@@ -203,7 +203,7 @@ def pmc_traffic(kernel_symbol_part, tag):
     (profiles/r4_pmc_traffic_<tag>.json, written by tests/prof_r4.sh: FETCH_SIZE x 2 + WRITE_SIZE as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be collected from inside this process; null when no
     summary for the configuration / kernel is committed."""
-    f = next((c for c in (ROOT / "profiles" / f"r5_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r4_pmc_traffic_{tag}.json") if c.exists()), None)
+    f = next((c for c in (ROOT / "profiles" / f"r6_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r5_pmc_traffic_{tag}.json", ROOT / "profiles" / f"r4_pmc_traffic_{tag}.json") if c.exists()), None)
     if f is None:
         return None
     try:
@@ -721,7 +721,7 @@ def main():
     def diarization_entry(r, n_ov):
         # The ASR engine and the side-car share the runtime's four hardware queues.  Round 6 (segment-tile TitaNet-L: an embedding call 3.4 -> 1.25 ms): ONE
         # side-car queue, lent by the ASR engine (nasr_engine_lend_stream), one host thread calling VAD then embeddings, and the ASR engine keeps THREE lanes
-        # (4.50 ms per step; two side-car queues + two ASR lanes, the round-2 arrangement: 4.91; profiles/r6_configs4.md).  NASR_DIAR_SPLIT=1 / NASR_DIAR_ASR_LANES=n
+        # (4.50 ms per step; two side-car queues + two ASR lanes, the round-2 arrangement: 4.91; profiles/r6_titanet_segment_tiles.md, last table).  NASR_DIAR_SPLIT=1 / NASR_DIAR_ASR_LANES=n
         # select the other arrangements.
         split = os.environ.get("NASR_DIAR_SPLIT", "0") != "0" and not args.sync_steps
         side_depth = 0 if args.sync_steps else min(args.pipeline_depth, int(os.environ.get("NASR_DIAR_ASR_LANES", "2" if split else "3")))

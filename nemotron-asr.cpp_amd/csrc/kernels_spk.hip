@@ -654,7 +654,8 @@ const char *spk_gemm_check(const SpkGemmParams &p) {
 int launch_spk_gemm(const SpkGemmParams &p, hipStream_t st) {
     if (spk_gemm_check(p)) return -1;
     const dim3 grid((unsigned)(p.S * (p.N / SG_BN))), block(SG_THREADS);
-    // the register-ring loop where K / 32 is a multiple of 8 (the 1024-deep GEMMs); the all-LDS loop for the two 128-deep ones.  NASR_SPK_LOOP=0 forces the latter (A/B)
+    // the register-ring loop where K / 32 is a multiple of 8 (the 1024-deep GEMMs); the all-LDS loop for the two 128-deep ones.  NASR_SPK_LOOP=0 forces the latter (A/B).
+    // Per launch the two measure the same (profiles/r6_titanet_segment_tiles.md); LOOP 1 is the default because it is the one the round's parity runs and GPU suite exercised.
     static const int force0 = []() { const char *e = getenv("NASR_SPK_LOOP"); return e && e[0] == '0' ? 1 : 0; }();
     const bool regs = !force0 && (p.K / 32) % 8 == 0;
 #define SG_LAUNCH(M_) do { if (regs) hipLaunchKernelGGL((k_spk_gemm<M_, 1>), grid, block, SG_LDS, st, p); else hipLaunchKernelGGL((k_spk_gemm<M_, 0>), grid, block, SG_LDS, st, p); } while (0)

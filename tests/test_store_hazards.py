@@ -68,21 +68,17 @@ def data_operand(mnemonic: str, ops: list[str]) -> str:
 
 
 def written_regs(mnemonic: str, ops: list[str]) -> set[tuple[str, int]]:
-    """VGPR / AGPR registers the instruction writes (first operand of VALU ops and of loads into registers)."""
-    if not ops:
+    """VGPR / AGPR registers a VALU instruction writes (its first operand).  The hazard is about VALU writes in the next two issue slots;
+    a load that targets the same registers (ds_read, global_load) returns its data tens of cycles after the store has read its own
+    (hipcc itself places `ds_read_b128 v[130:133]` right behind `global_store_dwordx4 ..., v[130:133]`)."""
+    if not ops or not mnemonic.startswith("v_"):
         return set()
     if mnemonic.startswith(("v_cmp", "v_nop", "v_readlane", "v_readfirstlane")):
         return set()
-    if mnemonic.startswith("v_"):
-        w = regs_of(ops[0])
-        if mnemonic.startswith(("v_swap", "v_permlane")) and len(ops) > 1:
-            w |= regs_of(ops[1])
-        return w
-    if "_lds_" in mnemonic or mnemonic.endswith("_lds"):
-        return set()
-    if re.match(r"^(global|buffer|flat|scratch)_(load|atomic)", mnemonic) or mnemonic.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append")):
-        return regs_of(ops[0])
-    return set()
+    w = regs_of(ops[0])
+    if mnemonic.startswith(("v_swap", "v_permlane")) and len(ops) > 1:
+        w |= regs_of(ops[1])
+    return w
 
 
 def wait_states(mnemonic: str, ops: list[str]) -> int:
@@ -155,6 +151,8 @@ def test_parser_sees_the_hazard():
     assert len(bad) == 1                                                           # one state is not two
     _, _, bad = audit([("global_store_dwordx4", ["v[0:1]", "v[4:7]", "off"]), ("s_branch", ["65197"]), clobber])
     assert bad == []                                                               # linear listing behind an unconditional branch is not the successor
+    _, _, bad = audit([("global_store_dwordx4", ["v[0:1]", "v[4:7]", "off"]), ("ds_read_b128", ["v[4:7]", "v9"])])
+    assert bad == []                                                               # a load into the data registers lands long after the store has read them
     _, _, bad = audit([("buffer_store_dwordx3", ["v[4:6]", "v1", "s[0:3]", "0 offen"]), ("v_mov_b32_e32", ["v7", "v1"]), ("v_mov_b32_e32", ["v8", "v1"]), ("v_mov_b32_e32", ["v4", "v1"])])
     assert bad == []                                                               # third state: safe
 
