@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512) void k_gemm_t64(GemmParams p, int n_groups, in
 // waves 8-15 the same on the second half, each half with its own 3-slot ring: 2 x 72 KiB = what two co-resident k_gemm_t64<3> workgroups hold).
 // Rounds 1-4 wrote the two halves out as f32 partial slabs (2 x 3.67 MB per GEMM at 896 rows, write-through) and k_post read them back with the
 // residual: 16.5 MB per k_post launch, 97 launches per step; leaving k_post out of a pipelined 64-stream step saved 0.41 of its 2.48 ms
-// (profiles/r5_ablation.md).  Here the halves meet in LDS, and the epilogue adds scale x (p0 + p1) to the residual stream in place
+// (profiles/r5_configs2_launch_structure.md, r5_ablation_b64_R13.json).  Here the halves meet in LDS, and the epilogue adds scale x (p0 + p1) to the residual stream in place
 // (EPI_RESID_F32: the order and the fmaf of k_post -- o = t[0] + t[1]; x = fmaf(scale, o, x) -- so x keeps its bits): no partial slab leaves the
 // CU, k_post is left with the LayerNorm.  Each half performs k_gemm_t64's MFMAs in k_gemm_t64's order (split = half of 2): p0 and p1 are
 // the slabs' values.  The residual tile (32 KiB) is requested at kernel entry, long before it is needed.

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_dwconv(ConvParams p) {
 // ---- the same, one workgroup per STREAM (or per half of its frames: below) (round 5; kernel size 9) ------------------------------------------
 // k_dwconv's grid is (streams, frames): every GLU row is fetched by nine workgroups and the conv cache by eight, 7 168 workgroups of one
 // load round trip + two barriers at 512 streams x R = 13 (30 us per launch for 78 MB of algorithmic bytes; with attention 2.3 ms of a
-// 14.6 ms pipelined step, profiles/r5_ablation.md).  Here a workgroup keeps the stream's whole window -- 8 cached rows + T new ones, its 4
+// 14.6 ms pipelined step, profiles/r5_configs2_launch_structure.md, r5_ablation_b64_R13.json).  Here a workgroup keeps the stream's whole window -- 8 cached rows + T new ones, its 4
 // channels per thread -- in registers: every row is read ONCE, the T outputs are formed in k_dwconv's order, their T LayerNorms share two
 // barriers (per row the sums are k_dwconv's: wave_sum, then (w0 + w1) + (w2 + w3)), and the new cache is the window's last 8 rows.
 // Same bits as k_dwconv (engine option "dwconv_stream" = 0; tests/micro/gemm_variant_identity.py).

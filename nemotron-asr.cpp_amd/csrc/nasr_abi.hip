@@ -152,7 +152,10 @@ int try_graph_step(nasr_engine *e, nasr_stream *const *streams, int B, const int
         if (d.n_frames > 0) s->abuf_par ^= 1;
         s->mel_count += d.n_frames;
     }
-    if (*gh_active < 0) return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    if (*gh_active < 0) {          // reported once: the flag is cleared so that the steps after this one are judged on their own (advisor, round 5: it was sticky)
+        hipMemsetAsync(e->n_active + 3, 0, sizeof(int), e->st);
+        return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    }
     if (*gh_active != 0) {   // some stream emitted more symbols than the graph's iteration budget: finish eagerly
         DecParams dp;
         make_dec_params(e, (const RowDesc *)(e->g_desc + L.rows), B, T * G, dp);

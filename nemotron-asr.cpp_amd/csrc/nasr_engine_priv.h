@@ -150,13 +150,13 @@ struct nasr_engine {
     int opt_gemm_prio = 0;           // option "gemm_prio": GemmParams::prio (probes of wave priority in the GEMM loops)
     bool opt_epilogue16 = true;      // option "epilogue16": SiLU rows, K / V ring rows and GLU pairs leave the GEMM epilogues as 16-byte stores (eight columns per thread; same values)
     bool opt_dwconv_stream = true;   // option "dwconv_stream": the depthwise conv with one workgroup per stream from 256 streams x 4 frames (k_dwconv_stream; same bits)
-    int opt_chain = 0;               // option "chain" (OFF: measured 23 % SLOWER, profiles/r5_chained_launches.md): 1 = in pipelined steps of 769 .. 1 343 rows the GEMM that reads a k_post's
+    int opt_chain = 0;               // option "chain" (OFF: measured 23 % SLOWER, profiles/r5_configs2_launch_structure.md section 3): 1 = in pipelined steps of 769 .. 1 343 rows the GEMM that reads a k_post's
                                      // rows carries that k_post as its head phase (GemmParams::chain: one launch fewer per LayerNorm, same bits); 2 = in synchronous steps too
     int opt_split_tasks = 0;         // option "split_tasks": residual GEMMs take ONE K slice from this many 128 x 128 output tiles (0 = the rule, 200; A/B runs)
     int opt_resid_epilogue = 1;       // option "resid_epilogue": residual GEMMs add to the residual stream in their own epilogue where one workgroup owns a tile's whole K sum
                                      // (k_gemm_t64w / launches without split-K): 1 = in pipelined steps (default), 2 = always, 0 = partial slabs + k_post everywhere (rounds 1-4); same bits
     int opt_ablate = 0;              // option "ablate" (MEASUREMENT ONLY, results are invalid): bit mask of launches left out of the unfused step -- 1 k_post, 2 attention,
-                                     // 4 depthwise conv, 8 decode iterations, 16 front end (mel + subsampling), 32 every encoder GEMM: what each costs a pipelined step (profiles/r5_ablation.md)
+                                     // 4 depthwise conv, 8 decode iterations, 16 front end (mel + subsampling), 32 every encoder GEMM: what each costs a pipelined step (profiles/r5_configs2_launch_structure.md, r5_ablation_b64_R13.json)
     bool opt_f32_mfma = true;        // f32 GEMMs above four rows on v_mfma_f32_32x32x2_f32 (bit-identical to the FMA tile kernel)
     char *gh = nullptr;                                                               // pinned host block
     int *gh_collect = nullptr;       // pinned landing zone of the token gather: [B][1 + COLLECT_STRIDE] + n_active

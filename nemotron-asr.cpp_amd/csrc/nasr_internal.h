@@ -103,7 +103,7 @@ struct PostParams {       // x += scale * sum_s part[s]; then LayerNorm(s)
 };
 // Round 5: a CHAINED launch.  The residual + LayerNorm that produces a GEMM's A rows used to be its own launch (k_post) between the GEMM that
 // wrote the residual and the GEMM that reads the normalised rows: 97 launches per 24-layer step whose removal saved 0.41 of a pipelined
-// 64-stream step's 2.48 ms (profiles/r5_ablation.md) although their own duration is 5 us -- what they cost is a place in the dependent chain
+// 64-stream step's 2.48 ms (profiles/r5_configs2_launch_structure.md, r5_ablation_b64_R13.json) although their own duration is 5 us -- what they cost is a place in the dependent chain
 // (a boundary on either side, a round trip of loads, two reductions).  In a chained launch the first `head_wgs` workgroups of the grid ARE
 // that k_post (nasr_post.h: the same body, `head_rows` rows each, in row order), and the tile workgroups behind them start by streaming
 // their WEIGHT panels into the LDS ring, then wait until the rows of their own row chunk are published (one counter per row chunk, agent
@@ -115,7 +115,7 @@ struct ChainParams {
     PostParams post;          // rows [0, post.M) = the GEMM's A rows
     int head_wgs;             // 0: an ordinary launch
     int head_rows;            // rows per head workgroup (a divisor of 128: a head workgroup's rows lie in one row chunk)
-    unsigned *flags;          // [2][32]: rows published per row chunk / tile workgroups of the chunk that have passed the wait (the last one resets both)
+    unsigned *flags;          // 128 words: [0, 64) rows published per row chunk, [64, 128) tile workgroups of the chunk that have passed the wait (the last one resets both)
     unsigned *error;          // set to 1 by a tile workgroup that gave up waiting
 };
 

@@ -266,7 +266,10 @@ int pipe_finish(nasr_engine *e, int p) {
     hipStream_t ds = dec_stream(e, P);
     { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.dec_done)); }
     int *gh_active = P.gh_collect + (size_t)B * (1 + COLLECT_STRIDE);      // k_collect appends n_active to its records
-    if (*gh_active < 0) return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    if (*gh_active < 0) {          // reported once: the flag is cleared so that the steps after this one are judged on their own (advisor, round 5: it was sticky)
+        hipMemsetAsync(e->n_active + 3, 0, sizeof(int), e->st);
+        return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    }
     if (*gh_active != 0 && !(e->opt_ablate & 8)) {
         const GraphDescLayout L = graph_desc_layout(B, P.G);
         DecParams dp;
@@ -605,7 +608,10 @@ int gp_finish_decode(nasr_engine *e) {
     hipStream_t ds = e->lane[nasr_engine::GP_C - 1];
     { HostTimer ht(e->host_wait_s); HIPCHK(hipEventSynchronize(P.dec_done)); }
     int *gh_active = P.gh_collect + (size_t)nB * (1 + COLLECT_STRIDE);
-    if (*gh_active < 0) return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    if (*gh_active < 0) {          // reported once: the flag is cleared so that the steps after this one are judged on their own (advisor, round 5: it was sticky)
+        hipMemsetAsync(e->n_active + 3, 0, sizeof(int), e->st);
+        return fail("a chained GEMM launch gave up waiting for its head workgroups (GemmParams::chain): results of this step are invalid");
+    }
     if (*gh_active != 0) {                                      // a burst beyond the graph's iteration budget: finish eagerly
         const GraphDescLayout L = graph_desc_layout(nB, P.G);
         DecParams dp;
