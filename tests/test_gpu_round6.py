@@ -133,3 +133,45 @@ def test_bf16_tolerance_vs_pinned_oracle_speech_checkpoint_24_layers(weights):
             d_max, d_mean, seen = max(d_max, float(d.max())), max(d_mean, float(d.mean())), seen + 1
     eng.close()
     assert seen == n_chunks and d_max < 3e-2 and d_mean < 5e-3, (seen, d_max, d_mean)
+
+
+def test_titanet_segment_tiles_tight_parity_graph_equals_eager_and_device_audio(monkeypatch):
+    """The bf16 engine's TitaNet-L path (round 6: segment tiles, csrc/kernels_spk.hip) against the F32 oracle at a bar that would catch a broken
+    epilogue (tests/test_gpu_diar.py keeps the stated tolerance of the precision, 6e-2): 1e-2 of the embedding scale, cosine > 0.9999 (measured
+    1.0e-3 ... 3.4e-3, >= 0.999995), over full, short and minimal lengths, tiled by max_segments.  Then the properties the new host path adds:
+    the hipGraph replay == eager launches bit for bit, a second call replays the cached graph with other lengths, batch == alone, and s16 PCM
+    resident in HBM (one gather launch) == the same samples as host floats."""
+    from oracle import diar_binding as db
+    W = synth.make_diar_weights(vad=False)
+    om = db.DiarModel(W)
+    pcm16 = [synth.make_pcm(40 + i, 1.5 + 0.01)[:24000] for i in range(7)]
+    segs = [p.astype(np.float32) / 32768.0 for p in pcm16]
+    lens = [24000, 24000, 12000, 4321, 100, 23999, 160]
+    ref = np.stack([om.spk_embed(a, l) for a, l in zip(segs, lens)])
+    scale = np.abs(ref).max()
+    eng = capi.Diar(W, dtype=capi.DTYPE_BF16, max_segments=4)           # 7 segments = two tiles of the call (4 + 3): two graph shapes
+    got = eng.embed(segs, lens)
+    assert np.isfinite(got).all()
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert np.abs(g - r).max() < 1e-2 * scale, (i, lens[i], float(np.abs(g - r).max() / scale))
+        assert float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r))) > 0.9999, i
+    again = eng.embed(segs, lens)                                        # cached graphs
+    assert np.array_equal(again, got)
+    lens2 = [160, 24000, 24000, 100, 12000, 4321, 23999]                 # same shapes, other lengths: the lengths are data of the graph, not part of it
+    got2 = eng.embed(segs, lens2)
+    ref2 = np.stack([om.spk_embed(a, l) for a, l in zip(segs, lens2)])
+    assert np.abs(got2 - ref2).max() < 1e-2 * scale
+    assert np.array_equal(eng.embed(segs[:1], lens[:1])[0], got[0])      # batch == alone: a tile is one sub-segment whatever the batch
+    # device-resident s16 (the ASR streams' own buffers in configs[4]): the same samples, the same bits
+    asr = capi.Engine(synth.make_weights(n_layers=1), n_layers=1, dtype=capi.DTYPE_BF16, max_streams=1)   # only for its device allocator (as tests/test_gpu_diar.py)
+    ptrs = [asr.upload(p) for p in pcm16]
+    got_dev = eng.embed_device_s16(ptrs, lens)
+    assert np.array_equal(got_dev, got)
+    assert eng.last_gpu_ms("embed") > 0.0
+    eng.close()
+    asr.close()
+    monkeypatch.setenv("NASR_DIAR_NO_GRAPH", "1")                        # read at nasr_diar_create
+    eager = capi.Diar(W, dtype=capi.DTYPE_BF16, max_segments=4)
+    got_eager = eager.embed(segs, lens)
+    eager.close()
+    assert np.array_equal(got_eager, got)
