@@ -632,7 +632,7 @@ def main():
         except (AttributeError, OSError):
             aff = []
         mine = dict(rank=rank, device=local_rank, stream_ids=dict(first=run_ids[0], stride=world, count=len(run_ids)), tokens_emitted=tokens_timed,
-                    lanes=run.eng.counter("lanes"), cpu_affinity=(f"{aff[0]}-{aff[-1]} ({len(aff)})" if aff else None),
+                    lanes=run.eng.counter("lanes"), cpu_affinity=((",".join(map(str, aff)) if len(aff) <= 8 else f"{len(aff)} CPUs in {aff[0]}..{aff[-1]}") if aff else None),
                     ms_per_step=round(1e3 * statistics.median(run.local_regions[-args.regions:]) / args.steps, 4) if getattr(run, "local_regions", None) else None)
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
