@@ -37,15 +37,15 @@ for dtype, name in ((capi.DTYPE_BF16 | capi.DIAR_VAD_BF16, "bf16, VAD on the bf1
           f"({4.3 * len(segs) / dt / 1e3:.1f} TFLOP/s at 4.3 GFLOP each); 64 streams need ~85/s", flush=True)
     if name.startswith("bf16, VAD on"):
         # configs[4]'s own call: sub-segments as device pointers into s16 PCM already resident in HBM (no host hand-over inside the call)
-        import torch
-        pcm = torch.from_numpy(np.stack([synth.make_pcm(100 + s, 1.5 + 0.01)[:24000] for s in range(96)])).to("cuda:0")
-        ptrs = [pcm.data_ptr() + 2 * 24000 * i for i in range(96)]
+        asr = capi.Engine(synth.make_weights(n_layers=1), n_layers=1, dtype=capi.DTYPE_BF16, max_streams=1)      # only for its device allocator (torch's own
+        # CUDA initialisation fails in a process whose GPU was first initialised through the library, unless a profiler did it even earlier)
+        ptrs = [asr.upload(synth.make_pcm(100 + s, 1.5 + 0.01)[:24000]) for s in range(96)]
         e2 = eng.embed_device_s16(ptrs)
-        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             e2 = eng.embed_device_s16(ptrs)
         dt = (time.perf_counter() - t0) / n
         assert np.abs(e2 - e).max() < 1e-2 * np.abs(e).max(), "device s16 path disagrees with the float host path"
-        print(f"[{name}] TitaNet-L, device-resident s16: {len(ptrs)} sub-segments in {dt * 1e3:.3f} ms ({0.511 / dt:.0f} TFLOP/s at 511 GFLOP of GEMMs per call)", flush=True)
+        print(f"[{name}] TitaNet-L, device-resident s16: {len(ptrs)} sub-segments in {dt * 1e3:.3f} ms, {eng.last_gpu_ms('embed'):.3f} ms on the device ({0.511 / dt:.0f} TFLOP/s at 511 GFLOP of GEMMs per call)", flush=True)
+        asr.close()
     eng.close()
