@@ -266,7 +266,9 @@ def stop_server(proc):
             partial += int(m.group(1))
             tails += int(m.group(2))
     eager = counters.get("eager_steps", 0)
-    return dict(engine_calls=calls, partial_chunk_calls=partial, tail_flushes=tails, engine_counters=counters,
+    worker_time = [dict(engine_calls_s=float(m.group(1)), events_into_sessions_s=float(m.group(2)), waiting_s=float(m.group(3)))
+                   for m in re.finditer(r"worker: wall time by activity: ([0-9.]+) s inside engine calls, ([0-9.]+) s moving received events into the sessions, ([0-9.]+) s waiting", err)]
+    return dict(worker_time=worker_time, engine_calls=calls, partial_chunk_calls=partial, tail_flushes=tails, engine_counters=counters,
                 eager_share=round(eager / max(calls, 1), 4),
                 # what is eager by construction: the sub-chunk remainder of sessions that end (one call per group of sessions that end
                 # together) and the tail flush behind it; everything else should be a graph replay
