@@ -38,7 +38,7 @@ their status.  Streams are independent units: rank r owns its own streams on GPU
 scaling, no data-path collective; torch.distributed (RCCL) only lines the ranks up (barrier) and takes
 the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line on rank 0 (< 3 KB: headline, `configs`, `roofline`, `cpu_baseline`, `f32_engine`, `token_agreement`
+Prints ONE JSON line on rank 0 (~4 KB: headline, `configs`, `roofline`, `cpu_baseline`, `f32_engine`, `token_agreement`
 first); per-kernel tables, every region's time and the notes go to gpurun_out/bench_details.json.
 """
 from __future__ import annotations
@@ -798,7 +798,7 @@ def main():
         if emb_gpu_ms > 0:
             ach = spk_flops / (emb_gpu_ms * 1e-3) / 1e12
             d["roofline"] = dict(bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
-                                 kernel="TitaNet-L launch sequence of one nasr_diar_embed call (13 x k_spk_gemm at 160 x 128 segment tiles + front / SE / pooling kernels), run alone",
+                                 kernel="TitaNet-L launch sequence (one nasr_diar_embed call, alone)",
                                  avg_launch_us=round(1e3 * emb_gpu_ms, 1), launches_per_step=1)
         d["step_mfma_frac"] = round((asr["flops_per_step"] + spk_flops + vad_flops) / t_ov / 1e12 / MFMA_PEAK_TFLOPS, 4)
         d["embed_gpu_ms"], d["vad_gpu_ms"] = round(emb_gpu_ms, 3), round(vad_gpu_ms, 3)
