@@ -38,7 +38,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned sg_u32x4;          // a pla
 #define SG_ABLATE 0          // probe builds only: 1 = no MFMAs, 2 = no loads (LDS-DMA / register loads), 3 = no fragment reads and no loads (MFMAs alone), 4 = no barrier
 #endif
 #ifdef SG_STAMPS
-#define SGSTAMP(i) do { if (threadIdx.x == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SGSTAMP(i) do { if (threadIdx.x == 0 && p.stamps) { p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); p.stamps[(size_t)blockIdx.x * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)      // [0, 4): 100 MHz real time, [4, 8): core clock
 #else
 #define SGSTAMP(i) do { } while (0)
 #endif
@@ -169,15 +169,17 @@ __device__ __forceinline__ void sg_combine(float *stage, const float *y_rows, in
 }  // namespace
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------------------------------------
-// LOOP 0: both operands through the LDS ring (4 slots of 18 KiB, three in flight), waves 2 x 2 (80 rows x 64 columns each).  Stamps of that form with cold
-//         operands (tests/micro/spk_gemm_probe.hip, 96 segments): 0.5-0.7 us per 32-deep chunk against 0.13 us of MFMA time -- the two co-resident
-//         workgroups keep 2 x 3 x 18 KiB = 110 KB in flight, and 110 KB per ~2 us of memory latency is exactly the 55 GB/s per CU they move: the
-//         loop is bound by the BYTES IN FLIGHT the LDS can hold, not by issue, LDS bandwidth or the matrix pipe.
-// LOOP 1: the registers take half of the in-flight bytes.  Waves 1 x 4: a wave owns 32 columns and ALL 160 rows, so its two weight fragments per chunk are its own
-//         (no second wave needs them): they come straight from global memory into a ring of 8 VGPR sets (global_load_dwordx4 in asm, counted by hand: 2 KB per
-//         wave and chunk, contiguous KiB in the packed weight layout), six chunks ahead; the LDS ring carries only the activation panel (10 KiB per chunk,
-//         7 slots, six in flight).  Per workgroup 6 x (10 + 8) = 108 KB in flight instead of 55.  One s_waitcnt vmcnt(25) per chunk covers both queues:
-//         every iteration issues the same group (3 LDS-DMA + 2 register loads) in the same order.  Needs K / 32 a multiple of 8.
+// LOOP 0: both operands through the LDS ring (4 slots of 18 KiB, three in flight), waves 2 x 2 (80 rows x 64 columns each).
+// LOOP 1: waves 1 x 4: a wave owns 32 columns and ALL 160 rows, so its two weight fragments per chunk are its own (no second wave needs them): they come straight from global
+//         memory into a ring of 8 VGPR sets (global_load_dwordx4 in asm, counted by hand: 2 KB per wave and chunk, contiguous KiB in the packed weight layout), six chunks ahead;
+//         the LDS ring carries only the activation panel (10 KiB per chunk, 7 slots, six in flight).  One s_waitcnt vmcnt(25) per chunk covers both queues: every iteration issues
+//         the same group (3 LDS-DMA + 2 register loads) in the same order.  Needs K / 32 a multiple of 8.
+// What the stamps say (tests/micro/spk_gemm_probe.hip, 96 segments, profiles/r6_titanet_segment_tiles.md): LOOP 0 takes 0.51-0.66 us per 32-deep chunk; MFMAs ALONE (no loads, no
+// fragment reads) take 0.37 us -- 2.05 GHz measured, ~19 cycles per v_mfma_f32_16x16x32_bf16 back to back from two waves per SIMD.  LOOP 1 was built on the theory that the loop was
+// short of BYTES IN FLIGHT (2 workgroups x 3 x 18 KiB per CU against ~2 us of latency); with twice the bytes in flight it takes 0.59 us per chunk instead of 0.63: the theory was
+// wrong.  Nor do hot operands, all fragment reads ahead of the MFMAs, or no barrier move it.  What is left as the bound: the CU's vector-memory path (18 KiB per workgroup and chunk at
+// 64 B per cycle = 288 cycles against 320-380 of MFMA, two workgroups per CU) next to the matrix pipe.  The two loops measure the same per launch; LOOP 1 ships where it applies because it
+// is the one the round's parity runs and GPU suite exercised (launch_spk_gemm).
 template <int MODE, int LOOP>
 __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     constexpr int NT = SG_THREADS;

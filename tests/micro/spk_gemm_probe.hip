@@ -92,16 +92,17 @@ int main(int argc, char **argv) {
         std::vector<unsigned long long> h(nwg * 8);
         CK(hipMemcpy(h.data(), stamps, nwg * 64, hipMemcpyDeviceToHost));
         unsigned long long t_min = ~0ull, t_max = 0;
-        double pro = 0, loop = 0, epi = 0, life = 0;
+        double pro = 0, loop = 0, epi = 0, life = 0, clk_num = 0, clk_den = 0;
         for (size_t w = 0; w < nwg; w++) {
             const unsigned long long *t = &h[w * 8];
+            clk_num += (double)(t[4 + 2] - t[4 + 1]); clk_den += (double)(t[2] - t[1]);          // core-clock ticks / 100 MHz ticks over the K loop
             t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[3]);
             pro += (double)(t[1] - t[0]); loop += (double)(t[2] - t[1]); epi += (double)(t[3] - t[2]); life += (double)(t[3] - t[0]);
         }
         const double c = 0.01 / nwg;     // 100 MHz ticks -> us, mean over workgroups
         printf("%-24s %7.1f us  %6.0f TFLOP/s | stamped launch %6.1f us; per workgroup: prologue %5.2f  K loop %6.2f (%5.3f us per chunk)  epilogue %6.2f  lifetime %6.2f us; "
-               "%zu workgroups, lifetime sum / (launch x 512 slots) = %.2f\n",
-               sh.name, us, tf, (t_max - t_min) * 0.01, pro * c, loop * c, loop * c / (sh.K / 32 - 1), epi * c, life * c, nwg, life * 0.01 / ((t_max - t_min) * 0.01 * 512));
+               "%zu workgroups, lifetime sum / (launch x 512 slots) = %.2f; core clock during the K loops %.2f GHz\n",
+               sh.name, us, tf, (t_max - t_min) * 0.01, pro * c, loop * c, loop * c / (sh.K / 32 - 1), epi * c, life * c, nwg, life * 0.01 / ((t_max - t_min) * 0.01 * 512), clk_den > 0 ? clk_num / clk_den * 0.1 : 0.0);
     }
     return 0;
 }
