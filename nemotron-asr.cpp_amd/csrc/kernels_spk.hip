@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(4))) float sg_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned sg_u32x4;          // a plain vector type: asm operands of HIP's uint4 class live in memory
 
 #ifndef SG_ABLATE
-#define SG_ABLATE 0          // probe builds only: 1 = no MFMAs, 2 = no loads (LDS-DMA / register loads), 3 = no fragment reads and no loads (MFMAs alone), 4 = no barrier
+#define SG_ABLATE 0          // probe builds only (tests/micro/spk_gemm_probe.hip, LOOP 1): 2 = no loads (LDS-DMA / register loads), 3 = no fragment reads and no loads (MFMAs alone), 4 = no barrier
 #endif
 #ifdef SG_STAMPS
 #define SGSTAMP(i) do { if (threadIdx.x == 0 && p.stamps) { p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); p.stamps[(size_t)blockIdx.x * 8 + 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)      // [0, 4): 100 MHz real time, [4, 8): core clock
@@ -314,7 +314,6 @@ __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
             __builtin_amdgcn_sched_barrier(0);                                                                                   \
             _Pragma("unroll") for (int mt = 0; mt < 10; mt++) {                                                                  \
                 const sg_bf16x8 bf = __builtin_bit_cast(sg_bf16x8, bv[mt]);                                                      \
-                if (SG_ABLATE == 1) { acc[mt][0] += __uint_as_float(bv[mt].x ^ wA##set[0]); acc[10 + mt][0] += __uint_as_float(bv[mt].y ^ wB##set[1]); continue; } \
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wA##set), bf, acc[mt], 0, 0, 0); \
                 acc[10 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_bf16x8, wB##set), bf, acc[10 + mt], 0, 0, 0); \
             }                                                                                                                    \
