@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "gguf_reader.h"
@@ -91,7 +92,18 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
-    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE... | chunks T SAMPLES... | jsonint DEFAULT JSON...\n", argv[0]); return 2; }
+    if (argc >= 6 && !strcmp(argv[1], "pickcall")) {    // pickcall T ROW_BUDGET MAX_STREAMS PENDING...: the batch former's choice for one call -> "G take0 take1 ..." (host logic test)
+        const int T = atoi(argv[2]), budget = atoi(argv[3]), cap = atoi(argv[4]), n = argc - 5;
+        std::vector<int> pend((size_t)n);
+        for (int i = 0; i < n; i++) pend[(size_t)i] = atoi(argv[5 + i]);
+        std::unique_ptr<bool[]> take(new bool[(size_t)n]);
+        const int G = nasr_proto::pick_call(pend.data(), n, T, budget, cap, take.get());
+        printf("%d", G);
+        for (int i = 0; i < n; i++) printf(" %d", take[(size_t)i] ? 1 : 0);
+        printf("\n");
+        return 0;
+    }
+    if (argc < 3) { fprintf(stderr, "usage: %s gguf|frames FILE... | chunks T SAMPLES... | jsonint DEFAULT JSON... | pickcall T ROW_BUDGET MAX_STREAMS PENDING...\n", argv[0]); return 2; }
     int rc = 0;
     for (int i = 2; i < argc; i++) rc |= !strcmp(argv[1], "gguf") ? run_gguf(argv[i]) : run_frames(argv[i]);
     return rc;

@@ -228,24 +228,16 @@ void worker_loop(Lane *lane) {
             const int T = g.first;
             std::vector<uint32_t> ids = g.second;
             if ((int)ids.size() * T > row_budget) { ids.resize((size_t)(row_budget / T)); more = true; }
-            // chunks per session in this call: the power of two G (every (streams, chunks) pair is a step shape with graphs of its own, ~20 ms to capture: a backlog
-            // is worked off in 8 + 4 + 2 + 1 rather than in 13 different sizes) that carries the most rows -- sessions holding fewer than G chunks wait for the
-            // next call instead of pulling the whole call down to their count (round 6: one late session made a 64-stream call single-chunk)
+            // chunks per session in this call and who takes part: nasr_proto::pick_call (server_protocol.h; tests/test_sanitizers.py checks the rule on the host)
             int G = 1;
             {
-                // 248: a call's samples stay below the engine's MAX_PUSH (256 encoder frames); and no more chunks per session than leave room for EVERY
-                // session of a full server in the call (a few sessions with a deep backlog must not crowd the others out of the launch)
-                const int gmax = std::max(1, std::min(248 / T, row_budget / (std::max(1, model->max_streams) * T)));
-                long best_rows = 0;
-                for (int g = 1; g <= gmax; g <<= 1) {
-                    int n_g = 0;
-                    for (uint32_t id : ids) n_g += sessions[id].whole_chunks_pending() >= g;
-                    n_g = std::min(n_g, row_budget / (g * T));
-                    if (n_g > 0 && (long)n_g * g >= best_rows) { best_rows = (long)n_g * g; G = g; }
-                }
+                std::vector<int> pend(ids.size());
+                for (size_t b = 0; b < ids.size(); b++) pend[b] = sessions[ids[b]].whole_chunks_pending();
+                std::unique_ptr<bool[]> take(new bool[ids.size()]);
+                G = nasr_proto::pick_call(pend.data(), (int)ids.size(), T, row_budget, model->max_streams, take.get());
                 std::vector<uint32_t> keep;
-                for (uint32_t id : ids) {
-                    if (sessions[id].whole_chunks_pending() >= G && (int)keep.size() < row_budget / (G * T)) keep.push_back(id);
+                for (size_t b = 0; b < ids.size(); b++) {
+                    if (take[b]) keep.push_back(ids[b]);
                     else more = true;
                 }
                 ids.swap(keep);

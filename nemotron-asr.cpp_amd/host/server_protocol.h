@@ -68,4 +68,34 @@ inline int64_t chunks_after(int64_t samples, int T) {
     return frames / (8 * T);
 }
 
+// The batch former's choice for ONE engine call (host/nemo_server.cpp, worker_loop::form_calls): `pending[i]` = whole chunks session i of one lookahead group holds (> 0),
+// T = 1 + right_context rows per chunk, row_budget = rows one launch sequence may carry (nasr_engine_create_ex: workspace_rows), max_streams = the server's session capacity.
+// Returns G, the chunks every chosen session completes in the call, and marks the chosen sessions in `take` (first come, first served, at most row_budget / (G T) of them):
+//   * G is a power of two (every (streams, chunks) pair is a step shape with hipGraphs of its own: a backlog is worked off in 8 + 4 + 2 + 1, not in 13 sizes);
+//   * G T <= 248 rows per session (a call's samples stay below the engine's MAX_PUSH of 256 encoder frames) and G <= row_budget / (max_streams T): never more chunks per
+//     session than leave room for EVERY session of a full server (round 6: without this cap the rule below picked 16 chunks x 16 streams);
+//   * among those, the G that carries the most rows; sessions holding fewer than G chunks are left for the next call instead of pulling the call down to their count; ties -> larger G.
+inline int pick_call(const int *pending, int n, int T, int row_budget, int max_streams, bool *take) {
+    for (int i = 0; i < n; i++) take[i] = false;
+    if (n <= 0 || T <= 0) return 0;
+    int gmax = 248 / T;
+    const int per_session = row_budget / ((max_streams > 0 ? max_streams : 1) * T);
+    if (per_session < gmax) gmax = per_session;
+    if (gmax < 1) gmax = 1;
+    int G = 1;
+    long best_rows = 0;
+    for (int g = 1; g <= gmax; g <<= 1) {
+        int n_g = 0;
+        for (int i = 0; i < n; i++) n_g += pending[i] >= g;
+        const int room = row_budget / (g * T);
+        if (n_g > room) n_g = room;
+        if (n_g > 0 && (long)n_g * g >= best_rows) { best_rows = (long)n_g * g; G = g; }
+    }
+    int room = row_budget / (G * T), taken = 0;
+    if (room < 1) room = 1;                    // a single session always fits: the engine cuts an over-long push into pieces itself
+    for (int i = 0; i < n && taken < room; i++)
+        if (pending[i] >= G) { take[i] = true; taken++; }
+    return G;
+}
+
 }  // namespace nasr_proto

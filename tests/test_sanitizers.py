@@ -218,3 +218,48 @@ def test_batch_former_chunk_arithmetic_equals_the_oracles_stream_manager(harness
         assert [k for _, k, _ in rows] == want, (R, list(zip(cuts, want, [k for _, k, _ in rows]))[:8])
         for S, k, need in rows:
             assert need <= S and (k == 0 or need > 0)
+
+
+def _pick_call(harness, T, budget, cap, pending):
+    r = subprocess.run([str(harness), "pickcall", str(T), str(budget), str(cap)] + [str(x) for x in pending], capture_output=True, text=True, env=dict(os.environ, **SAN_ENV), timeout=60)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-500:]
+    out = [int(x) for x in r.stdout.split()]
+    return out[0], out[1:]
+
+
+def test_batch_former_picks_the_chunk_count_that_carries_the_most_rows(harness):
+    """host/server_protocol.h: pick_call -- what one engine call of the server carries when sessions hold several whole chunks (round 6: `--backlog-chunks`, nasr_engine_create_ex).
+    The cases that went wrong or could: one late session must not pull a 64-stream call down to one chunk; sessions with a deep backlog must not crowd the others out (the first
+    version of the rule picked 16 chunks x 16 streams); a group larger than the launch's row budget is cut; and on random inputs the choice is a power of two within every bound
+    that carries at least as many rows as any other admissible power of two."""
+    T, budget, cap = 14, 64 * 14 * 4, 64                       # 64 streams x R = 13, --backlog-chunks 4
+    G, take = _pick_call(harness, T, budget, cap, [4] * 64)
+    assert G == 4 and sum(take) == 64
+    G, take = _pick_call(harness, T, budget, cap, [4] * 63 + [1])
+    assert G == 4 and sum(take) == 63 and take[-1] == 0          # 63 x 4 rows beat 64 x 1; the late session waits for the next call
+    G, take = _pick_call(harness, T, budget, cap, [16] * 64)
+    assert G == 4 and sum(take) == 64                            # never more chunks per session than leave room for every session of a full server
+    G, take = _pick_call(harness, T, budget, cap, [1] * 64)
+    assert G == 1 and sum(take) == 64                            # live streams: one chunk each, everybody
+    G, take = _pick_call(harness, T, 64 * 14, 64, [3] * 100)
+    assert G == 1 and sum(take) == 64 and take[:64] == [1] * 64  # --backlog-chunks 1: the launch takes 64 sessions, first come first served
+    G, take = _pick_call(harness, 1, 3584, 64, [1, 1, 1, 8])
+    assert G == 8 and take == [0, 0, 0, 1]                       # R = 0: eight chunks of one session are more rows than one chunk of four
+    rng = np.random.default_rng(11)
+    for _ in range(120):
+        T = int(rng.choice([1, 2, 7, 14]))
+        cap = int(rng.integers(1, 96))
+        budget = max(cap * 14 * int(rng.integers(1, 9)), 256)
+        n = int(rng.integers(1, 120))
+        pending = [int(x) for x in rng.integers(1, 20, n)]
+        G, take = _pick_call(harness, T, budget, cap, pending)
+        gmax = max(1, min(248 // T, budget // (cap * T)))
+        assert G >= 1 and G & (G - 1) == 0 and G <= gmax, (G, gmax)
+        assert all(p >= G for p, t in zip(pending, take) if t) and sum(take) >= 1
+        assert sum(take) * G * T <= budget or sum(take) == 1
+        rows = sum(take) * G
+        g = 1
+        while g <= gmax:
+            n_g = min(sum(p >= g for p in pending), budget // (g * T))
+            assert rows >= n_g * g, (T, cap, budget, pending, G, g)
+            g *= 2
