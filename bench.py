@@ -797,7 +797,15 @@ def main():
         asr = step_roofline(args.layers, r.B, r.R, t_ov, 1.0625 if args.weights == "q8_0" else 2.0)
         if emb_gpu_ms > 0:
             ach = spk_flops / (emb_gpu_ms * 1e-3) / 1e12
-            d["roofline"] = dict(bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+            # fabric traffic of one embedding call from the PMC passes (tests/prof_diar_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE, summed over the call's 40 launches); profiled at 96 sub-segments
+            traffic = None
+            try:
+                pj = json.loads((ROOT / "profiles" / "r6_pmc_traffic_diar.json").read_text())["embed_call_96_segments"]
+                if n_seg == 96 and not pj["kernels_without_counters"]:
+                    traffic = int(pj["hbm_bytes_corrected"])
+            except (OSError, KeyError, ValueError):
+                pass
+            d["roofline"] = dict(bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                                  kernel="TitaNet-L launch sequence (one nasr_diar_embed call, alone)",
                                  avg_launch_us=round(1e3 * emb_gpu_ms, 1), launches_per_step=1)
         d["step_mfma_frac"] = round((asr["flops_per_step"] + spk_flops + vad_flops) / t_ov / 1e12 / MFMA_PEAK_TFLOPS, 4)
