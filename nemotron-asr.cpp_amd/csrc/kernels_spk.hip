@@ -178,8 +178,8 @@ __device__ __forceinline__ void sg_combine(float *stage, const float *y_rows, in
 // fragment reads) take 0.37 us -- 2.05 GHz measured, ~19 cycles per v_mfma_f32_16x16x32_bf16 back to back from two waves per SIMD.  LOOP 1 was built on the theory that the loop was
 // short of BYTES IN FLIGHT (2 workgroups x 3 x 18 KiB per CU against ~2 us of latency); with twice the bytes in flight it takes 0.59 us per chunk instead of 0.63: the theory was
 // wrong.  Nor do hot operands, all fragment reads ahead of the MFMAs, or no barrier move it.  What is left as the bound: the CU's vector-memory path (18 KiB per workgroup and chunk at
-// 64 B per cycle = 288 cycles against 320-380 of MFMA, two workgroups per CU) next to the matrix pipe.  The two loops measure the same per launch; LOOP 1 ships where it applies because it
-// is the one the round's parity runs and GPU suite exercised (launch_spk_gemm).
+// 64 B per cycle = 288 cycles against 320-380 of MFMA, two workgroups per CU) next to the matrix pipe.  The two loops measure the same per launch in the probe and within 2 % per call
+// (LOOP 1 the shorter); LOOP 1 ships where it applies (launch_spk_gemm).
 template <int MODE, int LOOP>
 __global__ __launch_bounds__(SG_THREADS, 2) void k_spk_gemm(SpkGemmParams p) {
     constexpr int NT = SG_THREADS;
@@ -656,7 +656,8 @@ int launch_spk_gemm(const SpkGemmParams &p, hipStream_t st) {
     if (spk_gemm_check(p)) return -1;
     const dim3 grid((unsigned)(p.S * (p.N / SG_BN))), block(SG_THREADS);
     // the register-ring loop where K / 32 is a multiple of 8 (the 1024-deep GEMMs); the all-LDS loop for the two 128-deep ones.  NASR_SPK_LOOP=0 forces the latter (A/B).
-    // Per launch the two measure the same (profiles/r6_titanet_segment_tiles.md); LOOP 1 is the default because it is the one the round's parity runs and GPU suite exercised.
+    // Per launch in the probe the two measure the same; a whole embedding call is 1-2 % shorter with LOOP 1 (1.200 against 1.214-1.222 ms on the device, same box, twice) and a
+    // configs[4] step the same (4.48-4.50 ms): profiles/r6_titanet_segment_tiles.md.  LOOP 1 is the default; it is also the one the round's parity runs and GPU suite exercised.
     static const int force0 = []() { const char *e = getenv("NASR_SPK_LOOP"); return e && e[0] == '0' ? 1 : 0; }();
     const bool regs = !force0 && (p.K / 32) % 8 == 0;
 #define SG_LAUNCH(M_) do { if (regs) hipLaunchKernelGGL((k_spk_gemm<M_, 1>), grid, block, SG_LDS, st, p); else hipLaunchKernelGGL((k_spk_gemm<M_, 0>), grid, block, SG_LDS, st, p); } while (0)
